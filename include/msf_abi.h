@@ -1,0 +1,150 @@
+/*
+ * msf_abi.h -- C ABI of the MI355X-native feature extraction + matching stage.
+ *
+ * This is the drop-in boundary for the matcher hot path of
+ * Kolkir/mono_slam_framework.  Every entry point names the reference interface
+ * it replaces (paths relative to the reference tree):
+ *
+ *   slam_pipeline/include/FeatureMatcher.h:41-47   abstract FeatureMatcher::MatchFrames
+ *   slam_pipeline/include/FeatureMatcher.h:15-19   MatchFramesResult {keyPoints1, keyPoints2}
+ *   src/featurematcher.h:7-22,   src/featurematcher.cpp:3-47      ORB matcher
+ *   src/dnnfeaturematcher.h:9-36, src/dnnfeaturematcher.cpp:11-102 LoFTR (ONNX) matcher
+ *
+ * Plain C: no C++ types, no exceptions, no torch types.  All functions return
+ * MSF_OK (0) or a negative msf_status; msf_last_error() gives the text.  The
+ * reference signals no errors (it returns an empty MatchFramesResult when
+ * either descriptor set is empty, featurematcher.cpp:23); the C++ adapter
+ * (mono_slam_framework_amd/csrc/hip_feature_matcher.h) maps any non-zero status
+ * to an empty result.
+ *
+ * Threading: the reference calls MatchFrames from one thread at a time, but a
+ * different std::async thread per frame (src/main.cpp:131-139).  Every entry
+ * point therefore selects the handle's device itself and serialises on a
+ * per-handle mutex.
+ */
+#ifndef MSF_ABI_H
+#define MSF_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSF_ABI_VERSION 1
+
+typedef struct msf_handle msf_handle;
+
+typedef enum msf_status {
+  MSF_OK = 0,
+  MSF_ERR_INVALID_ARG = -1,
+  MSF_ERR_HIP = -2,          /* a HIP runtime call failed (no GPU, OOM, launch failure) */
+  MSF_ERR_UNSUPPORTED = -3,  /* e.g. LoFTR at a size other than 640x480 (the ONNX graph is fixed-shape) */
+  MSF_ERR_CAPACITY = -4,     /* a fixed-capacity device list overflowed; per-pair n_out is -1 for that pair */
+  MSF_ERR_IO = -5            /* weights file missing / malformed */
+} msf_status;
+
+typedef enum msf_kind {
+  MSF_KIND_ORB = 0,   /* replaces ::FeatureMatcher      (src/featurematcher.cpp) */
+  MSF_KIND_LOFTR = 1  /* replaces ::DNNFeatureMatcher   (src/dnnfeaturematcher.cpp) */
+} msf_kind;
+
+/* msf_config.flags */
+#define MSF_FLAG_BLUR_TIE_HALF_UP 1u /* ORB 7x7 blur: (sum+32768)>>16 instead of round-half-even */
+#define MSF_FLAG_PROFILE 2u          /* record per-stage HIP events on the launch stream (msf_stage_times) */
+
+typedef struct msf_config {
+  uint32_t struct_size;      /* sizeof(msf_config) */
+  int32_t kind;              /* msf_kind */
+  int32_t device;            /* HIP device ordinal */
+  float threshold;           /* ORB: Lowe ratio (featurematcher.h:9 default 0.8f, app uses 0.6f src/main.cpp:66)
+                                LoFTR: confidence threshold (dnnfeaturematcher.h:11 default 0.15f) */
+  int32_t image_width;       /* all frames of one handle share one size (dnnfeaturematcher.h:12-13) */
+  int32_t image_height;
+  int32_t max_batch_pairs;   /* device workspace is sized for this many pairs per call */
+  uint32_t flags;
+  const char* weights_path;  /* LoFTR weights blob; NULL = <library dir>/weights/loftr_teacher.bin */
+} msf_config;
+
+/* FrameBase::imGray as the matchers read it (slam_pipeline/include/FrameBase.h:45):
+ * 8-bit single channel, any row stride. */
+typedef struct msf_image {
+  const uint8_t* data;
+  int32_t width, height;
+  int64_t stride; /* bytes between rows */
+} msf_image;
+
+/* one element of MatchFramesResult::keyPoints1/keyPoints2 (cv::Point2i pair) */
+typedef struct msf_match {
+  int32_t x1, y1, x2, y2;
+} msf_match;
+
+/* one extracted ORB feature (cv::KeyPoint subset + level coordinates), 32 bytes */
+typedef struct msf_keypoint {
+  float x, y;       /* cv::KeyPoint::pt, level-0 coordinates */
+  float response;   /* Harris response */
+  float angle;      /* degrees */
+  int32_t octave;
+  int32_t lx, ly;   /* integer coordinates inside the pyramid level */
+  int32_t fast_score;
+} msf_keypoint;
+
+int msf_abi_version(void);
+void msf_default_config(msf_config* cfg, int kind);
+
+/* FeatureMatcher::FeatureMatcher(threshold) / DNNFeatureMatcher::DNNFeatureMatcher(path, threshold, w, h, res)
+ * (featurematcher.cpp:3-6, dnnfeaturematcher.cpp:11-40) */
+int msf_create(const msf_config* cfg, msf_handle** out);
+/* ~FeatureMatcher (featurematcher.cpp:8) */
+void msf_destroy(msf_handle* h);
+/* FeatureMatcher::SetThreshold / DNNFeatureMatcher::SetThreshold (featurematcher.cpp:47, dnnfeaturematcher.cpp:103) */
+int msf_set_threshold(msf_handle* h, float value);
+const char* msf_last_error(const msf_handle* h); /* h may be NULL: error of the last failed msf_create */
+
+/* FeatureMatcher::MatchFrames(pF1, pF2) (featurematcher.cpp:10-45, dnnfeaturematcher.cpp:44-102):
+ * host images in, host match list out.  Writes min(n, cap) matches, *n_out = n. */
+int msf_match_pair(msf_handle* h, const msf_image* a, const msf_image* b,
+                   msf_match* out, int32_t cap, int32_t* n_out);
+/* n_pairs independent MatchFrames calls in one launch sequence; out is [n_pairs][cap_per_pair] */
+int msf_match_batch(msf_handle* h, int32_t n_pairs, const msf_image* a, const msf_image* b,
+                    msf_match* out, int32_t cap_per_pair, int32_t* n_out);
+
+/* HBM-resident batch (throughput path): d_a/d_b are DEVICE pointers to n_pairs frames each,
+ * frame i at d_x + i*frame_stride, rows row_stride bytes apart (both multiples of 16, base 16-aligned).
+ * d_out [n_pairs][cap_per_pair] and d_n_out [n_pairs] are device buffers.  Asynchronous on `stream`
+ * (a hipStream_t; NULL = the handle's own stream, which is then synchronised before returning). */
+int msf_match_batch_device(msf_handle* h, int32_t n_pairs, const uint8_t* d_a, const uint8_t* d_b,
+                           int64_t frame_stride, int64_t row_stride,
+                           msf_match* d_out, int32_t cap_per_pair, int32_t* d_n_out, void* stream);
+
+/* "next" row 1 of SURVEY.md 8f: extract once per frame, match many (ORB only).
+ * Features stay in the handle's device feature slots [0, 2*max_batch_pairs). */
+int msf_extract_device(msf_handle* h, int32_t n_frames, const uint8_t* d_frames, int64_t frame_stride,
+                       int64_t row_stride, int32_t first_slot, void* stream);
+int msf_match_slots_device(msf_handle* h, int32_t n_pairs, const int32_t* d_slot_a, const int32_t* d_slot_b,
+                           msf_match* d_out, int32_t cap_per_pair, int32_t* d_n_out, void* stream);
+
+/* -------- introspection used by the parity tests and bench.py (not by the drop-in path) -------- */
+typedef enum msf_debug_what {
+  MSF_DBG_LEVEL_SIZES = 0,   /* int32 [nlevels][4] = w, h, row pitch, quota */
+  MSF_DBG_LEVEL_PIXELS = 1,  /* uint8 [h][pitch] of (slot, level); level 0 is the input frame itself (not kept) */
+  MSF_DBG_FAST_CANDS = 2,    /* int32 [n][3] (x, y, score) of (slot, level), unordered */
+  MSF_DBG_KEYPOINTS = 3,     /* msf_keypoint [n] of slot */
+  MSF_DBG_DESCRIPTORS = 4,   /* uint8 [n][32] of slot */
+  MSF_DBG_STAGE1 = 5,        /* msf_keypoint [n] (lx, ly, octave, fast_score, response) of (slot, level), unordered */
+  MSF_DBG_LOFTR_CONF = 6,    /* float [1200][1200] confidence matrix of pair `slot` (debug launch only) */
+  MSF_DBG_LOFTR_FEAT = 7     /* float [2][1200][32] coarse features after the transformer of pair `slot` */
+} msf_debug_what;
+/* copies to host; *n_bytes = bytes available (may exceed cap_bytes, then only cap_bytes are written) */
+int msf_debug_get(msf_handle* h, int32_t what, int32_t slot, int32_t level,
+                  void* host_out, size_t cap_bytes, size_t* n_bytes);
+
+/* per-stage device time of the LAST batch call, measured with HIP events on the launch stream
+ * (needs MSF_FLAG_PROFILE).  names[i] are static strings.  Returns the number of stages. */
+int msf_stage_times(msf_handle* h, const char** names, float* ms, int32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSF_ABI_H */

@@ -1,0 +1,81 @@
+"""ctypes view of include/msf_abi.h.  Loading fails loudly when libmsf.so is missing: there is no CPU fallback."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+MSF_OK = 0
+MSF_ERR_INVALID_ARG = -1
+MSF_ERR_HIP = -2
+MSF_ERR_UNSUPPORTED = -3
+MSF_ERR_CAPACITY = -4
+MSF_ERR_IO = -5
+
+MSF_KIND_ORB = 0
+MSF_KIND_LOFTR = 1
+
+MSF_FLAG_BLUR_TIE_HALF_UP = 1
+MSF_FLAG_PROFILE = 2
+
+(DBG_LEVEL_SIZES, DBG_LEVEL_PIXELS, DBG_FAST_CANDS, DBG_KEYPOINTS, DBG_DESCRIPTORS, DBG_STAGE1,
+ DBG_LOFTR_CONF, DBG_LOFTR_FEAT) = range(8)
+
+# every symbol include/msf_abi.h declares
+ABI_SYMBOLS = ["msf_abi_version", "msf_default_config", "msf_create", "msf_destroy", "msf_set_threshold",
+               "msf_last_error", "msf_match_pair", "msf_match_batch", "msf_match_batch_device",
+               "msf_extract_device", "msf_match_slots_device", "msf_debug_get", "msf_stage_times"]
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("kind", C.c_int32), ("device", C.c_int32), ("threshold", C.c_float),
+                ("image_width", C.c_int32), ("image_height", C.c_int32), ("max_batch_pairs", C.c_int32),
+                ("flags", C.c_uint32), ("weights_path", C.c_char_p)]
+
+
+class Image(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("stride", C.c_int64)]
+
+
+MATCH_DTYPE = np.dtype([("x1", "<i4"), ("y1", "<i4"), ("x2", "<i4"), ("y2", "<i4")])
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<f4"), ("angle", "<f4"),
+                     ("octave", "<i4"), ("lx", "<i4"), ("ly", "<i4"), ("fast_score", "<i4")])
+
+_lib = None
+
+
+def load():
+    """Loads libmsf.so (after torch, if torch is importable, so both share one HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    try:
+        import torch  # noqa: F401  (torch bundles its own libamdhip64.so.7; load it first)
+    except Exception:  # pragma: no cover
+        pass
+    path = _build.lib_path()
+    L = C.CDLL(path, mode=C.RTLD_GLOBAL if hasattr(C, "RTLD_GLOBAL") else 0)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    L.msf_abi_version.restype = C.c_int
+    L.msf_default_config.argtypes = [C.POINTER(Config), C.c_int]
+    L.msf_default_config.restype = None
+    L.msf_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.msf_destroy.argtypes = [vp]
+    L.msf_destroy.restype = None
+    L.msf_set_threshold.argtypes = [vp, f32]
+    L.msf_last_error.argtypes = [vp]
+    L.msf_last_error.restype = C.c_char_p
+    L.msf_match_pair.argtypes = [vp, C.POINTER(Image), C.POINTER(Image), vp, i32, C.POINTER(i32)]
+    L.msf_match_batch.argtypes = [vp, i32, C.POINTER(Image), C.POINTER(Image), vp, i32, vp]
+    L.msf_match_batch_device.argtypes = [vp, i32, vp, vp, i64, i64, vp, i32, vp, vp]
+    L.msf_extract_device.argtypes = [vp, i32, vp, i64, i64, i32, vp]
+    L.msf_match_slots_device.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp]
+    L.msf_debug_get.argtypes = [vp, i32, i32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.msf_stage_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(f32), i32]
+    _lib = L
+    return L
+
+
+def default_weights_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "weights", "loftr_teacher.bin")

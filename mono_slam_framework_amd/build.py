@@ -13,7 +13,7 @@ HIP_SOURCES = ["msf_abi.cpp", "orb_kernels.hip", "loftr_kernels.hip"]
 # -ffp-contract=off + correctly rounded f32 divide: the few f32 steps inside ORB
 # (Harris response, fastAtan2, pattern rotation) must round exactly like the CPU.
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-             "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+             "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 
 def _stale(target, deps):

@@ -1,0 +1,32 @@
+// LoFTR_teacher (coarse-only, d_model 32, linear attention) on gfx950: host-side launcher interface.
+// Replaces Ort::Session::Run + the threshold/decode loop of ::DNNFeatureMatcher::MatchFrames
+// (src/dnnfeaturematcher.cpp:44-102).  Implemented in loftr_kernels.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "msf_abi.h"
+
+namespace msf {
+
+class LoftrPipeline {
+ public:
+  LoftrPipeline() = default;
+  ~LoftrPipeline();
+  // returns empty string on success; "io: ..." for weight-file problems
+  std::string init(const char* weights_path, int max_pairs, bool profile);
+  void destroy();
+  hipError_t match(int n_pairs, const uint8_t* d_a, const uint8_t* d_b, long long frame_stride, int row_stride,
+                   float threshold, msf_match* d_out, int cap_per_pair, int32_t* d_n_out, hipStream_t st);
+  int debug_get(int what, int slot, int level, void* host_out, size_t cap, size_t* n_bytes, std::string* err);
+  int stage_times(const char** names, float* ms, int cap);
+
+ private:
+  struct Impl;
+  Impl* p_ = nullptr;
+};
+
+}  // namespace msf

@@ -1,0 +1,281 @@
+// extern "C" boundary of libmsf.so (declarations + the reference interfaces they replace: include/msf_abi.h).
+#include "msf_abi.h"
+
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "loftr_pipeline.h"
+#include "orb_pipeline.h"
+
+namespace {
+thread_local std::string g_create_error;
+}
+
+struct msf_handle {
+  msf_config cfg{};
+  std::mutex mu;
+  std::string err;
+  hipStream_t stream = nullptr;
+  msf::OrbPipeline orb;
+  msf::LoftrPipeline loftr;
+  // staging for the host-image entry points
+  uint8_t* d_stage = nullptr;   // [2 * max_pairs][H][pitch]
+  msf_match* d_out = nullptr;   // [max_pairs][stage_cap]
+  int32_t* d_n = nullptr;       // [max_pairs]
+  int stage_pitch = 0;
+  long long stage_frame = 0;
+  int stage_cap = 0;
+};
+
+namespace {
+
+int fail(msf_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg; else g_create_error = msg;
+  return code;
+}
+
+int hip_fail(msf_handle* h, const char* what, hipError_t e) {
+  return fail(h, MSF_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+constexpr int kStageCap = 4096;  // matches per pair kept by the host-image path (ORB <= n1 <= 2048; LoFTR: see below)
+
+int run_device(msf_handle* h, int n_pairs, const uint8_t* d_a, const uint8_t* d_b, long long frame_stride,
+               long long row_stride, msf_match* d_out, int cap, int32_t* d_n_out, hipStream_t st) {
+  if (n_pairs <= 0) return MSF_OK;
+  if (n_pairs > h->cfg.max_batch_pairs) return fail(h, MSF_ERR_INVALID_ARG, "n_pairs exceeds max_batch_pairs");
+  if (((uintptr_t)d_a | (uintptr_t)d_b | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 15)
+    return fail(h, MSF_ERR_INVALID_ARG, "device frames must be 16-byte aligned with strides multiple of 16");
+  if (row_stride < h->cfg.image_width) return fail(h, MSF_ERR_INVALID_ARG, "row_stride < image_width");
+  if (h->cfg.kind == MSF_KIND_ORB) {
+    msf::FrameSrc src{d_a, d_b, n_pairs, 0, frame_stride, (int)row_stride};
+    hipError_t e = h->orb.extract(src, 2 * n_pairs, st);
+    if (e != hipSuccess) return hip_fail(h, "orb extract", e);
+    e = h->orb.match(n_pairs, nullptr, nullptr, h->cfg.threshold, d_out, cap, d_n_out, st);
+    if (e != hipSuccess) return hip_fail(h, "orb match", e);
+    return MSF_OK;
+  }
+  hipError_t e = h->loftr.match(n_pairs, d_a, d_b, frame_stride, (int)row_stride, h->cfg.threshold, d_out, cap,
+                                d_n_out, st);
+  if (e != hipSuccess) return hip_fail(h, "loftr match", e);
+  return MSF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int msf_abi_version(void) { return MSF_ABI_VERSION; }
+
+void msf_default_config(msf_config* cfg, int kind) {
+  if (!cfg) return;
+  *cfg = msf_config{};
+  cfg->struct_size = sizeof(msf_config);
+  cfg->kind = kind;
+  cfg->device = 0;
+  cfg->threshold = kind == MSF_KIND_LOFTR ? 0.15f : 0.8f;  // dnnfeaturematcher.h:11 / featurematcher.h:9
+  cfg->image_width = 640;                                  // dnnfeaturematcher.h:12-13
+  cfg->image_height = 480;
+  cfg->max_batch_pairs = 1;
+  cfg->flags = 0;
+  cfg->weights_path = nullptr;
+}
+
+int msf_create(const msf_config* cfg, msf_handle** out) {
+  if (!cfg || !out) return fail(nullptr, MSF_ERR_INVALID_ARG, "msf_create: null argument");
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(msf_config)) return fail(nullptr, MSF_ERR_INVALID_ARG, "msf_create: struct_size mismatch");
+  if (cfg->kind != MSF_KIND_ORB && cfg->kind != MSF_KIND_LOFTR) return fail(nullptr, MSF_ERR_INVALID_ARG, "msf_create: bad kind");
+  if (cfg->max_batch_pairs < 1) return fail(nullptr, MSF_ERR_INVALID_ARG, "msf_create: max_batch_pairs < 1");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) return fail(nullptr, MSF_ERR_HIP, "msf_create: no HIP device (this library has no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, MSF_ERR_INVALID_ARG, "msf_create: device ordinal out of range");
+  if ((e = hipSetDevice(cfg->device)) != hipSuccess) return hip_fail(nullptr, "hipSetDevice", e);
+  msf_handle* h = new (std::nothrow) msf_handle();
+  if (!h) return fail(nullptr, MSF_ERR_HIP, "out of host memory");
+  h->cfg = *cfg;
+  h->cfg.weights_path = nullptr;
+  std::string err;
+  const bool profile = (cfg->flags & MSF_FLAG_PROFILE) != 0;
+  if (cfg->kind == MSF_KIND_ORB) {
+    err = h->orb.init(cfg->image_width, cfg->image_height, 2 * cfg->max_batch_pairs,
+                      (cfg->flags & MSF_FLAG_BLUR_TIE_HALF_UP) != 0, profile);
+  } else {
+    if (cfg->image_width != 640 || cfg->image_height != 480) {
+      delete h;
+      return fail(nullptr, MSF_ERR_UNSUPPORTED, "LoFTR_teacher is a fixed-shape 1x1x480x640 graph (model/LoFTR_teacher.onnx)");
+    }
+    err = h->loftr.init(cfg->weights_path, cfg->max_batch_pairs, profile);
+  }
+  if (!err.empty()) {
+    const bool io = err.rfind("io:", 0) == 0;
+    delete h;
+    return fail(nullptr, io ? MSF_ERR_IO : MSF_ERR_HIP, err);
+  }
+  if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) {
+    delete h;
+    return hip_fail(nullptr, "hipStreamCreate", e);
+  }
+  *out = h;
+  return MSF_OK;
+}
+
+void msf_destroy(msf_handle* h) {
+  if (!h) return;
+  hipSetDevice(h->cfg.device);
+  hipDeviceSynchronize();
+  h->orb.destroy();
+  h->loftr.destroy();
+  hipFree(h->d_stage);
+  hipFree(h->d_out);
+  hipFree(h->d_n);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int msf_set_threshold(msf_handle* h, float value) {
+  if (!h) return MSF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->cfg.threshold = value;
+  return MSF_OK;
+}
+
+const char* msf_last_error(const msf_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int msf_match_batch_device(msf_handle* h, int32_t n_pairs, const uint8_t* d_a, const uint8_t* d_b,
+                           int64_t frame_stride, int64_t row_stride, msf_match* d_out, int32_t cap_per_pair,
+                           int32_t* d_n_out, void* stream) {
+  if (!h) return MSF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (n_pairs < 0 || !d_a || !d_b || !d_out || !d_n_out || cap_per_pair < 1)
+    return fail(h, MSF_ERR_INVALID_ARG, "msf_match_batch_device: bad argument");
+  hipError_t e = hipSetDevice(h->cfg.device);
+  if (e != hipSuccess) return hip_fail(h, "hipSetDevice", e);
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  int rc = run_device(h, n_pairs, d_a, d_b, frame_stride, row_stride, d_out, cap_per_pair, d_n_out, st);
+  if (rc != MSF_OK) return rc;
+  if (!stream && (e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(h, "hipStreamSynchronize", e);
+  return MSF_OK;
+}
+
+int msf_match_batch(msf_handle* h, int32_t n_pairs, const msf_image* a, const msf_image* b, msf_match* out,
+                    int32_t cap_per_pair, int32_t* n_out) {
+  if (!h) return MSF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (n_pairs < 0 || !a || !b || !out || !n_out || cap_per_pair < 1)
+    return fail(h, MSF_ERR_INVALID_ARG, "msf_match_batch: bad argument");
+  hipError_t e = hipSetDevice(h->cfg.device);
+  if (e != hipSuccess) return hip_fail(h, "hipSetDevice", e);
+  const int W = h->cfg.image_width, H = h->cfg.image_height, maxp = h->cfg.max_batch_pairs;
+  for (int i = 0; i < n_pairs; i++) {
+    if (!a[i].data || !b[i].data || a[i].width != W || a[i].height != H || b[i].width != W || b[i].height != H ||
+        a[i].stride < W || b[i].stride < W)
+      return fail(h, MSF_ERR_INVALID_ARG, "msf_match_batch: image size differs from the handle's, or null data");
+  }
+  if (!h->d_stage) {
+    h->stage_pitch = (W + 15) & ~15;
+    h->stage_frame = (long long)h->stage_pitch * H;
+    h->stage_cap = kStageCap;
+    if ((e = hipMalloc(&h->d_stage, (size_t)2 * maxp * h->stage_frame)) != hipSuccess) return hip_fail(h, "hipMalloc stage", e);
+    if ((e = hipMalloc(&h->d_out, (size_t)maxp * h->stage_cap * sizeof(msf_match))) != hipSuccess) return hip_fail(h, "hipMalloc out", e);
+    if ((e = hipMalloc(&h->d_n, (size_t)maxp * sizeof(int32_t))) != hipSuccess) return hip_fail(h, "hipMalloc n", e);
+  }
+  hipStream_t st = h->stream;
+  std::vector<msf_match> tmp;
+  std::vector<int32_t> cnt(maxp);
+  bool capacity = false;
+  for (int p0 = 0; p0 < n_pairs; p0 += maxp) {
+    const int n = n_pairs - p0 < maxp ? n_pairs - p0 : maxp;
+    uint8_t* dA = h->d_stage;
+    uint8_t* dB = h->d_stage + (size_t)maxp * h->stage_frame;
+    for (int i = 0; i < n; i++) {
+      if ((e = hipMemcpy2DAsync(dA + (size_t)i * h->stage_frame, h->stage_pitch, a[p0 + i].data, a[p0 + i].stride, W, H,
+                                hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(h, "hipMemcpy2DAsync", e);
+      if ((e = hipMemcpy2DAsync(dB + (size_t)i * h->stage_frame, h->stage_pitch, b[p0 + i].data, b[p0 + i].stride, W, H,
+                                hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(h, "hipMemcpy2DAsync", e);
+    }
+    int rc = run_device(h, n, dA, dB, h->stage_frame, h->stage_pitch, h->d_out, h->stage_cap, h->d_n, st);
+    if (rc != MSF_OK) return rc;
+    if ((e = hipMemcpyAsync(cnt.data(), h->d_n, (size_t)n * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(h, "hipMemcpyAsync", e);
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(h, "hipStreamSynchronize", e);
+    for (int i = 0; i < n; i++) {
+      int32_t c = cnt[i];
+      n_out[p0 + i] = c;
+      if (c < 0) { capacity = true; continue; }
+      int avail = c < h->stage_cap ? c : h->stage_cap;
+      if (avail < c && cap_per_pair > avail) capacity = true;  // staging list shorter than what the caller asked for
+      int w = avail < cap_per_pair ? avail : cap_per_pair;
+      if (w > 0 && (e = hipMemcpy(out + (size_t)(p0 + i) * cap_per_pair, h->d_out + (size_t)i * h->stage_cap,
+                                  (size_t)w * sizeof(msf_match), hipMemcpyDeviceToHost)) != hipSuccess)
+        return hip_fail(h, "hipMemcpy", e);
+    }
+  }
+  if (capacity) return fail(h, MSF_ERR_CAPACITY, "a fixed-capacity device list overflowed for at least one pair");
+  return MSF_OK;
+}
+
+int msf_match_pair(msf_handle* h, const msf_image* a, const msf_image* b, msf_match* out, int32_t cap,
+                   int32_t* n_out) {
+  return msf_match_batch(h, 1, a, b, out, cap, n_out);
+}
+
+int msf_extract_device(msf_handle* h, int32_t n_frames, const uint8_t* d_frames, int64_t frame_stride,
+                       int64_t row_stride, int32_t first_slot, void* stream) {
+  if (!h) return MSF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (h->cfg.kind != MSF_KIND_ORB) return fail(h, MSF_ERR_UNSUPPORTED, "msf_extract_device: ORB handles only");
+  if (n_frames < 0 || !d_frames || first_slot < 0 || first_slot + n_frames > h->orb.max_slots())
+    return fail(h, MSF_ERR_INVALID_ARG, "msf_extract_device: slot range outside [0, 2*max_batch_pairs)");
+  if (((uintptr_t)d_frames | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 15)
+    return fail(h, MSF_ERR_INVALID_ARG, "device frames must be 16-byte aligned with strides multiple of 16");
+  hipError_t e = hipSetDevice(h->cfg.device);
+  if (e != hipSuccess) return hip_fail(h, "hipSetDevice", e);
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  msf::FrameSrc src{d_frames, d_frames, n_frames, first_slot, frame_stride, (int)row_stride};
+  if ((e = h->orb.extract(src, n_frames, st)) != hipSuccess) return hip_fail(h, "orb extract", e);
+  if (!stream && (e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(h, "hipStreamSynchronize", e);
+  return MSF_OK;
+}
+
+int msf_match_slots_device(msf_handle* h, int32_t n_pairs, const int32_t* d_slot_a, const int32_t* d_slot_b,
+                           msf_match* d_out, int32_t cap_per_pair, int32_t* d_n_out, void* stream) {
+  if (!h) return MSF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (h->cfg.kind != MSF_KIND_ORB) return fail(h, MSF_ERR_UNSUPPORTED, "msf_match_slots_device: ORB handles only");
+  if (n_pairs < 0 || !d_slot_a || !d_slot_b || !d_out || !d_n_out || cap_per_pair < 1)
+    return fail(h, MSF_ERR_INVALID_ARG, "msf_match_slots_device: bad argument");
+  hipError_t e = hipSetDevice(h->cfg.device);
+  if (e != hipSuccess) return hip_fail(h, "hipSetDevice", e);
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  if ((e = h->orb.match(n_pairs, d_slot_a, d_slot_b, h->cfg.threshold, d_out, cap_per_pair, d_n_out, st)) != hipSuccess)
+    return hip_fail(h, "orb match", e);
+  if (!stream && (e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(h, "hipStreamSynchronize", e);
+  return MSF_OK;
+}
+
+int msf_debug_get(msf_handle* h, int32_t what, int32_t slot, int32_t level, void* host_out, size_t cap_bytes,
+                  size_t* n_bytes) {
+  if (!h || !n_bytes || (!host_out && cap_bytes)) return MSF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  hipError_t e = hipSetDevice(h->cfg.device);
+  if (e != hipSuccess) return hip_fail(h, "hipSetDevice", e);
+  std::string err;
+  int rc = h->cfg.kind == MSF_KIND_ORB ? h->orb.debug_get(what, slot, level, host_out, cap_bytes, n_bytes, &err)
+                                        : h->loftr.debug_get(what, slot, level, host_out, cap_bytes, n_bytes, &err);
+  if (rc != 0) return fail(h, rc, err);
+  return MSF_OK;
+}
+
+int msf_stage_times(msf_handle* h, const char** names, float* ms, int32_t cap) {
+  if (!h || !names || !ms || cap < 1) return 0;
+  std::lock_guard<std::mutex> lk(h->mu);
+  hipSetDevice(h->cfg.device);
+  return h->cfg.kind == MSF_KIND_ORB ? h->orb.stage_times(names, ms, cap) : h->loftr.stage_times(names, ms, cap);
+}
+
+}  // extern "C"

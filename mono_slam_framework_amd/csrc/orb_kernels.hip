@@ -1,0 +1,844 @@
+// ORB extract + match kernels for gfx950 (CDNA4, wave64).
+//
+// What is computed (and the upstream routine each stage stands in for) is stated in
+// DESIGN.md "ORB path"; the reference entry point is ::FeatureMatcher::MatchFrames
+// (src/featurematcher.cpp:10-45), whose arithmetic is cv::ORB::detectAndCompute
+// (cv::ORB::create() defaults) and BFMatcher(NORM_HAMMING)::knnMatch(k=2).
+//
+// Integer/byte work, HBM- and VALU-bound: no MFMA here.  This TU is compiled with
+// -ffp-contract=off so the few f32 steps (Harris response, fastAtan2, pattern rotation)
+// round exactly as the CPU restatement does.
+#include "orb_pipeline.h"
+
+#include <math.h>
+#include <string.h>
+
+#include "orb_pattern.h"
+
+namespace msf {
+
+// ------------------------------------------------------------------ constants
+constexpr int kEdge = 31;          // edgeThreshold
+constexpr int kFastT = 20;         // fastThreshold
+constexpr int TW = 64, TH = 32;    // FAST output tile
+constexpr int PW = TW + 8, PH = TH + 8;      // pixel tile (halo 4: ring 3 + NMS 1)
+constexpr int SW = TW + 2, SH = TH + 2, SP = 68;  // score tile (halo 1), pitch 68
+constexpr int kTileCandCap = TW * TH / 4;    // strict 3x3 maxima: at most one per 2x2
+
+constexpr uint32_t kStatusOverflow = 1u;
+
+__constant__ __attribute__((aligned(16))) signed char c_pattern[1024];
+__constant__ int c_umax[16];
+
+// ------------------------------------------------------------------ helpers
+__device__ __forceinline__ const uint8_t* level_ptr(const OrbGeometry& g, const FrameSrc& src,
+                                                    const uint8_t* pyr, int fi, int l, int* pitch) {
+  if (l == 0) {
+    *pitch = src.row_stride;
+    return fi < src.n_a ? src.a + (long long)fi * src.frame_stride
+                        : src.b + (long long)(fi - src.n_a) * src.frame_stride;
+  }
+  *pitch = g.lv[l].pitch;
+  return pyr + (long long)(src.slot0 + fi) * g.pyr_bytes + g.lv[l].pix_off;
+}
+
+// ------------------------------------------------------------------ K2: pyramid level l from l-1
+// cv::resize(..., INTER_LINEAR_EXACT) restated: 8.8 fixed-point taps from host tables,
+// 16-bit horizontal sums, 32-bit vertical, (v + 32768) >> 16.  One thread = 4 output pixels.
+__global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uint8_t* pyr,
+                                                const uint16_t* __restrict__ tab, int l) {
+  const int fi = blockIdx.z;
+  const OrbLevelInfo L = g.lv[l];
+  int spitch;
+  const uint8_t* s = level_ptr(g, src, pyr, fi, l - 1, &spitch);
+  uint8_t* d = pyr + (long long)(src.slot0 + fi) * g.pyr_bytes + L.pix_off;
+  const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (y >= L.h || x4 >= L.w) return;
+  const uint16_t* xofs = tab + L.tab_off;
+  const uint16_t* xw = xofs + L.w;
+  const uint16_t* yofs = xw + L.w;
+  const uint16_t* yw = yofs + L.h;
+  const int sy = yofs[y];
+  const uint32_t wy1 = yw[y], wy0 = 256u - wy1;
+  const uint8_t* r0 = s + (long long)sy * spitch;
+  const uint8_t* r1 = wy1 ? r0 + spitch : r0;
+  uint32_t packed = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int x = x4 + i;
+    if (x < L.w) {
+      const int sx = xofs[x];
+      const uint32_t wx1 = xw[x], wx0 = 256u - wx1;
+      const int sx1 = wx1 ? sx + 1 : sx;
+      const uint32_t h0 = wx0 * r0[sx] + wx1 * r0[sx1];
+      const uint32_t h1 = wx0 * r1[sx] + wx1 * r1[sx1];
+      uint32_t v = (h0 * wy0 + h1 * wy1 + 32768u) >> 16;
+      v = v > 255u ? 255u : v;
+      packed |= v << (8 * i);
+    }
+  }
+  *reinterpret_cast<uint32_t*>(d + (long long)y * L.pitch + x4) = packed;  // pitch % 16 == 0, pad bytes are never read as pixels
+}
+
+// ------------------------------------------------------------------ K3+K4: FAST-9/16 score, NMS, border, candidate list
+__device__ __forceinline__ bool run9(uint32_t m) {
+  m |= m << 16;
+  uint32_t r = m & (m >> 1);
+  r &= r >> 2;
+  r &= r >> 4;
+  r &= m >> 8;
+  return (r & 0xFFFFu) != 0;
+}
+
+// FAST_t<16> corner test + cornerScore<16> on an LDS pixel tile (pitch PW); 0 = not a corner.
+__device__ __forceinline__ int fast_score_lds(const uint8_t* p) {
+  constexpr int off[16] = {3 * PW + 0,  3 * PW + 1,  2 * PW + 2,  1 * PW + 3,  0 * PW + 3, -1 * PW + 3,
+                           -2 * PW + 2, -3 * PW + 1, -3 * PW + 0, -3 * PW - 1, -2 * PW - 2, -1 * PW - 3,
+                           0 * PW - 3,  1 * PW - 3,  2 * PW - 2,  3 * PW - 1};
+  const int v = p[0];
+  int d[16];
+  uint32_t dark = 0, bright = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    d[k] = v - (int)p[off[k]];
+    dark |= (uint32_t)(d[k] > kFastT) << k;
+    bright |= (uint32_t)(d[k] < -kFastT) << k;
+  }
+  if (!(run9(dark) || run9(bright))) return 0;
+  // max over the 16 arcs of min(d) (darker) and of min(-d) (brighter): sliding window of 9
+  int mn[16], mx[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    mn[k] = min(d[k], d[(k + 1) & 15]);
+    mx[k] = max(d[k], d[(k + 1) & 15]);
+  }
+  int mn4[16], mx4[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    mn4[k] = min(mn[k], mn[(k + 2) & 15]);
+    mx4[k] = max(mx[k], mx[(k + 2) & 15]);
+  }
+  int A = -1000, B = 1000;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int m9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+    const int M9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+    A = max(A, m9);
+    B = min(B, M9);
+  }
+  return max(A, -B) - 1;
+}
+
+__global__ __launch_bounds__(256) void k_fast(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
+                                              uint32_t* cand_cnt, uint2* cand) {
+  __shared__ __attribute__((aligned(16))) uint8_t px[PW * PH];
+  __shared__ uint8_t sc[SP * SH];
+  __shared__ uint2 llist[kTileCandCap];
+  __shared__ uint32_t lcount, gbase;
+
+  const int fi = blockIdx.y;
+  const int slot = src.slot0 + fi;
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < kOrbLevels; i++)
+    if (i < g.nlevels && (int)blockIdx.x >= g.lv[i].tile_base) l = i;
+  const OrbLevelInfo L = g.lv[l];
+  const int t = blockIdx.x - L.tile_base;
+  const int x0 = (t % L.tiles_x) * TW, y0 = (t / L.tiles_x) * TH;
+  int pitch;
+  const uint8_t* img = level_ptr(g, src, pyr, fi, l, &pitch);
+  const int tid = threadIdx.x;
+  if (tid == 0) lcount = 0;
+
+  // stage the pixel tile (halo 4) through aligned dword loads
+  for (int i = tid; i < (PW / 4) * PH; i += 256) {
+    const int r = i / (PW / 4), c = i % (PW / 4);
+    const int gx = x0 - 4 + 4 * c, gy = y0 - 4 + r;
+    uint32_t v = 0;
+    if (gx >= 0 && gx + 4 <= pitch && gy >= 0 && gy < L.h)
+      v = *reinterpret_cast<const uint32_t*>(img + (long long)gy * pitch + gx);
+    *reinterpret_cast<uint32_t*>(&px[r * PW + 4 * c]) = v;
+  }
+  __syncthreads();
+
+  // scores for the tile + 1 halo; FAST_t scores only rows/cols 3 .. dim-4
+  for (int i = tid; i < SW * SH; i += 256) {
+    const int sy = i / SW, sx = i % SW;
+    const int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
+    int s = 0;
+    if (gx >= 3 && gx < L.w - 3 && gy >= 3 && gy < L.h - 3) s = fast_score_lds(&px[(sy + 3) * PW + sx + 3]);
+    sc[sy * SP + sx] = (uint8_t)s;
+  }
+  __syncthreads();
+
+  // strict 3x3 NMS + runByImageBorder(31)
+  for (int i = tid; i < TW * TH; i += 256) {
+    const int oy = i / TW, ox = i % TW;
+    const uint8_t* q = &sc[(oy + 1) * SP + ox + 1];
+    const int s = q[0];
+    if (s == 0) continue;
+    const int gx = x0 + ox, gy = y0 + oy;
+    if (gx < kEdge || gx >= L.w - kEdge || gy < kEdge || gy >= L.h - kEdge) continue;
+    if (s > q[-1] && s > q[1] && s > q[-SP - 1] && s > q[-SP] && s > q[-SP + 1] && s > q[SP - 1] &&
+        s > q[SP] && s > q[SP + 1]) {
+      const uint32_t k = atomicAdd(&lcount, 1u);
+      llist[k] = make_uint2(((uint32_t)gy << 16) | (uint32_t)gx, (uint32_t)s);
+    }
+  }
+  __syncthreads();
+  const uint32_t n = lcount;
+  if (n == 0) return;
+  if (tid == 0) gbase = atomicAdd(&cand_cnt[slot * kOrbLevels + l], n);
+  __syncthreads();
+  const uint32_t base = gbase;
+  uint2* out = cand + (long long)slot * g.cand_total + L.cand_off;
+  for (uint32_t i = tid; i < n; i += 256)
+    if (base + i < (uint32_t)L.cand_cap) out[base + i] = llist[i];
+}
+
+// ------------------------------------------------------------------ K5+K6: retainBest(2N) by FAST score, Harris response
+// HarrisResponses (orb.cpp), blockSize 7, k = 0.04, on the unblurred level.
+__device__ __forceinline__ float harris_at(const uint8_t* img, int step, int x0, int y0) {
+  int a = 0, b = 0, c = 0;
+  for (int i = -3; i <= 3; i++) {
+    const uint8_t* r0 = img + (long long)(y0 + i - 1) * step + x0;
+    const uint8_t* r1 = r0 + step;
+    const uint8_t* r2 = r1 + step;
+    for (int j = -3; j <= 3; j++) {
+      const int Ix = ((int)r1[j + 1] - (int)r1[j - 1]) * 2 + ((int)r0[j + 1] - (int)r0[j - 1]) +
+                     ((int)r2[j + 1] - (int)r2[j - 1]);
+      const int Iy = ((int)r2[j] - (int)r0[j]) * 2 + ((int)r2[j - 1] - (int)r0[j - 1]) +
+                     ((int)r2[j + 1] - (int)r0[j + 1]);
+      a += Ix * Ix;
+      b += Iy * Iy;
+      c += Ix * Iy;
+    }
+  }
+  const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+  const float scale_sq_sq = scale * scale * scale * scale;
+  const float fa = (float)a, fb = (float)b, fc = (float)c;
+  return (fa * fb - fc * fc - 0.04f * (fa + fb) * (fa + fb)) * scale_sq_sq;
+}
+
+__global__ __launch_bounds__(256) void k_thr_harris(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
+                                                    const uint32_t* cand_cnt, const uint2* cand,
+                                                    uint32_t* s1_cnt, uint4* s1, uint32_t* status) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t thr_s, lcount;
+  const int l = blockIdx.x, fi = blockIdx.y, slot = src.slot0 + fi, tid = threadIdx.x;
+  if (l >= g.nlevels) return;
+  const OrbLevelInfo L = g.lv[l];
+  uint32_t n = cand_cnt[slot * kOrbLevels + l];
+  if (n > (uint32_t)L.cand_cap) {
+    if (tid == 0) atomicOr(&status[slot], kStatusOverflow);
+    n = L.cand_cap;
+  }
+  const uint2* in = cand + (long long)slot * g.cand_total + L.cand_off;
+  uint4* out = s1 + (long long)slot * g.s1_total + L.s1_off;
+  hist[tid] = 0;
+  if (tid == 0) lcount = 0;
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += 256) atomicAdd(&hist[in[i].y & 255u], 1u);
+  __syncthreads();
+  if (tid == 0) {
+    // KeyPointsFilter::retainBest(keypoints, 2 * featuresNum): keep all >= the (2N)-th largest score
+    const uint32_t keep = 2u * (uint32_t)L.quota;
+    uint32_t thr = 0;
+    if (n > keep) {
+      thr = 256;  // keep == 0: drop all
+      uint32_t cum = 0;
+      for (int b = 255; b >= 0 && keep > 0; b--) {
+        cum += hist[b];
+        if (cum >= keep) { thr = b; break; }
+      }
+    }
+    thr_s = thr;
+  }
+  __syncthreads();
+  const uint32_t thr = thr_s;
+  int pitch;
+  const uint8_t* img = level_ptr(g, src, pyr, fi, l, &pitch);
+  for (uint32_t i = tid; i < n; i += 256) {
+    const uint2 c = in[i];
+    if (c.y >= thr) {
+      const int x = c.x & 0xFFFF, y = c.x >> 16;
+      const float r = harris_at(img, pitch, x, y);
+      const uint32_t k = atomicAdd(&lcount, 1u);
+      if (k < (uint32_t)kS1Cap) out[k] = make_uint4(c.x, __float_as_uint(r), c.y, 0u);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t m = lcount;
+    if (m > (uint32_t)kS1Cap) { atomicOr(&status[slot], kStatusOverflow); m = kS1Cap; }
+    s1_cnt[slot * kOrbLevels + l] = m;
+  }
+}
+
+// ------------------------------------------------------------------ K7: retainBest(N) by Harris, canonical order
+// One workgroup per frame walks the levels so the final list is ordered (level, y, x).
+constexpr int kSelCap = kKpCap;
+__global__ __launch_bounds__(256) void k_select(OrbGeometry g, int slot0, const uint32_t* s1_cnt, const uint4* s1,
+                                                msf_keypoint* kp, uint32_t* kp_cnt, uint32_t* status) {
+  __shared__ uint4 kept[kSelCap];
+  __shared__ uint32_t nkept;
+  const int slot = slot0 + blockIdx.x, tid = threadIdx.x;
+  msf_keypoint* out = kp + (long long)slot * kKpCap;
+  uint32_t base = 0;
+  bool overflow = false;
+  for (int l = 0; l < g.nlevels; l++) {
+    const OrbLevelInfo L = g.lv[l];
+    const uint32_t n = s1_cnt[slot * kOrbLevels + l];
+    const uint4* in = s1 + (long long)slot * g.s1_total + L.s1_off;
+    const uint32_t keep = (uint32_t)L.quota;
+    if (tid == 0) nkept = 0;
+    __syncthreads();
+    // retainBest(N): v is kept iff fewer than N entries are strictly greater than v
+    for (uint32_t i = tid; i < n; i += 256) {
+      const uint4 e = in[i];
+      bool k = true;
+      if (n > keep) {
+        const float v = __uint_as_float(e.y);
+        uint32_t greater = 0;
+        for (uint32_t j = 0; j < n; j++) greater += (__uint_as_float(in[j].y) > v) ? 1u : 0u;
+        k = greater < keep;
+      }
+      if (k) {
+        const uint32_t q = atomicAdd(&nkept, 1u);
+        if (q < (uint32_t)kSelCap) kept[q] = e;
+      }
+    }
+    __syncthreads();
+    uint32_t m = nkept;
+    if (m > (uint32_t)kSelCap) { overflow = true; m = kSelCap; }
+    if (base + m > (uint32_t)kKpCap) { overflow = true; m = kKpCap - base; }
+    // canonical order inside the level: rank by (y, x)
+    for (uint32_t i = tid; i < m; i += 256) {
+      const uint4 e = kept[i];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < m; j++) rank += (kept[j].x < e.x) ? 1u : 0u;
+      msf_keypoint k;
+      k.lx = e.x & 0xFFFF;
+      k.ly = e.x >> 16;
+      k.x = (float)k.lx * L.scale;   // allKeypoints[i].pt *= scale
+      k.y = (float)k.ly * L.scale;
+      k.response = __uint_as_float(e.y);
+      k.angle = -1.f;
+      k.octave = l;
+      k.fast_score = (int)e.z;
+      out[base + rank] = k;
+    }
+    base += m;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    kp_cnt[slot] = base;
+    if (overflow) atomicOr(&status[slot], kStatusOverflow);
+  }
+}
+
+// ------------------------------------------------------------------ K8+K9+K10: orientation, blur, steered rBRIEF
+// cv::fastAtan2 scalar path (core mathfuncs_core.simd.hpp atan_f32)
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+  const float k = (float)(180.0 / 3.14159265358979323846);
+  const float p1 = 0.9997878412794807f * k, p3 = -0.3258083974640975f * k, p5 = 0.1555786518463281f * k,
+              p7 = -0.04432655554792128f * k;
+  const float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + (float)2.2204460492503131e-16);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + (float)2.2204460492503131e-16);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+// sin/cos of t in [0, ~2*pi]: Cody-Waite reduction by pi/2 + fdlibm kernel polynomials in IEEE
+// double (plain mul/add, no FMA), rounded once to f32.  Same operation sequence as the CPU side.
+__device__ __forceinline__ void det_sincosf(float t, float* s, float* c) {
+  const double x = (double)t;
+  const int k = (int)(x * 6.36619772367581382433e-01 + 0.5);
+  const double kd = (double)k;
+  const double r = (x - kd * 1.57079632673412561417e+00) - kd * 6.07710050650619224932e-11;
+  const double z = r * r;
+  double p = 1.58969099521155010221e-10;
+  p = p * z + -2.50507602534068634195e-08;
+  p = p * z + 2.75573137070700676789e-06;
+  p = p * z + -1.98412698298579493134e-04;
+  p = p * z + 8.33333333332248946124e-03;
+  p = p * z + -1.66666666666666324348e-01;
+  const double sr = r + (r * z) * p;
+  double q = -1.13596475577881948265e-11;
+  q = q * z + 2.08757232129817482790e-09;
+  q = q * z + -2.75573143513906633035e-07;
+  q = q * z + 2.48015872894767294178e-05;
+  q = q * z + -1.38888888888741095749e-03;
+  q = q * z + 4.16666666666666019037e-02;
+  const double cr = (1.0 - 0.5 * z) + (z * z) * q;
+  double sv, cv;
+  switch (k & 3) {
+    case 0: sv = sr; cv = cr; break;
+    case 1: sv = cr; cv = -sr; break;
+    case 2: sv = -sr; cv = -cr; break;
+    default: sv = -cr; cv = sr; break;
+  }
+  *s = (float)sv;
+  *c = (float)cv;
+}
+
+constexpr int PR = 22;             // patch radius: 19 (rotated pattern reach) + 3 (blur taps)
+constexpr int PD = 2 * PR + 1;     // 45
+constexpr int PP = 48;             // raw patch pitch
+constexpr int HB = PD - 6;         // 39 horizontally blurred columns
+constexpr int HP = 40;
+
+__global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
+                                                  msf_keypoint* kp, const uint32_t* kp_cnt, uint8_t* desc,
+                                                  int half_up) {
+  __shared__ uint8_t raw_s[4][PD * PP];
+  __shared__ uint16_t hb_s[4][PD * HP];
+  const int fi = blockIdx.y, slot = src.slot0 + fi;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t count = min(kp_cnt[slot], (uint32_t)kKpCap);
+  uint8_t* raw = raw_s[wave];
+  uint16_t* hb = hb_s[wave];
+  for (uint32_t k0 = blockIdx.x * 4; k0 < count; k0 += gridDim.x * 4) {
+    const uint32_t k = k0 + wave;
+    const bool active = k < count;
+    msf_keypoint* K = kp + (long long)slot * kKpCap + k;
+    int l = 0, cx = 0, cy = 0, pitch = 0;
+    const uint8_t* img = nullptr;
+    if (active) {
+      l = K->octave; cx = K->lx; cy = K->ly;
+      img = level_ptr(g, src, pyr, fi, l, &pitch);
+      // raw patch, radius 22 (keypoints sit >= 31 px inside the level, so this never leaves it)
+      for (int i = lane; i < PD * PD; i += 64) {
+        const int r = i / PD, c = i % PD;
+        raw[r * PP + c] = img[(long long)(cy - PR + r) * pitch + (cx - PR + c)];
+      }
+    }
+    __syncthreads();
+    float angle = 0.f;
+    if (active) {
+      // ICAngles (orb.cpp): lanes 0..30 take one row of the 31-px disc each
+      int m10 = 0, m01 = 0;
+      if (lane < 31) {
+        const int v = lane - 15;
+        const int dmax = c_umax[v < 0 ? -v : v];
+        const uint8_t* row = raw + (PR + v) * PP + PR;
+        int rs = 0;
+        for (int u = -dmax; u <= dmax; u++) {
+          const int p = row[u];
+          m10 += u * p;
+          rs += p;
+        }
+        m01 = v * rs;
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        m10 += __shfl_xor(m10, o);
+        m01 += __shfl_xor(m01, o);
+      }
+      angle = fast_atan2_deg((float)m01, (float)m10);
+      // 7-tap row pass of GaussianBlur(7x7, sigma 2) in its 8u integer form (18 34 49 55 49 34 18)
+      for (int i = lane; i < PD * HB; i += 64) {
+        const int r = i / HB, c = i % HB;
+        const uint8_t* p = raw + r * PP + c;
+        const uint32_t s = 18u * (p[0] + p[6]) + 34u * (p[1] + p[5]) + 49u * (p[2] + p[4]) + 55u * p[3];
+        hb[r * HP + c] = (uint16_t)s;  // <= 255 * 257 = 65535
+      }
+    }
+    __syncthreads();
+    if (active) {
+      float a, b;
+      float rad = angle;
+      rad *= (float)(3.14159265358979323846 / 180.f);
+      det_sincosf(rad, &b, &a);  // a = cos, b = sin
+      // computeOrbDescriptors (orb.cpp), WTA_K = 2: lane handles tests 4*lane .. 4*lane+3
+      const int4 pk = *reinterpret_cast<const int4*>(&c_pattern[lane * 16]);
+      const int words[4] = {pk.x, pk.y, pk.z, pk.w};
+      uint32_t nib = 0;
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        int val[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const float px = (float)(signed char)(words[t] >> (16 * e));
+          const float py = (float)(signed char)(words[t] >> (16 * e + 8));
+          const int ix = __float2int_rn(px * a - py * b);
+          const int iy = __float2int_rn(px * b + py * a);
+          // column pass at the sampled pixel only
+          const uint16_t* q = hb + (PR + iy - 3) * HP + (PR + ix - 3);
+          const uint32_t s = 18u * (q[0] + q[6 * HP]) + 34u * (q[HP] + q[5 * HP]) + 49u * (q[2 * HP] + q[4 * HP]) +
+                             55u * q[3 * HP];
+          uint32_t r;
+          if (half_up) {
+            r = (s + 32768u) >> 16;
+          } else {
+            r = s >> 16;
+            const uint32_t frac = s & 0xFFFFu;
+            if (frac > 0x8000u || (frac == 0x8000u && (r & 1u))) r++;
+          }
+          val[e] = (int)(r > 255u ? 255u : r);
+        }
+        nib |= (uint32_t)(val[0] < val[1]) << t;
+      }
+      const uint32_t hi = __shfl_down(nib, 1);
+      if ((lane & 1) == 0) desc[((long long)slot * kKpCap + k) * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+      if (lane == 0) K->angle = angle;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ K11: brute-force Hamming 2-NN + ratio + ordered compaction
+constexpr int kTrainChunk = 1024;  // train descriptors staged per LDS pass (32 KB)
+__global__ __launch_bounds__(256) void k_match(int n_pairs, const int32_t* slot_a, const int32_t* slot_b,
+                                               const msf_keypoint* kp, const uint32_t* kp_cnt, const uint8_t* desc,
+                                               const uint32_t* status, float ratio, msf_match* out, int cap,
+                                               int32_t* n_out) {
+  __shared__ __attribute__((aligned(16))) unsigned long long train[kTrainChunk * 4];
+  __shared__ uint32_t wave_cnt[4];
+  __shared__ uint32_t running;
+  const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sa = slot_a ? slot_a[pair] : pair;
+  const int sb = slot_b ? slot_b[pair] : n_pairs + pair;
+  if ((status[sa] | status[sb]) & kStatusOverflow) {
+    if (tid == 0) n_out[pair] = -1;
+    return;
+  }
+  const uint32_t n1 = min(kp_cnt[sa], (uint32_t)kKpCap), n2 = min(kp_cnt[sb], (uint32_t)kKpCap);
+  const unsigned long long* tsrc = reinterpret_cast<const unsigned long long*>(desc + (long long)sb * kKpCap * 32);
+  if (tid == 0) running = 0;
+  __syncthreads();
+  const msf_keypoint* ka = kp + (long long)sa * kKpCap;
+  const msf_keypoint* kb = kp + (long long)sb * kKpCap;
+  msf_match* o = out + (long long)pair * cap;
+  for (uint32_t q0 = 0; q0 < n1; q0 += 256) {
+    const uint32_t q = q0 + tid;
+    const bool have_q = q < n1;
+    unsigned long long q0w = 0, q1w = 0, q2w = 0, q3w = 0;
+    if (have_q) {
+      const unsigned long long* qd =
+          reinterpret_cast<const unsigned long long*>(desc + ((long long)sa * kKpCap + q) * 32);
+      q0w = qd[0]; q1w = qd[1]; q2w = qd[2]; q3w = qd[3];
+    }
+    int d0 = 0x7fffffff, d1 = 0x7fffffff, i0 = -1;
+    for (uint32_t t0 = 0; t0 < n2; t0 += kTrainChunk) {
+      const uint32_t tn = min(n2 - t0, (uint32_t)kTrainChunk);
+      __syncthreads();
+      for (uint32_t i = tid; i < tn * 4; i += 256) train[i] = tsrc[(size_t)t0 * 4 + i];
+      __syncthreads();
+      if (have_q) {
+        for (uint32_t t = 0; t < tn; t++) {
+          const unsigned long long* tr = &train[t * 4];
+          const int d = __popcll(q0w ^ tr[0]) + __popcll(q1w ^ tr[1]) + __popcll(q2w ^ tr[2]) + __popcll(q3w ^ tr[3]);
+          // batchDistance K=2 insertion: strict '<' keeps the lower train index on ties
+          if (d < d1) {
+            if (d < d0) { d1 = d0; d0 = d; i0 = (int)(t0 + t); }
+            else d1 = d;
+          }
+        }
+      }
+    }
+    // train sets of < 2 give no matches (reference: UB at matches[i][1]); featurematcher.cpp:32
+    const bool pass = have_q && n2 >= 2 && ((float)d0 < ratio * (float)d1);
+    // ordered compaction (query order)
+    const unsigned long long bal = __ballot(pass);
+    const uint32_t before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    uint32_t off = running;
+    for (int w = 0; w < wave; w++) off += wave_cnt[w];
+    if (pass) {
+      const uint32_t idx = off + before;
+      if (idx < (uint32_t)cap) {
+        msf_match m;
+        m.x1 = (int)ka[q].x; m.y1 = (int)ka[q].y;      // static_cast<int>(kp.pt.x) (:33-38)
+        m.x2 = (int)kb[i0].x; m.y2 = (int)kb[i0].y;
+        o[idx] = m;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  if (tid == 0) n_out[pair] = (int32_t)running;
+}
+
+// ================================================================== host side
+static int cv_round_f(float v) { return (int)lrintf(v); }
+static int cv_round_d(double v) { return (int)lrint(v); }
+
+// interpolationLinear<uchar>::getCoeffs (imgproc resize.cpp, INTER_LINEAR_EXACT)
+static void make_table(int src, int dst, uint16_t* ofs, uint16_t* w1) {
+  const double inv_scale = (double)dst / (double)src;
+  const double scale = 1.0 / inv_scale;
+  for (int d = 0; d < dst; d++) {
+    const double f = scale * ((double)d + 0.5) - 0.5;
+    const int i = (int)floor(f);
+    if (i >= 0 && src > 1) {
+      if (i < src - 1) {
+        ofs[d] = (uint16_t)i;
+        w1[d] = (uint16_t)cv_round_d((f - (double)i) * 256.0);
+      } else {
+        ofs[d] = (uint16_t)(src - 1);
+        w1[d] = 0;
+      }
+    } else {
+      ofs[d] = 0;
+      w1[d] = 0;
+    }
+  }
+}
+
+OrbPipeline::~OrbPipeline() { destroy(); }
+
+void OrbPipeline::destroy() {
+  hipFree(d_pyr_); hipFree(d_tab_); hipFree(d_cand_cnt_); hipFree(d_cand_); hipFree(d_s1_cnt_); hipFree(d_s1_);
+  hipFree(d_kp_); hipFree(d_desc_); hipFree(d_kp_cnt_); hipFree(d_status_);
+  d_pyr_ = nullptr; d_tab_ = nullptr; d_cand_cnt_ = nullptr; d_cand_ = nullptr; d_s1_cnt_ = nullptr;
+  d_s1_ = nullptr; d_kp_ = nullptr; d_desc_ = nullptr; d_kp_cnt_ = nullptr; d_status_ = nullptr;
+  if (ev_ok_) for (auto& e : ev_) hipEventDestroy(e);
+  ev_ok_ = false;
+}
+
+#define MSF_HIP_TRY(expr)                                                                 \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) return std::string(#expr) + ": " + hipGetErrorString(e_);       \
+  } while (0)
+
+std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_half_up, bool profile) {
+  if (width < 64 || height < 64 || width > 8192 || height > 8192) return "ORB: image size must be in [64, 8192]";
+  if (max_slots < 2) return "ORB: max_slots < 2";
+  max_slots_ = max_slots;
+  half_up_ = blur_half_up;
+  profile_ = profile;
+  OrbGeometry& g = g_;
+  g.nlevels = kOrbLevels;
+  g.w0 = width;
+  g.h0 = height;
+  // ORB_Impl::detectAndCompute: layer scales and sizes; computeKeyPoints: per-level quotas and umax
+  const float scale_factor_f = 1.2f;
+  const double scale_factor = (double)scale_factor_f;
+  const int nfeatures = 500;
+  {
+    const float factor = (float)(1.0 / scale_factor);
+    float nd = (float)nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)g.nlevels));
+    int sum = 0;
+    for (int l = 0; l < g.nlevels - 1; l++) {
+      g.lv[l].quota = cv_round_f(nd);
+      sum += g.lv[l].quota;
+      nd *= factor;
+    }
+    g.lv[g.nlevels - 1].quota = nfeatures - sum > 0 ? nfeatures - sum : 0;
+  }
+  {
+    const int half = 15;
+    int umax[17] = {0};
+    const int vmax = (int)floor(half * sqrt(2.f) / 2 + 1);
+    const int vmin = (int)ceil(half * sqrt(2.f) / 2);
+    for (int v = 0; v <= vmax; ++v) umax[v] = cv_round_d(sqrt((double)half * half - v * v));
+    for (int v = half, v0 = 0; v >= vmin; --v) {
+      while (umax[v0] == umax[v0 + 1]) ++v0;
+      umax[v] = v0;
+      ++v0;
+    }
+    for (int v = 0; v < 16; v++) g.umax[v] = umax[v];
+  }
+  long long pix = 0;
+  int cand = 0, tiles = 0, tab = 0, s1 = 0;
+  for (int l = 0; l < g.nlevels; l++) {
+    OrbLevelInfo& L = g.lv[l];
+    const float s = (float)pow(scale_factor, (double)l);
+    const float inv = 1.0f / s;
+    L.scale = s;
+    L.w = cv_round_f((float)width * inv);
+    L.h = cv_round_f((float)height * inv);
+    L.pitch = (L.w + 15) & ~15;
+    L.pix_off = pix;
+    if (l > 0) pix += (long long)L.pitch * L.h;
+    // strict 3x3 maxima are at most w*h/4; w*h/8 covers white noise with margin (overflow is flagged, never silent)
+    int cap = (int)((long long)L.w * L.h / 8);
+    if (cap < 4096) cap = 4096;
+    L.cand_cap = cap;
+    L.cand_off = cand;
+    cand += cap;
+    L.s1_off = s1;
+    s1 += kS1Cap;
+    L.tiles_x = (L.w + TW - 1) / TW;
+    L.tiles_y = (L.h + TH - 1) / TH;
+    L.tile_base = tiles;
+    tiles += L.tiles_x * L.tiles_y;
+    L.tab_off = tab;
+    if (l > 0) tab += 2 * L.w + 2 * L.h;
+  }
+  g.pyr_bytes = (pix + 255) & ~255ll;
+  g.cand_total = cand;
+  g.s1_total = s1;
+  g.total_tiles = tiles;
+
+  std::vector<uint16_t> htab(tab > 0 ? tab : 1);
+  for (int l = 1; l < g.nlevels; l++) {
+    const OrbLevelInfo& L = g.lv[l];
+    uint16_t* xofs = htab.data() + L.tab_off;
+    uint16_t* xw = xofs + L.w;
+    uint16_t* yofs = xw + L.w;
+    uint16_t* yw = yofs + L.h;
+    make_table(g.lv[l - 1].w, L.w, xofs, xw);
+    make_table(g.lv[l - 1].h, L.h, yofs, yw);
+  }
+  const size_t S = (size_t)max_slots;
+  MSF_HIP_TRY(hipMalloc(&d_pyr_, S * g.pyr_bytes));
+  MSF_HIP_TRY(hipMalloc(&d_tab_, htab.size() * sizeof(uint16_t)));
+  MSF_HIP_TRY(hipMemcpy(d_tab_, htab.data(), htab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  MSF_HIP_TRY(hipMalloc(&d_cand_cnt_, S * kOrbLevels * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMalloc(&d_cand_, S * g.cand_total * sizeof(uint2)));
+  MSF_HIP_TRY(hipMalloc(&d_s1_cnt_, S * kOrbLevels * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMalloc(&d_s1_, S * g.s1_total * sizeof(uint4)));
+  MSF_HIP_TRY(hipMalloc(&d_kp_, S * kKpCap * sizeof(msf_keypoint)));
+  MSF_HIP_TRY(hipMalloc(&d_desc_, S * kKpCap * 32));
+  MSF_HIP_TRY(hipMalloc(&d_kp_cnt_, S * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMalloc(&d_status_, S * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMemset(d_kp_cnt_, 0, S * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMemset(d_status_, 0, S * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMemset(d_cand_cnt_, 0, S * kOrbLevels * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMemset(d_s1_cnt_, 0, S * kOrbLevels * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), k_orb_bit_pattern_31, 1024));
+  MSF_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), g.umax, sizeof(int) * 16));
+  if (profile_) {
+    for (auto& e : ev_) MSF_HIP_TRY(hipEventCreate(&e));
+    ev_ok_ = true;
+  }
+  return "";
+}
+
+hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  if (src.slot0 < 0 || src.slot0 + n > max_slots_) return hipErrorInvalidValue;
+  const OrbGeometry& g = g_;
+  last_src_ = src;
+  hipError_t e;
+  if ((e = hipMemsetAsync(d_cand_cnt_ + (size_t)src.slot0 * kOrbLevels, 0, (size_t)n * kOrbLevels * 4, st))) return e;
+  if ((e = hipMemsetAsync(d_status_ + src.slot0, 0, (size_t)n * 4, st))) return e;
+  if (ev_ok_) hipEventRecord(ev_[0], st);
+  for (int l = 1; l < g.nlevels; l++) {
+    const OrbLevelInfo& L = g.lv[l];
+    dim3 grid((L.w + 255) / 256, (L.h + 3) / 4, n);
+    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, g, src, d_pyr_, d_tab_, l);
+  }
+  if (ev_ok_) hipEventRecord(ev_[1], st);
+  hipLaunchKernelGGL(k_fast, dim3(g.total_tiles, n), dim3(256), 0, st, g, src, d_pyr_, d_cand_cnt_, d_cand_);
+  if (ev_ok_) hipEventRecord(ev_[2], st);
+  hipLaunchKernelGGL(k_thr_harris, dim3(g.nlevels, n), dim3(256), 0, st, g, src, d_pyr_, d_cand_cnt_, d_cand_,
+                     d_s1_cnt_, d_s1_, d_status_);
+  hipLaunchKernelGGL(k_select, dim3(n), dim3(256), 0, st, g, src.slot0, d_s1_cnt_, d_s1_, d_kp_, d_kp_cnt_,
+                     d_status_);
+  if (ev_ok_) hipEventRecord(ev_[3], st);
+  hipLaunchKernelGGL(k_describe, dim3(8, n), dim3(256), 0, st, g, src, d_pyr_, d_kp_, d_kp_cnt_, d_desc_,
+                     half_up_ ? 1 : 0);
+  if (ev_ok_) hipEventRecord(ev_[4], st);
+  return hipGetLastError();
+}
+
+hipError_t OrbPipeline::match(int n_pairs, const int32_t* d_slot_a, const int32_t* d_slot_b, float ratio,
+                              msf_match* d_out, int cap, int32_t* d_n_out, hipStream_t st) {
+  if (n_pairs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_match, dim3(n_pairs), dim3(256), 0, st, n_pairs, d_slot_a, d_slot_b, d_kp_, d_kp_cnt_,
+                     d_desc_, d_status_, ratio, d_out, cap, d_n_out);
+  if (ev_ok_) {
+    hipEventRecord(ev_[5], st);
+    ev_recorded_ = true;
+  }
+  return hipGetLastError();
+}
+
+int OrbPipeline::stage_times(const char** names, float* ms, int cap) {
+  static const char* kNames[5] = {"pyramid", "fast_nms", "select_harris", "orient_describe", "match"};
+  if (!ev_ok_ || !ev_recorded_) return 0;
+  if (hipEventSynchronize(ev_[5]) != hipSuccess) return 0;
+  int n = 0;
+  for (int i = 0; i < 5 && n < cap; i++, n++) {
+    names[n] = kNames[i];
+    if (hipEventElapsedTime(&ms[n], ev_[i], ev_[i + 1]) != hipSuccess) ms[n] = -1.f;
+  }
+  return n;
+}
+
+int OrbPipeline::debug_get(int what, int slot, int level, void* host_out, size_t cap, size_t* n_bytes,
+                           std::string* err) {
+  const OrbGeometry& g = g_;
+  auto fail = [&](const char* m) { *err = m; return (int)MSF_ERR_INVALID_ARG; };
+  auto copy_out = [&](const void* dsrc, size_t bytes) -> int {
+    *n_bytes = bytes;
+    const size_t n = bytes < cap ? bytes : cap;
+    if (n && hipMemcpy(host_out, dsrc, n, hipMemcpyDeviceToHost) != hipSuccess) {
+      *err = "hipMemcpy failed in debug_get";
+      return (int)MSF_ERR_HIP;
+    }
+    return 0;
+  };
+  if (hipDeviceSynchronize() != hipSuccess) { *err = "hipDeviceSynchronize failed"; return MSF_ERR_HIP; }
+  if (what == MSF_DBG_LEVEL_SIZES) {
+    int32_t v[kOrbLevels][4];
+    for (int l = 0; l < kOrbLevels; l++) { v[l][0] = g.lv[l].w; v[l][1] = g.lv[l].h; v[l][2] = g.lv[l].pitch; v[l][3] = g.lv[l].quota; }
+    *n_bytes = sizeof(v);
+    memcpy(host_out, v, sizeof(v) < cap ? sizeof(v) : cap);
+    return 0;
+  }
+  if (slot < 0 || slot >= max_slots_) return fail("slot out of range");
+  switch (what) {
+    case MSF_DBG_LEVEL_PIXELS: {
+      if (level < 1 || level >= g.nlevels) return fail("level must be 1..7 (level 0 is the input frame)");
+      return copy_out(d_pyr_ + (size_t)slot * g.pyr_bytes + g.lv[level].pix_off, (size_t)g.lv[level].pitch * g.lv[level].h);
+    }
+    case MSF_DBG_FAST_CANDS: {
+      if (level < 0 || level >= g.nlevels) return fail("bad level");
+      uint32_t n = 0;
+      hipMemcpy(&n, d_cand_cnt_ + (size_t)slot * kOrbLevels + level, 4, hipMemcpyDeviceToHost);
+      if (n > (uint32_t)g.lv[level].cand_cap) n = g.lv[level].cand_cap;
+      std::vector<uint2> tmp(n);
+      if (n) hipMemcpy(tmp.data(), d_cand_ + (size_t)slot * g.cand_total + g.lv[level].cand_off, n * sizeof(uint2), hipMemcpyDeviceToHost);
+      std::vector<int32_t> o(n * 3);
+      for (uint32_t i = 0; i < n; i++) { o[i * 3] = tmp[i].x & 0xFFFF; o[i * 3 + 1] = tmp[i].x >> 16; o[i * 3 + 2] = tmp[i].y; }
+      *n_bytes = o.size() * 4;
+      memcpy(host_out, o.data(), *n_bytes < cap ? *n_bytes : cap);
+      return 0;
+    }
+    case MSF_DBG_STAGE1: {
+      if (level < 0 || level >= g.nlevels) return fail("bad level");
+      uint32_t n = 0;
+      hipMemcpy(&n, d_s1_cnt_ + (size_t)slot * kOrbLevels + level, 4, hipMemcpyDeviceToHost);
+      std::vector<uint4> tmp(n);
+      if (n) hipMemcpy(tmp.data(), d_s1_ + (size_t)slot * g.s1_total + g.lv[level].s1_off, n * sizeof(uint4), hipMemcpyDeviceToHost);
+      std::vector<msf_keypoint> o(n);
+      for (uint32_t i = 0; i < n; i++) {
+        o[i].lx = tmp[i].x & 0xFFFF; o[i].ly = tmp[i].x >> 16; o[i].x = (float)o[i].lx; o[i].y = (float)o[i].ly;
+        memcpy(&o[i].response, &tmp[i].y, 4); o[i].angle = -1.f; o[i].octave = level; o[i].fast_score = tmp[i].z;
+      }
+      *n_bytes = o.size() * sizeof(msf_keypoint);
+      memcpy(host_out, o.data(), *n_bytes < cap ? *n_bytes : cap);
+      return 0;
+    }
+    case MSF_DBG_KEYPOINTS:
+    case MSF_DBG_DESCRIPTORS: {
+      uint32_t n = 0;
+      hipMemcpy(&n, d_kp_cnt_ + slot, 4, hipMemcpyDeviceToHost);
+      if (n > (uint32_t)kKpCap) n = kKpCap;
+      if (what == MSF_DBG_KEYPOINTS) return copy_out(d_kp_ + (size_t)slot * kKpCap, n * sizeof(msf_keypoint));
+      return copy_out(d_desc_ + (size_t)slot * kKpCap * 32, (size_t)n * 32);
+    }
+    default:
+      return fail("unknown debug item for ORB");
+  }
+}
+
+}  // namespace msf

@@ -1,0 +1,95 @@
+// ORB extract + match on gfx950: host-side launcher interface (implemented in orb_kernels.hip).
+//
+// Replaces the arithmetic behind the reference's ::FeatureMatcher::MatchFrames
+// (src/featurematcher.cpp:10-45): cv::ORB::detectAndCompute x2 + BFMatcher::knnMatch(k=2)
+// + ratio test.  Stage names follow SURVEY.md 2.4 (K1..K11).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "msf_abi.h"
+
+namespace msf {
+
+constexpr int kOrbLevels = 8;
+constexpr int kKpCap = 2048;       // keypoints per frame (cv::ORB nfeatures = 500, + ties)
+constexpr int kOrbStages = 6;
+constexpr int kS1Cap = 8192;       // per level: keypoints kept by retainBest(2N) on the FAST score (+ ties)
+
+struct OrbLevelInfo {
+  int w, h, pitch;     // level size, row pitch in bytes (multiple of 16)
+  int quota;           // nfeaturesPerLevel
+  float scale;         // getScale(level)
+  int cand_cap;        // capacity of the FAST candidate list of this level
+  int cand_off;        // offset (entries) of this level inside a slot's candidate array
+  int s1_off;          // offset (entries) of this level inside a slot's stage-1 array
+  int tiles_x, tiles_y, tile_base;  // FAST tiling
+  int tab_off;         // offset (entries) of this level's resize tables
+  long long pix_off;   // byte offset of this level inside a slot's pyramid blob (levels >= 1)
+};
+
+struct OrbGeometry {
+  int nlevels;
+  int w0, h0;
+  int total_tiles;
+  int cand_total;          // candidate entries per slot
+  int s1_total;            // stage-1 entries per slot
+  long long pyr_bytes;     // pyramid blob bytes per slot (levels 1..)
+  OrbLevelInfo lv[kOrbLevels];
+  int umax[16];
+};
+
+// where level 0 of slot s lives: slot < n_a ? a + slot*frame_stride : b + (slot-n_a)*frame_stride
+struct FrameSrc {
+  const uint8_t* a;
+  const uint8_t* b;
+  int n_a;
+  int slot0;               // first feature slot written by this call
+  long long frame_stride;
+  int row_stride;
+};
+
+class OrbPipeline {
+ public:
+  OrbPipeline() = default;
+  ~OrbPipeline();
+  // returns empty string on success
+  std::string init(int width, int height, int max_slots, bool blur_half_up, bool profile);
+  void destroy();
+
+  // extract features of n frames into slots [src.slot0, src.slot0 + n)
+  hipError_t extract(const FrameSrc& src, int n_frames, hipStream_t st);
+  // match slot pairs; d_slot_a/d_slot_b may be null => pair i = (i, n_pairs + i)
+  hipError_t match(int n_pairs, const int32_t* d_slot_a, const int32_t* d_slot_b, float ratio,
+                   msf_match* d_out, int cap_per_pair, int32_t* d_n_out, hipStream_t st);
+
+  const OrbGeometry& geom() const { return g_; }
+  int max_slots() const { return max_slots_; }
+  int debug_get(int what, int slot, int level, void* host_out, size_t cap, size_t* n_bytes, std::string* err);
+  int stage_times(const char** names, float* ms, int cap);
+
+ private:
+  OrbGeometry g_{};
+  int max_slots_ = 0;
+  bool half_up_ = false, profile_ = false;
+  // device storage
+  uint8_t* d_pyr_ = nullptr;
+  uint16_t* d_tab_ = nullptr;      // resize tables
+  uint32_t* d_cand_cnt_ = nullptr; // [slots][8]
+  uint2* d_cand_ = nullptr;        // [slots][cand_total] (key, score)
+  uint32_t* d_s1_cnt_ = nullptr;   // [slots][8]
+  uint4* d_s1_ = nullptr;          // [slots][s1_total] (key, response bits, score, 0)
+  msf_keypoint* d_kp_ = nullptr;   // [slots][kKpCap]
+  uint8_t* d_desc_ = nullptr;      // [slots][kKpCap][32]
+  uint32_t* d_kp_cnt_ = nullptr;   // [slots]
+  uint32_t* d_status_ = nullptr;   // [slots]
+  hipEvent_t ev_[kOrbStages + 2] = {};
+  bool ev_ok_ = false, ev_recorded_ = false;
+  FrameSrc last_src_{};
+};
+
+}  // namespace msf

@@ -1,0 +1,173 @@
+"""Host-side mirror of the reference's matcher classes over the C ABI (include/msf_abi.h).
+
+  FeatureMatcher     <- ::FeatureMatcher     (src/featurematcher.h:7-22,   src/featurematcher.cpp:3-47)
+  DNNFeatureMatcher  <- ::DNNFeatureMatcher  (src/dnnfeaturematcher.h:9-36, src/dnnfeaturematcher.cpp:11-103)
+
+Same names and argument meaning (threshold, SetThreshold, MatchFrames(frame1, frame2)); a frame is the
+8-bit single-channel image the reference reads from FrameBase::imGray (slam_pipeline/include/FrameBase.h:45).
+MatchFrames returns an int32 [m, 4] array: columns 0:2 are MatchFramesResult::keyPoints1, 2:4 keyPoints2
+(slam_pipeline/include/FeatureMatcher.h:15-19).  The C++ twin for linking into slam_pipeline is
+csrc/hip_feature_matcher.h.  All compute happens in libmsf.so on the GPU; there is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class MsfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("msf error %d: %s" % (code, msg))
+        self.code = code
+
+
+class _Matcher:
+    _kind = None
+
+    def __init__(self, threshold, image_width, image_height, device=0, max_batch_pairs=1, flags=0,
+                 weights_path=None):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        cfg = _lib.Config()
+        self._L.msf_default_config(C.byref(cfg), self._kind)
+        cfg.threshold = threshold
+        cfg.device = device
+        cfg.image_width = image_width
+        cfg.image_height = image_height
+        cfg.max_batch_pairs = max_batch_pairs
+        cfg.flags = flags
+        self._wpath = weights_path.encode() if weights_path else None
+        cfg.weights_path = self._wpath
+        rc = self._L.msf_create(C.byref(cfg), C.byref(self._h))
+        if rc != _lib.MSF_OK:
+            msg = self._L.msf_last_error(None).decode()
+            self._h = C.c_void_p()
+            raise MsfError(rc, msg)
+        self.width, self.height = image_width, image_height
+        self.max_batch_pairs = max_batch_pairs
+        self.device = device
+        self.threshold = threshold
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.msf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != _lib.MSF_OK:
+            raise MsfError(rc, self._L.msf_last_error(self._h).decode())
+
+    # --- reference API -------------------------------------------------------------------------
+    def SetThreshold(self, value):
+        self._check(self._L.msf_set_threshold(self._h, float(value)))
+        self.threshold = float(value)
+
+    @staticmethod
+    def _image(arr):
+        if arr.dtype != np.uint8 or arr.ndim != 2 or arr.strides[1] != 1:
+            raise ValueError("frames must be 2-D uint8 with unit column stride (CV_8UC1)")
+        return _lib.Image(arr.ctypes.data, arr.shape[1], arr.shape[0], arr.strides[0])
+
+    def MatchFrames(self, frame1, frame2, cap=4096):
+        a, b = self._image(frame1), self._image(frame2)
+        out = np.zeros((cap,), _lib.MATCH_DTYPE)
+        n = C.c_int32(0)
+        self._check(self._L.msf_match_pair(self._h, C.byref(a), C.byref(b), out.ctypes.data, cap, C.byref(n)))
+        m = min(n.value, cap)
+        return out[:m].view(np.int32).reshape(m, 4).copy()
+
+    # --- batched forms -------------------------------------------------------------------------
+    def match_batch(self, frames1, frames2, cap=4096):
+        n = len(frames1)
+        A = (_lib.Image * n)(*[self._image(f) for f in frames1])
+        B = (_lib.Image * n)(*[self._image(f) for f in frames2])
+        out = np.zeros((n, cap), _lib.MATCH_DTYPE)
+        cnt = np.zeros((n,), np.int32)
+        self._check(self._L.msf_match_batch(self._h, n, A, B, out.ctypes.data, cap, cnt.ctypes.data))
+        return [out[i, :min(cnt[i], cap)].view(np.int32).reshape(-1, 4).copy() for i in range(n)]
+
+    def match_batch_device(self, d_a, d_b, d_out, d_n_out, stream=None):
+        """d_a/d_b: torch uint8 CUDA tensors [n, H, W(pitch)] resident in HBM; d_out int32 [n, cap, 4];
+        d_n_out int32 [n].  Asynchronous on `stream` (an int hipStream_t; None = handle stream + sync)."""
+        n = d_a.shape[0]
+        assert d_a.is_cuda and d_b.is_cuda and d_out.is_cuda and d_n_out.is_cuda
+        assert d_a.stride(2) == 1 and d_b.stride() == d_a.stride()
+        cap = d_out.shape[1]
+        self._check(self._L.msf_match_batch_device(
+            self._h, n, d_a.data_ptr(), d_b.data_ptr(), d_a.stride(0), d_a.stride(1),
+            d_out.data_ptr(), cap, d_n_out.data_ptr(), stream))
+
+    def stage_times(self):
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        n = self._L.msf_stage_times(self._h, names, ms, 16)
+        return {names[i].decode(): float(ms[i]) for i in range(n)}
+
+    # --- introspection (parity tests) ----------------------------------------------------------
+    def _debug(self, what, slot, level, dtype, cap_bytes):
+        buf = np.zeros((cap_bytes,), np.uint8)
+        nb = C.c_size_t(0)
+        self._check(self._L.msf_debug_get(self._h, what, slot, level, buf.ctypes.data, cap_bytes, C.byref(nb)))
+        if nb.value > cap_bytes:
+            return self._debug(what, slot, level, dtype, nb.value)
+        return buf[:nb.value].view(dtype).copy()
+
+
+class FeatureMatcher(_Matcher):
+    """ORB (cv::ORB::create() defaults) + BruteForce-Hamming 2-NN + ratio test, on the GPU."""
+    _kind = _lib.MSF_KIND_ORB
+
+    def __init__(self, threshold=0.8, image_width=640, image_height=480, **kw):
+        super().__init__(threshold, image_width, image_height, **kw)
+
+    def extract_device(self, d_frames, first_slot=0, stream=None):
+        self._check(self._L.msf_extract_device(self._h, d_frames.shape[0], d_frames.data_ptr(), d_frames.stride(0),
+                                               d_frames.stride(1), first_slot, stream))
+
+    def match_slots_device(self, d_slot_a, d_slot_b, d_out, d_n_out, stream=None):
+        self._check(self._L.msf_match_slots_device(self._h, d_slot_a.shape[0], d_slot_a.data_ptr(),
+                                                   d_slot_b.data_ptr(), d_out.data_ptr(), d_out.shape[1],
+                                                   d_n_out.data_ptr(), stream))
+
+    def level_sizes(self):
+        return self._debug(_lib.DBG_LEVEL_SIZES, 0, 0, np.int32, 8 * 4 * 4).reshape(8, 4)
+
+    def level_pixels(self, slot, level):
+        w, h, pitch, _ = self.level_sizes()[level]
+        return self._debug(_lib.DBG_LEVEL_PIXELS, slot, level, np.uint8, int(pitch) * int(h)).reshape(h, pitch)[:, :w]
+
+    def fast_candidates(self, slot, level):
+        return self._debug(_lib.DBG_FAST_CANDS, slot, level, np.int32, 1 << 20).reshape(-1, 3)
+
+    def stage1(self, slot, level):
+        return self._debug(_lib.DBG_STAGE1, slot, level, _lib.KP_DTYPE, 1 << 18)
+
+    def keypoints(self, slot):
+        return self._debug(_lib.DBG_KEYPOINTS, slot, 0, _lib.KP_DTYPE, 2048 * 32)
+
+    def descriptors(self, slot):
+        return self._debug(_lib.DBG_DESCRIPTORS, slot, 0, np.uint8, 2048 * 32).reshape(-1, 32)
+
+
+class DNNFeatureMatcher(_Matcher):
+    """LoFTR_teacher (model/LoFTR_teacher.onnx restated as HIP kernels) + threshold + decode, on the GPU."""
+    _kind = _lib.MSF_KIND_LOFTR
+
+    def __init__(self, model_file_path=None, threshold=0.15, image_width=640, image_height=480,
+                 model_resolution=16, **kw):
+        if model_resolution != 16:
+            raise MsfError(_lib.MSF_ERR_UNSUPPORTED, "LoFTR_teacher works at 1/16 resolution only")
+        super().__init__(threshold, image_width, image_height, weights_path=model_file_path, **kw)
+
+    def conf_matrix(self, pair=0):
+        return self._debug(_lib.DBG_LOFTR_CONF, pair, 0, np.float32, 1200 * 1200 * 4).reshape(1200, 1200)
+
+    def coarse_features(self, pair=0):
+        return self._debug(_lib.DBG_LOFTR_FEAT, pair, 0, np.float32, 2 * 1200 * 32 * 4).reshape(2, 1200, 32)
