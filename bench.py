@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- frame-pairs/sec (extract + match) of the MI355X-native matcher stage.
+
+A "step" is one pass of the hot path (ORB extract x2 + Hamming 2-NN + ratio test + match-list pack, and for
+N > 1 the RCCL gather of the packed match lists to rank 0) over one batch of synthetic 1280x720 pairs that
+is resident in HBM before the timed region starts (BASELINE.json configs[1]).  One process per GPU; launched
+by torch.distributed.run for N > 1.  Pairs are independent, so ranks shard them with no data-path collective
+other than the gather of results ("weak" scaling: every rank owns --pairs pairs).
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes_per_pair(w, h):
+    # 2*W*H u8 reads + <= 2*500*(8+32) B features + <= 500*16 B matches
+    return 2 * w * h + 2 * 500 * 40 + 500 * 16
+
+
+def cpu_baseline(args, A, B, gpu_lists):
+    """Times the CPU oracle (kind "port") on a bounded sample of the same pairs, one pair per thread."""
+    from concurrent.futures import ThreadPoolExecutor
+    import numpy as np
+    from oracle import orb as oracle_orb
+    cores = min(os.cpu_count() or 1, args.cpu_threads)
+    n = min(len(A), cores * args.cpu_pairs_per_thread)
+    oracle_orb.lib()
+
+    def work(t):
+        orc = oracle_orb.FeatureMatcherOracle(args.ratio)
+        res = []
+        for i in range(t, n, cores):
+            res.append((i, orc.MatchFrames(A[i], B[i])))
+        return res
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        results = [r for part in ex.map(work, range(cores)) for r in part]
+    dt = time.perf_counter() - t0
+    mismatches = 0
+    for i, m in results:
+        if gpu_lists is not None and not (len(m) == len(gpu_lists[i]) and np.array_equal(m, gpu_lists[i])):
+            mismatches += 1
+    return {"value": round(n / dt, 3), "unit": "frame-pairs/sec", "cores": cores, "kind": "port",
+            "sample": "%d of the same %dx%d pairs, oracle/orb_oracle.c (scalar C restatement), one pair per thread, %.1f s"
+                      % (n, args.width, args.height, dt),
+            "parity_mismatches_vs_gpu": mismatches}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=1024, help="pairs per GPU per step (resident in HBM)")
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--ratio", type=float, default=0.6, help="Lowe ratio (the app uses 0.6, src/main.cpp:66)")
+    ap.add_argument("--cap", type=int, default=1024, help="match-list capacity per pair")
+    ap.add_argument("--matcher", default="orb", choices=["orb", "loftr"])
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-pairs-per-thread", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mono_slam_framework_amd import _lib, synth
+    from mono_slam_framework_amd.matcher import DNNFeatureMatcher, FeatureMatcher
+
+    if args.matcher == "loftr":
+        args.width, args.height = 640, 480
+    W, H, P = args.width, args.height, args.pairs
+    # synthetic pairs of this rank (pair index = rank * P + i), resident in HBM before timing
+    A, B = synth.synth_batch(rank * P, P, W, H, threads=min(16, os.cpu_count() or 1))
+    dA, dB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+    if args.matcher == "orb":
+        fm = FeatureMatcher(args.ratio, W, H, device=local_rank, max_batch_pairs=P, flags=_lib.MSF_FLAG_PROFILE)
+    else:
+        fm = DNNFeatureMatcher(threshold=args.ratio if args.ratio < 0.5 else 0.15, device=local_rank,
+                               max_batch_pairs=P, flags=_lib.MSF_FLAG_PROFILE)
+    out = torch.zeros((P, args.cap, 4), dtype=torch.int32, device=dev)
+    cnt = torch.zeros((P,), dtype=torch.int32, device=dev)
+    packed = torch.zeros((P * args.cap, 4), dtype=torch.int32, device=dev)
+    offs = torch.zeros((P + 1,), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    totals = torch.zeros((world,), dtype=torch.int32, device=dev)
+    recv = [None] * world
+    stage_acc = {}
+
+    def step(timed):
+        fm.match_batch_device(dA, dB, out, cnt, stream=stream)
+        fm.pack_matches_device(out, cnt, packed, offs, stream=stream)
+        if world > 1:
+            # gather of variable-length match lists to rank 0: counts first, then exact-size send/recv
+            # (ncclSend/ncclRecv over xGMI); no all-reduce anywhere
+            dist.all_gather_into_tensor(totals, offs[P:P + 1])
+            dist.all_gather_into_tensor(all_offs, offs)
+            tl = totals.tolist()
+            if rank == 0:
+                ops = []
+                for r in range(1, world):
+                    if recv[r] is None or recv[r].shape[0] < tl[r]:
+                        recv[r] = torch.empty((max(tl[r], 1) * 2, 4), dtype=torch.int32, device=dev)
+                    if tl[r]:
+                        ops.append(dist.P2POp(dist.irecv, recv[r][:tl[r]], r))
+            else:
+                ops = [dist.P2POp(dist.isend, packed[:tl[rank]], 0)] if tl[rank] else []
+            if ops:
+                for w_ in dist.batch_isend_irecv(ops):
+                    w_.wait()
+        if timed:
+            for k, v in fm.stage_times().items():   # HIP events recorded on the launch stream
+                stage_acc[k] = stage_acc.get(k, 0.0) + v
+
+    if world > 1:
+        all_offs = torch.zeros((world * (P + 1),), dtype=torch.int32, device=dev)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)   # timing only, outside the timed region
+        dt = float(tmax.item())
+
+    if rank == 0:
+        cnt_h = cnt.cpu().numpy()
+        out_h = out.cpu().numpy()
+        lists = [out_h[i, :max(cnt_h[i], 0)] for i in range(P)]
+        ms_per_step = dt / args.steps * 1e3
+        value = world * P * args.steps / dt
+        bpp = algorithmic_bytes_per_pair(W, H)
+        stages = {k: v / args.steps for k, v in stage_acc.items()}
+        dom = max(stages, key=stages.get) if stages else None
+        roofline = None
+        if dom:
+            achieved = P * bpp / (stages[dom] * 1e-3) / 1e9
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.matcher)
+            if os.path.exists(tfile):
+                try:
+                    traffic = json.load(open(tfile)).get(dom)
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "hbm" if args.matcher == "orb" else "mfma", "kernel": dom,
+                        "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "avg_launch_ms": round(stages[dom], 4),
+                        "algorithmic_bytes_per_launch": P * bpp,
+                        "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+                        "pipeline_frac": round(value / world * bpp / 1e9 / HBM_PEAK_GBS, 5)}
+        line = {
+            "metric": "frame-pairs/sec (extract+match)", "value": round(value, 2), "unit": "frame-pairs/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8" if args.matcher == "orb" else "f32", "data": "synthetic",
+            "config": {"workload": "%s extract+match, %dx%d pairs, %d pairs/GPU/step resident in HBM, ratio %.2f"
+                                   % (args.matcher.upper(), W, H, P, args.ratio),
+                       "pairs_per_gpu": P, "width": W, "height": H,
+                       "matches_per_pair_mean": round(float(np.mean([len(l) for l in lists])), 2),
+                       "overflow_pairs": int((cnt_h < 0).sum())},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and args.matcher == "orb":
+            line["cpu_baseline"] = cpu_baseline(args, A, B, lists)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

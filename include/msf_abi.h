@@ -125,6 +125,12 @@ int msf_extract_device(msf_handle* h, int32_t n_frames, const uint8_t* d_frames,
 int msf_match_slots_device(msf_handle* h, int32_t n_pairs, const int32_t* d_slot_a, const int32_t* d_slot_b,
                            msf_match* d_out, int32_t cap_per_pair, int32_t* d_n_out, void* stream);
 
+/* Packs [n_pairs][cap_per_pair] match lists + counts into one contiguous device list:
+ * d_offsets[i] = start of pair i, d_offsets[n_pairs] = total; pairs with n_out < 0 contribute nothing.
+ * This is the payload of the multi-GPU gather of match lists (and of MatchFramesResult's vectors). */
+int msf_pack_matches_device(msf_handle* h, int32_t n_pairs, const msf_match* d_in, int32_t cap_per_pair,
+                            const int32_t* d_n_out, msf_match* d_packed, int32_t* d_offsets, void* stream);
+
 /* -------- introspection used by the parity tests and bench.py (not by the drop-in path) -------- */
 typedef enum msf_debug_what {
   MSF_DBG_LEVEL_SIZES = 0,   /* int32 [nlevels][4] = w, h, row pitch, quota */

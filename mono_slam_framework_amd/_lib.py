@@ -25,7 +25,8 @@ MSF_FLAG_PROFILE = 2
 # every symbol include/msf_abi.h declares
 ABI_SYMBOLS = ["msf_abi_version", "msf_default_config", "msf_create", "msf_destroy", "msf_set_threshold",
                "msf_last_error", "msf_match_pair", "msf_match_batch", "msf_match_batch_device",
-               "msf_extract_device", "msf_match_slots_device", "msf_debug_get", "msf_stage_times"]
+               "msf_extract_device", "msf_match_slots_device", "msf_pack_matches_device", "msf_debug_get",
+               "msf_stage_times"]
 
 
 class Config(C.Structure):
@@ -71,6 +72,7 @@ def load():
     L.msf_match_batch_device.argtypes = [vp, i32, vp, vp, i64, i64, vp, i32, vp, vp]
     L.msf_extract_device.argtypes = [vp, i32, vp, i64, i64, i32, vp]
     L.msf_match_slots_device.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp]
+    L.msf_pack_matches_device.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp]
     L.msf_debug_get.argtypes = [vp, i32, i32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.msf_stage_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(f32), i32]
     _lib = L

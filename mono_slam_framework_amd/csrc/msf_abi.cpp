@@ -11,6 +11,11 @@
 #include "loftr_pipeline.h"
 #include "orb_pipeline.h"
 
+namespace msf {
+hipError_t pack_matches(int n, const msf_match* d_in, int cap, const int32_t* d_cnt, msf_match* d_packed,
+                        int32_t* d_offsets, hipStream_t st);
+}
+
 namespace {
 thread_local std::string g_create_error;
 }
@@ -254,6 +259,21 @@ int msf_match_slots_device(msf_handle* h, int32_t n_pairs, const int32_t* d_slot
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
   if ((e = h->orb.match(n_pairs, d_slot_a, d_slot_b, h->cfg.threshold, d_out, cap_per_pair, d_n_out, st)) != hipSuccess)
     return hip_fail(h, "orb match", e);
+  if (!stream && (e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(h, "hipStreamSynchronize", e);
+  return MSF_OK;
+}
+
+int msf_pack_matches_device(msf_handle* h, int32_t n_pairs, const msf_match* d_in, int32_t cap_per_pair,
+                            const int32_t* d_n_out, msf_match* d_packed, int32_t* d_offsets, void* stream) {
+  if (!h) return MSF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (n_pairs < 0 || !d_in || !d_n_out || !d_packed || !d_offsets || cap_per_pair < 1)
+    return fail(h, MSF_ERR_INVALID_ARG, "msf_pack_matches_device: bad argument");
+  hipError_t e = hipSetDevice(h->cfg.device);
+  if (e != hipSuccess) return hip_fail(h, "hipSetDevice", e);
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  if ((e = msf::pack_matches(n_pairs, d_in, cap_per_pair, d_n_out, d_packed, d_offsets, st)) != hipSuccess)
+    return hip_fail(h, "pack_matches", e);
   if (!stream && (e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(h, "hipStreamSynchronize", e);
   return MSF_OK;
 }

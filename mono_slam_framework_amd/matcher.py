@@ -104,6 +104,12 @@ class _Matcher:
             self._h, n, d_a.data_ptr(), d_b.data_ptr(), d_a.stride(0), d_a.stride(1),
             d_out.data_ptr(), cap, d_n_out.data_ptr(), stream))
 
+    def pack_matches_device(self, d_out, d_n_out, d_packed, d_offsets, stream=None):
+        """[n, cap, 4] + counts -> contiguous [total, 4] prefix of d_packed, offsets int32 [n + 1]."""
+        self._check(self._L.msf_pack_matches_device(self._h, d_out.shape[0], d_out.data_ptr(), d_out.shape[1],
+                                                    d_n_out.data_ptr(), d_packed.data_ptr(), d_offsets.data_ptr(),
+                                                    stream))
+
     def stage_times(self):
         names = (C.c_char_p * 16)()
         ms = (C.c_float * 16)()
