@@ -1,0 +1,92 @@
+"""GPU parity tests for the LoFTR path through the C ABI: confidences within 1e-3 of the reference graph
+(golden fixtures produced from model/LoFTR_teacher.onnx) and of the CPU restatement; match lists identical
+wherever |conf - thr| > 1e-3.  Reference path: src/dnnfeaturematcher.cpp:44-102."""
+import os
+
+import numpy as np
+import pytest
+
+from mono_slam_framework_amd import synth
+from oracle import loftr as oracle_loftr
+
+pytestmark = pytest.mark.gpu
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "loftr_kat.npz"))
+CONF_TOL = 1e-3   # north_star: "LoFTR match confidences within 1e-3"
+
+
+def _dm(thr=0.15, pairs=1):
+    from mono_slam_framework_amd.matcher import DNNFeatureMatcher
+    return DNNFeatureMatcher(threshold=thr, max_batch_pairs=pairs)
+
+
+def _check_lists(got, conf_ref, thr):
+    """identical match lists wherever |conf - thr| > tol: got must contain every sure hit and no sure miss"""
+    sure = oracle_loftr.DNNFeatureMatcherOracle(thr).decode(conf_ref, thr + CONF_TOL)
+    maybe = oracle_loftr.DNNFeatureMatcherOracle(thr).decode(conf_ref, thr - CONF_TOL)
+    gs = set(map(tuple, got))
+    assert set(map(tuple, sure)) <= gs <= set(map(tuple, maybe))
+    # order: row-major over (i, j)  (cv::findNonZero)
+    key = [(y1 // 16) * 40 + x1 // 16 for x1, y1, _, _ in got]
+    key2 = [(y2 // 16) * 40 + x2 // 16 for _, _, x2, y2 in got]
+    assert all((a, b) < (c, d) for (a, b), (c, d) in zip(zip(key, key2), list(zip(key, key2))[1:]))
+
+
+@pytest.mark.parametrize("name", ["i", "ii", "iii", "synth"])
+def test_conf_and_matches_vs_golden(name):
+    a, b = G["img0_" + name], G["img1_" + name]
+    dm = _dm(0.15)
+    got = dm.MatchFrames(a, b, cap=8192)
+    conf = dm.conf_matrix()
+    feat = dm.coarse_features()
+    assert np.abs(feat[0] - G["feat0_" + name]).max() < 1e-3
+    assert np.abs(feat[1] - G["feat1_" + name]).max() < 1e-3
+    bi, bv = G["big_ij_" + name].astype(int), G["big_v_" + name]
+    si, sv = G["samp_ij_" + name].astype(int), G["samp_v_" + name]
+    if len(bv):
+        assert np.abs(conf[bi[:, 0], bi[:, 1]] - bv).max() <= CONF_TOL
+    assert np.abs(conf[si[:, 0], si[:, 1]] - sv).max() <= CONF_TOL
+    assert np.abs(conf.sum(1) - G["rowsum_" + name]).max() < 5e-3
+    # golden match lists: exact unless an entry sits within tol of the threshold
+    exp = G["matches_%s_015" % name]
+    full_ref = oracle_loftr.DNNFeatureMatcherOracle(0.15).run(a, b)["conf"]
+    assert np.abs(conf - full_ref).max() <= CONF_TOL
+    _check_lists(got, full_ref, 0.15)
+    near = np.abs(full_ref - 0.15) <= CONF_TOL
+    if not near.any():
+        np.testing.assert_array_equal(got, exp)
+    dm.SetThreshold(0.1)
+    got10 = dm.MatchFrames(a, b, cap=8192)
+    _check_lists(got10, full_ref, 0.1)
+    if not (np.abs(full_ref - 0.1) <= CONF_TOL).any():
+        np.testing.assert_array_equal(got10, G["matches_%s_010" % name])
+
+
+def test_batch_equals_single_and_chunks():
+    n = 5
+    A, B = synth.synth_batch(40, n, 640, 480, mode=1)
+    single = _dm(0.15)
+    ref = [single.MatchFrames(A[i], B[i], cap=8192) for i in range(n)]
+    batched = _dm(0.15, pairs=2).match_batch(list(A), list(B), cap=8192)   # chunks of 2
+    for r, g in zip(ref, batched):
+        np.testing.assert_array_equal(r, g)
+
+
+def test_low_threshold_capacity_and_count():
+    a, b = G["img0_ii"], G["img1_ii"]
+    dm = _dm(1e-4)
+    from mono_slam_framework_amd.matcher import MsfError
+    full_ref = oracle_loftr.DNNFeatureMatcherOracle(1e-4).run(a, b)["conf"]
+    n_ref = int((full_ref > 1e-4).sum())
+    assert n_ref > 4096
+    with pytest.raises(MsfError):         # the host staging list (4096) is shorter than the result: loud, not silent
+        dm.MatchFrames(a, b, cap=100000)
+    got = dm.MatchFrames(a, b, cap=64)    # caller-side truncation is part of the contract
+    assert len(got) == 64
+
+
+def test_wrong_size_is_unsupported():
+    from mono_slam_framework_amd.matcher import DNNFeatureMatcher, MsfError
+    with pytest.raises(MsfError) as e:
+        DNNFeatureMatcher(threshold=0.15, image_width=1280, image_height=720)
+    assert e.value.code == -3
