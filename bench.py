@@ -19,6 +19,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, exact f32 (the LoFTR path's dtype)
+LOFTR_FLOPS_PER_PAIR = 2.601e9  # conv 2.273 G + matmul 0.328 G (2 x MAC)
+LOFTR_CONV_FLOPS_PER_PAIR = 2.273e9
 
 
 def algorithmic_bytes_per_pair(w, h):
@@ -56,6 +59,21 @@ def cpu_baseline(args, A, B, gpu_lists):
             "parity_mismatches_vs_gpu": mismatches}
 
 
+def cpu_baseline_loftr(args, A, B, gpu_lists):
+    """LoFTR CPU baseline: the C restatement (OpenMP over its convolutions), pairs one after another."""
+    import numpy as np
+    from oracle import loftr as oracle_loftr
+    orc = oracle_loftr.DNNFeatureMatcherOracle(args.threshold)
+    n = min(len(A), args.cpu_loftr_pairs)
+    t0 = time.perf_counter()
+    res = [orc.MatchFrames(A[i], B[i]) for i in range(n)]
+    dt = time.perf_counter() - t0
+    mism = sum(0 if (len(m) == len(gpu_lists[i]) and np.array_equal(m, gpu_lists[i])) else 1 for i, m in enumerate(res))
+    return {"value": round(n / dt, 3), "unit": "frame-pairs/sec", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d of the same 640x480 pairs, oracle/loftr_oracle.c (f32 C restatement, OpenMP), %.1f s" % (n, dt),
+            "match_list_mismatches_vs_gpu": mism}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +87,8 @@ def main():
     ap.add_argument("--matcher", default="orb", choices=["orb", "loftr"])
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--cpu-pairs-per-thread", type=int, default=2)
+    ap.add_argument("--cpu-loftr-pairs", type=int, default=8)
+    ap.add_argument("--threshold", type=float, default=0.15, help="LoFTR confidence threshold (dnnfeaturematcher.h:11)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -94,51 +114,40 @@ def main():
 
     if args.matcher == "loftr":
         args.width, args.height = 640, 480
+        if args.pairs == 1024:
+            args.pairs = 256
     W, H, P = args.width, args.height, args.pairs
     # synthetic pairs of this rank (pair index = rank * P + i), resident in HBM before timing
-    A, B = synth.synth_batch(rank * P, P, W, H, threads=min(16, os.cpu_count() or 1))
+    A, B = synth.synth_batch(rank * P, P, W, H, mode=1 if args.matcher == "loftr" else 0,
+                             threads=min(16, os.cpu_count() or 1))
     dA, dB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
     if args.matcher == "orb":
         fm = FeatureMatcher(args.ratio, W, H, device=local_rank, max_batch_pairs=P, flags=_lib.MSF_FLAG_PROFILE)
     else:
-        fm = DNNFeatureMatcher(threshold=args.ratio if args.ratio < 0.5 else 0.15, device=local_rank,
-                               max_batch_pairs=P, flags=_lib.MSF_FLAG_PROFILE)
+        fm = DNNFeatureMatcher(threshold=args.threshold, device=local_rank, max_batch_pairs=P,
+                               flags=_lib.MSF_FLAG_PROFILE)
     out = torch.zeros((P, args.cap, 4), dtype=torch.int32, device=dev)
     cnt = torch.zeros((P,), dtype=torch.int32, device=dev)
     packed = torch.zeros((P * args.cap, 4), dtype=torch.int32, device=dev)
     offs = torch.zeros((P + 1,), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    totals = torch.zeros((world,), dtype=torch.int32, device=dev)
-    recv = [None] * world
+    from mono_slam_framework_amd.gather import MatchListGather
+    gather = MatchListGather(P, dev) if world > 1 else None
     stage_acc = {}
+    gathered = [0]
 
     def step(timed):
         fm.match_batch_device(dA, dB, out, cnt, stream=stream)
         fm.pack_matches_device(out, cnt, packed, offs, stream=stream)
-        if world > 1:
-            # gather of variable-length match lists to rank 0: counts first, then exact-size send/recv
-            # (ncclSend/ncclRecv over xGMI); no all-reduce anywhere
-            dist.all_gather_into_tensor(totals, offs[P:P + 1])
-            dist.all_gather_into_tensor(all_offs, offs)
-            tl = totals.tolist()
-            if rank == 0:
-                ops = []
-                for r in range(1, world):
-                    if recv[r] is None or recv[r].shape[0] < tl[r]:
-                        recv[r] = torch.empty((max(tl[r], 1) * 2, 4), dtype=torch.int32, device=dev)
-                    if tl[r]:
-                        ops.append(dist.P2POp(dist.irecv, recv[r][:tl[r]], r))
-            else:
-                ops = [dist.P2POp(dist.isend, packed[:tl[rank]], 0)] if tl[rank] else []
-            if ops:
-                for w_ in dist.batch_isend_irecv(ops):
-                    w_.wait()
+        if gather is not None:
+            # gather of variable-length match lists to rank 0 (all-gather of offsets, then exact-size
+            # ncclSend/ncclRecv over xGMI); no all-reduce in the data path
+            res = gather(packed, offs)
+            if res is not None:
+                gathered[0] = sum(int(r[0].shape[0]) for r in res)
         if timed:
             for k, v in fm.stage_times().items():   # HIP events recorded on the launch stream
                 stage_acc[k] = stage_acc.get(k, 0.0) + v
-
-    if world > 1:
-        all_offs = torch.zeros((world * (P + 1),), dtype=torch.int32, device=dev)
 
     def fence():
         if world > 1:
@@ -168,7 +177,16 @@ def main():
         stages = {k: v / args.steps for k, v in stage_acc.items()}
         dom = max(stages, key=stages.get) if stages else None
         roofline = None
-        if dom:
+        if dom and args.matcher == "loftr":
+            # dominant "kernel" = the 22-launch convolution stack (k_conv<...>) of one call
+            flops = P * (LOFTR_CONV_FLOPS_PER_PAIR if dom == "backbone_convs" else LOFTR_FLOPS_PER_PAIR)
+            achieved = flops / (stages[dom] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 5), "traffic": None,
+                        "avg_launch_ms": round(stages[dom], 4), "algorithmic_flops_per_launch": flops,
+                        "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+                        "pipeline_frac": round(value / world * LOFTR_FLOPS_PER_PAIR / 1e12 / MFMA_F32_PEAK_TFLOPS, 5)}
+        elif dom:
             achieved = P * bpp / (stages[dom] * 1e-3) / 1e9
             traffic = None
             tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.matcher)
@@ -189,15 +207,16 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8" if args.matcher == "orb" else "f32", "data": "synthetic",
-            "config": {"workload": "%s extract+match, %dx%d pairs, %d pairs/GPU/step resident in HBM, ratio %.2f"
-                                   % (args.matcher.upper(), W, H, P, args.ratio),
+            "config": {"workload": "%s extract+match, %dx%d pairs, %d pairs/GPU/step resident in HBM, %s"
+                                   % (args.matcher.upper(), W, H, P,
+                                      "ratio %.2f" % args.ratio if args.matcher == "orb" else "conf threshold %.2f" % args.threshold),
                        "pairs_per_gpu": P, "width": W, "height": H,
                        "matches_per_pair_mean": round(float(np.mean([len(l) for l in lists])), 2),
                        "overflow_pairs": int((cnt_h < 0).sum())},
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline and args.matcher == "orb":
-            line["cpu_baseline"] = cpu_baseline(args, A, B, lists)
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = (cpu_baseline if args.matcher == "orb" else cpu_baseline_loftr)(args, A, B, lists)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

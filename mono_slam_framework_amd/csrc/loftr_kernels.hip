@@ -500,7 +500,8 @@ struct LoftrPipeline::Impl {
   float* feat_dbg = nullptr; // [2][1200][32]
   int dbg_pair = 0;
   bool have_dbg = false;
-  hipEvent_t ev[5] = {};
+  std::vector<hipEvent_t> ev;  // 4 per chunk
+  int ev_chunks = 0;
   bool ev_ok = false, ev_rec = false;
 };
 
@@ -509,7 +510,7 @@ LoftrPipeline::~LoftrPipeline() { destroy(); }
 void LoftrPipeline::destroy() {
   if (!p_) return;
   for (float* a : p_->allocs) hipFree(a);
-  if (p_->ev_ok) for (auto& e : p_->ev) hipEventDestroy(e);
+  for (auto& e : p_->ev) hipEventDestroy(e);
   delete p_;
   p_ = nullptr;
 }
@@ -674,6 +675,7 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
   LF_TRY(dalloc(&P.conf_dbg, (size_t)NTOK * NTOK));
   LF_TRY(dalloc(&P.feat_dbg, (size_t)2 * NTOK * DM));
   if (profile) {
+    P.ev.resize((size_t)4 * ((max_pairs + P.chunk - 1) / P.chunk));
     for (auto& e : P.ev) LF_TRY(hipEventCreate(&e));
     P.ev_ok = true;
   }
@@ -711,7 +713,8 @@ hipError_t LoftrPipeline::match(int n_pairs, const uint8_t* d_a, const uint8_t* 
     const int n = std::min(P.chunk, n_pairs - p0);
     const int ni = 2 * n;  // images: [0, n) = frame 1 of each pair, [n, 2n) = frame 2
     const bool first = p0 == 0;
-    if (P.ev_ok && first) hipEventRecord(P.ev[0], st);
+    hipEvent_t* ev = P.ev_ok ? &P.ev[(size_t)4 * (p0 / P.chunk)] : nullptr;
+    if (ev) hipEventRecord(ev[0], st);
     // the stem reads u8 frames from two arrays: launch it per array
     const ConvDesc* c = P.conv;
     float *a = P.bufA, *b = P.bufB, *cc = P.bufC, *d = P.bufD;
@@ -745,7 +748,7 @@ hipError_t LoftrPipeline::match(int n_pairs, const uint8_t* d_a, const uint8_t* 
     launch_conv<32, 32, 3, 1, 16, true, false, false>(c[18], cc, s40, 0, nullptr, b, ni, st);
     launch_conv<32, 32, 3, 1, 16, true, true, false>(c[19], b, s40, 0, cc, a, ni, st);             // a = 244
     launch_conv<32, 32, 1, 1, 16, false, false, false>(c[20], a, s40, 0, nullptr, b, ni, st);      // b = 245
-    if (P.ev_ok && first) hipEventRecord(P.ev[1], st);
+    if (ev) hipEventRecord(ev[1], st);
     // tokens: images [0,n) -> tok[0] (feat0), [n,2n) -> tok[1] (feat1)
     const long long ts = (long long)NTOK * DM;
     hipLaunchKernelGGL(k_tokens, dim3((n * NTOK * DM + 255) / 256), dim3(256), 0, st, b, P.d_pe, P.tok[0], n);
@@ -759,7 +762,7 @@ hipError_t LoftrPipeline::match(int n_pairs, const uint8_t* d_a, const uint8_t* 
       hipLaunchKernelGGL(k_attn_update, dim3((NTOK + 63) / 64, n), dim3(64), 0, st, seq[bi].x, ts, P.kv, P.blk[bi],
                          seq[bi].o, ts);
     }
-    if (P.ev_ok && first) hipEventRecord(P.ev[2], st);
+    if (ev) hipEventRecord(ev[2], st);
     // matching head on (f0, f1)
     hipLaunchKernelGGL(k_sim_stats, dim3(NTOK / STRIP, n), dim3(256), 0, st, f0, f1, ts, P.rstats, 2LL * NTOK);
     hipLaunchKernelGGL(k_sim_stats, dim3(NTOK / STRIP, n), dim3(256), 0, st, f1, f0, ts, P.cstats, 2LL * NTOK);
@@ -772,7 +775,7 @@ hipError_t LoftrPipeline::match(int n_pairs, const uint8_t* d_a, const uint8_t* 
       hipMemcpyAsync(P.feat_dbg + ts, f1, ts * sizeof(float), hipMemcpyDeviceToDevice, st);
       P.have_dbg = true;
     }
-    if (P.ev_ok && first) { hipEventRecord(P.ev[3], st); P.ev_rec = true; }
+    if (ev) { hipEventRecord(ev[3], st); P.ev_rec = true; P.ev_chunks = p0 / P.chunk + 1; }
   }
   return hipGetLastError();
 }
@@ -780,11 +783,15 @@ hipError_t LoftrPipeline::match(int n_pairs, const uint8_t* d_a, const uint8_t* 
 int LoftrPipeline::stage_times(const char** names, float* ms, int cap) {
   static const char* kNames[3] = {"backbone_convs", "transformer", "match_head"};
   if (!p_ || !p_->ev_ok || !p_->ev_rec) return 0;
-  if (hipEventSynchronize(p_->ev[3]) != hipSuccess) return 0;
+  if (hipEventSynchronize(p_->ev[(size_t)4 * p_->ev_chunks - 1]) != hipSuccess) return 0;
   int n = 0;
   for (int i = 0; i < 3 && n < cap; i++, n++) {
     names[n] = kNames[i];
-    if (hipEventElapsedTime(&ms[n], p_->ev[i], p_->ev[i + 1]) != hipSuccess) ms[n] = -1.f;
+    ms[n] = 0.f;
+    for (int c = 0; c < p_->ev_chunks; c++) {   // sum over the chunks of the last call
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, p_->ev[(size_t)4 * c + i], p_->ev[(size_t)4 * c + i + 1]) == hipSuccess) ms[n] += t;
+    }
   }
   return n;
 }

@@ -1,0 +1,41 @@
+"""The C++ host-side mirror of the reference's matcher classes (csrc/hip_feature_matcher.h) builds with plain g++
+against libmsf.so; on a GPU box it reproduces the oracle's match list, without a GPU its constructor throws
+(no CPU fallback)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(tmp_path):
+    from mono_slam_framework_amd import build
+    from oracle import orb as oracle_orb
+    lib = build.lib_path()
+    synth = build.ensure_synth()
+    osol = oracle_orb.build()
+    exe = str(tmp_path / "test_host_mirror")
+    pkg = os.path.join(ROOT, "mono_slam_framework_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(pkg, "csrc"), "-I", os.path.join(ROOT, "oracle"),
+                           os.path.join(ROOT, "tests", "cpp", "test_host_mirror.cpp"), lib, synth, osol,
+                           "-Wl,-rpath," + pkg, "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
+                           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-o", exe])
+    return exe
+
+
+def test_host_mirror_builds_and_fails_loudly_without_gpu(tmp_path):
+    import torch
+    exe = _build(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "no HIP device" in r.stdout
+
+
+@pytest.mark.gpu
+def test_host_mirror_parity_on_gpu(tmp_path):
+    exe = _build(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
