@@ -11,6 +11,7 @@
 #include "orb_pipeline.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "orb_pattern.h"
@@ -43,99 +44,123 @@ __device__ __forceinline__ const uint8_t* level_ptr(const OrbGeometry& g, const 
 }
 
 // ------------------------------------------------------------------ K2: pyramid level l from l-1
-// cv::resize(..., INTER_LINEAR_EXACT) restated: 8.8 fixed-point taps from host tables,
-// 16-bit horizontal sums, 32-bit vertical, (v + 32768) >> 16.  One thread = 4 output pixels.
+// cv::resize(..., INTER_LINEAR_EXACT) restated: 8.8 fixed-point taps from host tables, 16-bit horizontal sums,
+// 32-bit vertical, (v + 32768) >> 16.  A workgroup makes a 64x16 output tile: the source window (<= 24 rows x
+// 96 bytes) is staged in LDS through coalesced dword loads, then each lane blends 4 consecutive output pixels
+// and stores them as one dword.  Taps with weight 0 may read one byte past the image: staged as 0, times 0.
+constexpr int RTW = 64, RTH = 64, RLW = 96, RLH = 84;   // big tiles: the launch is latency-bound, not ALU-bound
 __global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uint8_t* pyr,
-                                                const uint16_t* __restrict__ tab, int l) {
+                                                const uint16_t* __restrict__ tab, int l, int dbg) {
+  __shared__ __attribute__((aligned(16))) uint8_t t[RLH * RLW];
   const int fi = blockIdx.z;
   const OrbLevelInfo L = g.lv[l];
+  const int sh = g.lv[l - 1].h;
   int spitch;
   const uint8_t* s = level_ptr(g, src, pyr, fi, l - 1, &spitch);
   uint8_t* d = pyr + (long long)(src.slot0 + fi) * g.pyr_bytes + L.pix_off;
-  const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (y >= L.h || x4 >= L.w) return;
   const uint16_t* xofs = tab + L.tab_off;
   const uint16_t* xw = xofs + L.w;
   const uint16_t* yofs = xw + L.w;
   const uint16_t* yw = yofs + L.h;
-  const int sy = yofs[y];
-  const uint32_t wy1 = yw[y], wy0 = 256u - wy1;
-  const uint8_t* r0 = s + (long long)sy * spitch;
-  const uint8_t* r1 = wy1 ? r0 + spitch : r0;
-  uint32_t packed = 0;
+  const int X0 = blockIdx.x * RTW, Y0 = blockIdx.y * RTH, tid = threadIdx.x;
+  const int sx0 = xofs[X0] & ~3, sy0 = yofs[Y0];
+  const int nrow = yofs[min(Y0 + RTH - 1, L.h - 1)] + 2 - sy0;   // <= RLH for any 1.2x level pair
+  for (int i = tid; i < RLH * (RLW / 4); i += 256) {
+    const int r = i / (RLW / 4), c = i % (RLW / 4);
+    if (r >= nrow) break;
+    const int gx = sx0 + 4 * c, gy = sy0 + r;
+    uint32_t v = 0;
+    if (gy < sh && gx + 4 <= spitch && !(dbg & 1)) v = *reinterpret_cast<const uint32_t*>(s + (long long)gy * spitch + gx);
+    reinterpret_cast<uint32_t*>(t)[i] = v;
+  }
+  __syncthreads();
+  const int x4 = X0 + 4 * (tid & 15);
+  if (x4 >= L.w || (dbg & 2)) return;
+  // LDS is read as ALIGNED dwords and the two taps are cut out with v_alignbyte: adjacent byte reads get fused
+  // by the compiler into misaligned ds_read_u16, which the LDS replays (measured: 5x slower kernel).
+  const uint32_t* T = reinterpret_cast<const uint32_t*>(t);
+  int wofs[4];
+  uint32_t bsh[4], wx1[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const int x = x4 + i;
-    if (x < L.w) {
-      const int sx = xofs[x];
-      const uint32_t wx1 = xw[x], wx0 = 256u - wx1;
-      const int sx1 = wx1 ? sx + 1 : sx;
-      const uint32_t h0 = wx0 * r0[sx] + wx1 * r0[sx1];
-      const uint32_t h1 = wx0 * r1[sx] + wx1 * r1[sx1];
+    const int x = min(x4 + i, L.w - 1);
+    const int cx = xofs[x] - sx0;
+    wofs[i] = cx >> 2;
+    bsh[i] = cx & 3;
+    wx1[i] = xw[x];
+  }
+  for (int y = Y0 + (tid >> 4); y < min(Y0 + RTH, L.h); y += 16) {
+    const uint32_t wy1 = yw[y], wy0 = 256u - wy1;
+    const int rbase = (yofs[y] - sy0) * (RLW / 4);
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int w0i = rbase + wofs[i];
+      const uint32_t a = __builtin_amdgcn_alignbyte(T[w0i + 1], T[w0i], bsh[i]);                       // row sy:   p[cx], p[cx+1]
+      const uint32_t c = __builtin_amdgcn_alignbyte(T[w0i + RLW / 4 + 1], T[w0i + RLW / 4], bsh[i]);   // row sy+1
+      const uint32_t wx0 = 256u - wx1[i];
+      const uint32_t h0 = wx0 * (a & 0xFFu) + wx1[i] * ((a >> 8) & 0xFFu);
+      const uint32_t h1 = wx0 * (c & 0xFFu) + wx1[i] * ((c >> 8) & 0xFFu);
       uint32_t v = (h0 * wy0 + h1 * wy1 + 32768u) >> 16;
       v = v > 255u ? 255u : v;
       packed |= v << (8 * i);
     }
+    *reinterpret_cast<uint32_t*>(d + (long long)y * L.pitch + x4) = packed;  // pitch % 16 == 0, pad bytes are never read as pixels
   }
-  *reinterpret_cast<uint32_t*>(d + (long long)y * L.pitch + x4) = packed;  // pitch % 16 == 0, pad bytes are never read as pixels
 }
 
 // ------------------------------------------------------------------ K3+K4: FAST-9/16 score, NMS, border, candidate list
-__device__ __forceinline__ bool run9(uint32_t m) {
-  m |= m << 16;
-  uint32_t r = m & (m >> 1);
-  r &= r >> 2;
-  r &= r >> 4;
-  r &= m >> 8;
-  return (r & 0xFFFFu) != 0;
+// Three dense phases per 64x32 tile instead of one divergent one:
+//  1. prefilter, 4 px per lane in one dword (SWAR): any arc of 9 contains two ADJACENT cardinal ring pixels
+//     ((0,3),(3,0),(0,-3),(-3,0)), so "some adjacent cardinal pair is all-brighter or all-darker" is necessary.
+//     Per-byte threshold tests use v_lerp_u8 as a carry-free byte adder: lerp(p, ~c) = (p + 255 - c) >> 1, and a
+//     second lerp against a constant puts the compare result in bit 7 of each byte.  Conservative (superset).
+//  2. survivors (compacted in LDS) get the exact cornerScore<16>: max over the 16 arcs of min9(d) / min9(-d)
+//     through min3/max3 networks; score > threshold <=> FAST_t's 9-contiguous test.
+//  3. strict 3x3 NMS + runByImageBorder on the corner list only.
+constexpr int HX = 8, HY = 4;                      // pixel-tile halo: x aligned to the 4-px groups
+constexpr int PW2 = TW + 2 * HX, PH2 = TH + 2 * HY;  // 80 x 40
+constexpr int GPR = 18;                            // 4-px groups per score row: tile x = 4g-4 .. 4g-1
+constexpr uint32_t kLerpBright = 0x01010101u * (128 - kFastT / 2);  // L + K >= 256  <=>  L >= 128 + t/2
+constexpr uint32_t kLerpNotDark = 0x01010101u * (255 - (254 - kFastT) / 2);
+static_assert(kFastT % 2 == 0, "prefilter constants assume an even FAST threshold (cv::ORB default 20)");
+
+__device__ __forceinline__ uint32_t mbcnt64(unsigned long long m) {   // set bits of m below this lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// FAST_t<16> corner test + cornerScore<16> on an LDS pixel tile (pitch PW); 0 = not a corner.
-__device__ __forceinline__ int fast_score_lds(const uint8_t* p) {
-  constexpr int off[16] = {3 * PW + 0,  3 * PW + 1,  2 * PW + 2,  1 * PW + 3,  0 * PW + 3, -1 * PW + 3,
-                           -2 * PW + 2, -3 * PW + 1, -3 * PW + 0, -3 * PW - 1, -2 * PW - 2, -1 * PW - 3,
-                           0 * PW - 3,  1 * PW - 3,  2 * PW - 2,  3 * PW - 1};
+__device__ __forceinline__ int fast_score_exact(const uint8_t* p) {
+  constexpr int off[16] = {3 * PW2 + 0,  3 * PW2 + 1,  2 * PW2 + 2,  1 * PW2 + 3,  0 * PW2 + 3, -1 * PW2 + 3,
+                           -2 * PW2 + 2, -3 * PW2 + 1, -3 * PW2 + 0, -3 * PW2 - 1, -2 * PW2 - 2, -1 * PW2 - 3,
+                           0 * PW2 - 3,  1 * PW2 - 3,  2 * PW2 - 2,  3 * PW2 - 1};
   const int v = p[0];
   int d[16];
-  uint32_t dark = 0, bright = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) d[k] = v - (int)p[off[k]];
+  int m3[16], M3[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    d[k] = v - (int)p[off[k]];
-    dark |= (uint32_t)(d[k] > kFastT) << k;
-    bright |= (uint32_t)(d[k] < -kFastT) << k;
-  }
-  if (!(run9(dark) || run9(bright))) return 0;
-  // max over the 16 arcs of min(d) (darker) and of min(-d) (brighter): sliding window of 9
-  int mn[16], mx[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    mn[k] = min(d[k], d[(k + 1) & 15]);
-    mx[k] = max(d[k], d[(k + 1) & 15]);
-  }
-  int mn4[16], mx4[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    mn4[k] = min(mn[k], mn[(k + 2) & 15]);
-    mx4[k] = max(mx[k], mx[(k + 2) & 15]);
+    m3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+    M3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
   }
   int A = -1000, B = 1000;
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    const int m9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
-    const int M9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
-    A = max(A, m9);
-    B = min(B, M9);
+    A = max(A, min(min(m3[k], m3[(k + 3) & 15]), m3[(k + 6) & 15]));   // min over the arc k .. k+8
+    B = min(B, max(max(M3[k], M3[(k + 3) & 15]), M3[(k + 6) & 15]));
   }
-  return max(A, -B) - 1;
+  const int m = max(A, -B);
+  return m > kFastT ? m - 1 : 0;   // cornerScore<16> = max(t, A, B') - 1 for corners, 0 otherwise
 }
 
 __global__ __launch_bounds__(256) void k_fast(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
                                               uint32_t* cand_cnt, uint2* cand) {
-  __shared__ __attribute__((aligned(16))) uint8_t px[PW * PH];
-  __shared__ uint8_t sc[SP * SH];
+  __shared__ __attribute__((aligned(16))) uint8_t px[PW2 * PH2];
+  __shared__ __attribute__((aligned(16))) uint8_t sc[SP * SH];
+  __shared__ uint16_t list1[SW * SH + 8];
+  __shared__ uint16_t list2[SW * SH + 8];
   __shared__ uint2 llist[kTileCandCap];
-  __shared__ uint32_t lcount, gbase;
+  __shared__ uint32_t n1, n2, lcount, gbase;
 
   const int fi = blockIdx.y;
   const int slot = src.slot0 + fi;
@@ -149,41 +174,118 @@ __global__ __launch_bounds__(256) void k_fast(OrbGeometry g, FrameSrc src, const
   int pitch;
   const uint8_t* img = level_ptr(g, src, pyr, fi, l, &pitch);
   const int tid = threadIdx.x;
-  if (tid == 0) lcount = 0;
+  if (tid == 0) { n1 = 0; n2 = 0; lcount = 0; }
 
-  // stage the pixel tile (halo 4) through aligned dword loads
-  for (int i = tid; i < (PW / 4) * PH; i += 256) {
-    const int r = i / (PW / 4), c = i % (PW / 4);
-    const int gx = x0 - 4 + 4 * c, gy = y0 - 4 + r;
+  // stage the pixel tile through aligned dword loads; zero the score tile
+  for (int i = tid; i < (PW2 / 4) * PH2; i += 256) {
+    const int r = i / (PW2 / 4), c = i % (PW2 / 4);
+    const int gx = x0 - HX + 4 * c, gy = y0 - HY + r;
     uint32_t v = 0;
     if (gx >= 0 && gx + 4 <= pitch && gy >= 0 && gy < L.h)
       v = *reinterpret_cast<const uint32_t*>(img + (long long)gy * pitch + gx);
-    *reinterpret_cast<uint32_t*>(&px[r * PW + 4 * c]) = v;
+    reinterpret_cast<uint32_t*>(px)[i] = v;
+  }
+  for (int i = tid; i < SP * SH / 4; i += 256) reinterpret_cast<uint32_t*>(sc)[i] = 0;
+  __syncthreads();
+
+  // phase 1: cardinal prefilter on 4 px per lane
+  const uint32_t* T = reinterpret_cast<const uint32_t*>(px);
+  const int lane = tid & 63;
+  const int txlo = max(-1, 3 - x0), txhi = min(TW, L.w - 4 - x0);   // scored tile-x range
+  for (int i0 = 0; i0 < GPR * SH; i0 += 256) {
+    const int i = i0 + tid;
+    const int ic = i < GPR * SH ? i : GPR * SH - 1;   // idle lanes recompute the last task, masked below
+    const int sr = ic / GPR, gq = ic % GPR;        // score row, 4-px group
+    const int ty = sr - 1, tx0 = 4 * gq - 4;
+    const int b = ((ty + HY) * PW2 + tx0 + HX) >> 2;
+    const uint32_t C = T[b], Lf = T[b - 1], Rt = T[b + 1];
+    const uint32_t U = T[b - 3 * (PW2 / 4)], D = T[b + 3 * (PW2 / 4)];
+    const uint32_t W3 = __builtin_amdgcn_alignbyte(C, Lf, 1);   // pixels x-3 .. x
+    const uint32_t E3 = __builtin_amdgcn_alignbyte(Rt, C, 3);   // pixels x+3 .. x+6
+    const uint32_t nC = ~C;
+    const uint32_t l0 = __builtin_amdgcn_lerp(D, nC, 0), l4 = __builtin_amdgcn_lerp(E3, nC, 0);
+    const uint32_t l8 = __builtin_amdgcn_lerp(U, nC, 0), l12 = __builtin_amdgcn_lerp(W3, nC, 0);
+    const uint32_t b0 = __builtin_amdgcn_lerp(l0, kLerpBright, 0), b4 = __builtin_amdgcn_lerp(l4, kLerpBright, 0);
+    const uint32_t b8 = __builtin_amdgcn_lerp(l8, kLerpBright, 0), b12 = __builtin_amdgcn_lerp(l12, kLerpBright, 0);
+    const uint32_t n0 = __builtin_amdgcn_lerp(l0, kLerpNotDark, 0), n4 = __builtin_amdgcn_lerp(l4, kLerpNotDark, 0);
+    const uint32_t n8 = __builtin_amdgcn_lerp(l8, kLerpNotDark, 0), n12 = __builtin_amdgcn_lerp(l12, kLerpNotDark, 0);
+    uint32_t cnd = (((b0 | b8) & (b4 | b12)) | ~((n0 & n8) | (n4 & n12))) & 0x80808080u;
+    // FAST_t scores only rows/cols 3 .. dim-4; the score tile spans tile +- 1
+    {
+      const int gy = y0 + ty;
+      int first = txlo - tx0, last = txhi - tx0;         // valid bytes: first .. last
+      first = first < 0 ? 0 : first;
+      last = last > 3 ? 3 : last;
+      uint32_t vm = 0;
+      if (i < GPR * SH && gy >= 3 && gy < L.h - 3 && first <= last)
+        vm = (0x80808080u << (8 * first)) & (0x80808080u >> (8 * (3 - last)));
+      cnd &= vm;
+    }
+    // ordered, wave-aggregated append (lane order = x order, so phase 2's LDS reads stay bank-friendly)
+    const unsigned long long q0 = __ballot(cnd & 0x80u), q1 = __ballot(cnd & 0x8000u);
+    const unsigned long long q2 = __ballot(cnd & 0x800000u), q3 = __ballot(cnd & 0x80000000u);
+    const uint32_t total = __popcll(q0) + __popcll(q1) + __popcll(q2) + __popcll(q3);
+    if (total) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&n1, total);
+      base = __shfl(base, 0);
+      uint32_t k = base + mbcnt64(q0) + mbcnt64(q1) + mbcnt64(q2) + mbcnt64(q3);
+      const uint32_t e0 = (uint32_t)(sr * SP + tx0 + 1);
+      if (cnd & 0x80u) list1[k++] = (uint16_t)e0;
+      if (cnd & 0x8000u) list1[k++] = (uint16_t)(e0 + 1);
+      if (cnd & 0x800000u) list1[k++] = (uint16_t)(e0 + 2);
+      if (cnd & 0x80000000u) list1[k++] = (uint16_t)(e0 + 3);
+    }
   }
   __syncthreads();
 
-  // scores for the tile + 1 halo; FAST_t scores only rows/cols 3 .. dim-4
-  for (int i = tid; i < SW * SH; i += 256) {
-    const int sy = i / SW, sx = i % SW;
-    const int gx = x0 - 1 + sx, gy = y0 - 1 + sy;
-    int s = 0;
-    if (gx >= 3 && gx < L.w - 3 && gy >= 3 && gy < L.h - 3) s = fast_score_lds(&px[(sy + 3) * PW + sx + 3]);
-    sc[sy * SP + sx] = (uint8_t)s;
+  // phase 2: exact score on the survivors
+  const uint32_t m1 = n1;
+  for (uint32_t i0 = 0; i0 < m1; i0 += 256) {
+    const uint32_t i = i0 + tid;
+    int e = 0, s = 0;
+    if (i < m1) {
+      e = list1[i];
+      const int sy = e / SP, sx = e - sy * SP;
+      s = fast_score_exact(&px[(sy - 1 + HY) * PW2 + (sx - 1 + HX)]);
+      if (s) sc[e] = (uint8_t)s;
+    }
+    const unsigned long long q = __ballot(s != 0);
+    if (q) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&n2, (uint32_t)__popcll(q));
+      base = __shfl(base, 0);
+      if (s) list2[base + mbcnt64(q)] = (uint16_t)e;
+    }
   }
   __syncthreads();
 
-  // strict 3x3 NMS + runByImageBorder(31)
-  for (int i = tid; i < TW * TH; i += 256) {
-    const int oy = i / TW, ox = i % TW;
-    const uint8_t* q = &sc[(oy + 1) * SP + ox + 1];
-    const int s = q[0];
-    if (s == 0) continue;
-    const int gx = x0 + ox, gy = y0 + oy;
-    if (gx < kEdge || gx >= L.w - kEdge || gy < kEdge || gy >= L.h - kEdge) continue;
-    if (s > q[-1] && s > q[1] && s > q[-SP - 1] && s > q[-SP] && s > q[-SP + 1] && s > q[SP - 1] &&
-        s > q[SP] && s > q[SP + 1]) {
-      const uint32_t k = atomicAdd(&lcount, 1u);
-      llist[k] = make_uint2(((uint32_t)gy << 16) | (uint32_t)gx, (uint32_t)s);
+  // phase 3: strict 3x3 NMS + runByImageBorder(31) on the corners
+  const uint32_t m2 = n2;
+  for (uint32_t i0 = 0; i0 < m2; i0 += 256) {
+    const uint32_t i = i0 + tid;
+    bool keep = false;
+    int gx = 0, gy = 0, s = 0;
+    if (i < m2) {
+      const int e = list2[i];
+      const int sy = e / SP, sx = e - sy * SP;
+      gx = x0 + sx - 1;
+      gy = y0 + sy - 1;
+      // halo entries only serve as neighbours
+      if (sx >= 1 && sx <= TW && sy >= 1 && sy <= TH && gx >= kEdge && gx < L.w - kEdge && gy >= kEdge &&
+          gy < L.h - kEdge) {
+        const uint8_t* q = &sc[e];
+        s = q[0];
+        keep = s > q[-1] && s > q[1] && s > q[-SP - 1] && s > q[-SP] && s > q[-SP + 1] && s > q[SP - 1] &&
+               s > q[SP] && s > q[SP + 1];
+      }
+    }
+    const unsigned long long q = __ballot(keep);
+    if (q) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&lcount, (uint32_t)__popcll(q));
+      base = __shfl(base, 0);
+      if (keep) llist[base + mbcnt64(q)] = make_uint2(((uint32_t)gy << 16) | (uint32_t)gx, (uint32_t)s);
     }
   }
   __syncthreads();
@@ -259,14 +361,28 @@ __global__ __launch_bounds__(256) void k_thr_harris(OrbGeometry g, FrameSrc src,
   const uint32_t thr = thr_s;
   int pitch;
   const uint8_t* img = level_ptr(g, src, pyr, fi, l, &pitch);
-  for (uint32_t i = tid; i < n; i += 256) {
-    const uint2 c = in[i];
-    if (c.y >= thr) {
-      const int x = c.x & 0xFFFF, y = c.x >> 16;
-      const float r = harris_at(img, pitch, x, y);
-      const uint32_t k = atomicAdd(&lcount, 1u);
-      if (k < (uint32_t)kS1Cap) out[k] = make_uint4(c.x, __float_as_uint(r), c.y, 0u);
+  // pass 1: compact the kept candidates (score >= thr) into the stage-1 list, response pending
+  for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+    const uint32_t i = i0 + tid;
+    uint2 c = make_uint2(0u, 0u);
+    bool keep = false;
+    if (i < n) { c = in[i]; keep = c.y >= thr; }
+    const unsigned long long q = __ballot(keep);
+    if (q) {
+      uint32_t base = 0;
+      if ((tid & 63) == 0) base = atomicAdd(&lcount, (uint32_t)__popcll(q));
+      base = __shfl(base, 0);
+      const uint32_t k = base + mbcnt64(q);
+      if (keep && k < (uint32_t)kS1Cap) out[k] = make_uint4(c.x, 0u, c.y, 0u);
     }
+  }
+  __syncthreads();
+  // pass 2: Harris response on dense lanes
+  const uint32_t kept = min(lcount, (uint32_t)kS1Cap);
+  for (uint32_t i = tid; i < kept; i += 256) {
+    const uint32_t key = out[i].x;
+    const float r = harris_at(img, pitch, key & 0xFFFF, key >> 16);
+    out[i].y = __float_as_uint(r);
   }
   __syncthreads();
   if (tid == 0) {
@@ -730,10 +846,11 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
   if ((e = hipMemsetAsync(d_cand_cnt_ + (size_t)src.slot0 * kOrbLevels, 0, (size_t)n * kOrbLevels * 4, st))) return e;
   if ((e = hipMemsetAsync(d_status_ + src.slot0, 0, (size_t)n * 4, st))) return e;
   if (ev_ok_) hipEventRecord(ev_[0], st);
+  static const int dbg_resize = getenv("MSF_DEBUG_RESIZE") ? atoi(getenv("MSF_DEBUG_RESIZE")) : 0;
   for (int l = 1; l < g.nlevels; l++) {
     const OrbLevelInfo& L = g.lv[l];
-    dim3 grid((L.w + 255) / 256, (L.h + 3) / 4, n);
-    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, g, src, d_pyr_, d_tab_, l);
+    dim3 grid((L.w + RTW - 1) / RTW, (L.h + RTH - 1) / RTH, n);
+    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, g, src, d_pyr_, d_tab_, l, dbg_resize);
   }
   if (ev_ok_) hipEventRecord(ev_[1], st);
   hipLaunchKernelGGL(k_fast, dim3(g.total_tiles, n), dim3(256), 0, st, g, src, d_pyr_, d_cand_cnt_, d_cand_);
