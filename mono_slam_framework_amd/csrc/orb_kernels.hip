@@ -118,9 +118,11 @@ __global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uin
 //  2. survivors (compacted in LDS) get the exact cornerScore<16>: max over the 16 arcs of min9(d) / min9(-d)
 //     through min3/max3 networks; score > threshold <=> FAST_t's 9-contiguous test.
 //  3. strict 3x3 NMS + runByImageBorder on the corner list only.
-constexpr int HX = 8, HY = 4;                      // pixel-tile halo: x aligned to the 4-px groups
-constexpr int PW2 = TW + 2 * HX, PH2 = TH + 2 * HY;  // 80 x 40
+constexpr int HX = 16, HY = 4;                     // pixel-tile halo: rows start 16-byte aligned (x0 - 16)
+constexpr int PW2 = TW + 2 * HX, PH2 = TH + 2 * HY;  // 96 x 40
+constexpr int SCO = 4;                              // byte offset of the score tile inside its LDS array
 constexpr int GPR = 18;                            // 4-px groups per score row: tile x = 4g-4 .. 4g-1
+constexpr int kList1Cap = 2 * SW * SH;             // brighter-type survivors from the front, darker from the back
 constexpr uint32_t kLerpBright = 0x01010101u * (128 - kFastT / 2);  // L + K >= 256  <=>  L >= 128 + t/2
 constexpr uint32_t kLerpNotDark = 0x01010101u * (255 - (254 - kFastT) / 2);
 static_assert(kFastT % 2 == 0, "prefilter constants assume an even FAST threshold (cv::ORB default 20)");
@@ -129,38 +131,58 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m) {   // set bit
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-__device__ __forceinline__ int fast_score_exact(const uint8_t* p) {
+// cornerScore<16> restricted to one polarity (a pixel cannot have both a brighter and a darker arc of 9):
+// max over the 16 arcs of the minimum of e over the arc, e = p - v (brighter) or v - p (darker).
+template <bool BRIGHT>
+__device__ __forceinline__ int fast_score_pol(const uint8_t* p) {
   constexpr int off[16] = {3 * PW2 + 0,  3 * PW2 + 1,  2 * PW2 + 2,  1 * PW2 + 3,  0 * PW2 + 3, -1 * PW2 + 3,
                            -2 * PW2 + 2, -3 * PW2 + 1, -3 * PW2 + 0, -3 * PW2 - 1, -2 * PW2 - 2, -1 * PW2 - 3,
                            0 * PW2 - 3,  1 * PW2 - 3,  2 * PW2 - 2,  3 * PW2 - 1};
   const int v = p[0];
-  int d[16];
+  int e[16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) d[k] = v - (int)p[off[k]];
-  int m3[16], M3[16];
+  for (int k = 0; k < 16; k++) e[k] = BRIGHT ? (int)p[off[k]] - v : v - (int)p[off[k]];
+  int m3[16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    m3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-    M3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-  }
-  int A = -1000, B = 1000;
+  for (int k = 0; k < 16; k++) m3[k] = min(min(e[k], e[(k + 1) & 15]), e[(k + 2) & 15]);
+  int A = -1000;
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    A = max(A, min(min(m3[k], m3[(k + 3) & 15]), m3[(k + 6) & 15]));   // min over the arc k .. k+8
-    B = min(B, max(max(M3[k], M3[(k + 3) & 15]), M3[(k + 6) & 15]));
-  }
-  const int m = max(A, -B);
-  return m > kFastT ? m - 1 : 0;   // cornerScore<16> = max(t, A, B') - 1 for corners, 0 otherwise
+  for (int k = 0; k < 16; k++) A = max(A, min(min(m3[k], m3[(k + 3) & 15]), m3[(k + 6) & 15]));   // arc k .. k+8
+  return A > kFastT ? A - 1 : 0;   // = max(t, A, B) - 1 for corners, 0 otherwise
 }
 
-__global__ __launch_bounds__(256) void k_fast(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
-                                              uint32_t* cand_cnt, uint2* cand) {
+// inclusive prefix sum over the 64 lanes of a wave (DPP row shifts + row broadcasts, the gfx9 scan idiom)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
+// ordered, wave-aggregated reservation on a packed LDS counter (low 16 bits / high 16 bits = two lists):
+// `mine` holds this lane's two counts packed the same way; returns the packed first slots of this lane.
+__device__ __forceinline__ uint32_t reserve_packed(uint32_t mine, uint32_t* counter, int lane) {
+  const uint32_t incl = wave_incl_scan(mine);
+  const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+  uint32_t base = 0;
+  if (total) {
+    if (lane == 0) base = atomicAdd(counter, total);
+    base = __builtin_amdgcn_readfirstlane(base);
+  }
+  return base + incl - mine;
+}
+
+constexpr int kFastThreads = 256;   // 320 (two full prefilter passes) measured slower: 5 waves sit unevenly on 4 SIMDs
+__global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
+                                                       uint32_t* cand_cnt, uint2* cand, int dbg) {
   __shared__ __attribute__((aligned(16))) uint8_t px[PW2 * PH2];
-  __shared__ __attribute__((aligned(16))) uint8_t sc[SP * SH];
-  __shared__ uint16_t list1[SW * SH + 8];
-  __shared__ uint16_t list2[SW * SH + 8];
+  __shared__ __attribute__((aligned(16))) uint8_t sc[SP * SH + 2 * SCO];   // one dword of slack either side
+  __shared__ uint16_t list1[kList1Cap];
   __shared__ uint2 llist[kTileCandCap];
-  __shared__ uint32_t n1, n2, lcount, gbase;
+  __shared__ uint32_t nbd, lcount, gbase;   // nbd: brighter count (low 16) | darker count (high 16)
 
   const int fi = blockIdx.y;
   const int slot = src.slot0 + fi;
@@ -173,26 +195,27 @@ __global__ __launch_bounds__(256) void k_fast(OrbGeometry g, FrameSrc src, const
   const int x0 = (t % L.tiles_x) * TW, y0 = (t / L.tiles_x) * TH;
   int pitch;
   const uint8_t* img = level_ptr(g, src, pyr, fi, l, &pitch);
-  const int tid = threadIdx.x;
-  if (tid == 0) { n1 = 0; n2 = 0; lcount = 0; }
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) { nbd = 0; lcount = 0; }
 
-  // stage the pixel tile through aligned dword loads; zero the score tile
-  for (int i = tid; i < (PW2 / 4) * PH2; i += 256) {
-    const int r = i / (PW2 / 4), c = i % (PW2 / 4);
-    const int gx = x0 - HX + 4 * c, gy = y0 - HY + r;
-    uint32_t v = 0;
-    if (gx >= 0 && gx + 4 <= pitch && gy >= 0 && gy < L.h)
-      v = *reinterpret_cast<const uint32_t*>(img + (long long)gy * pitch + gx);
-    reinterpret_cast<uint32_t*>(px)[i] = v;
+  // stage the pixel tile through aligned 16-byte loads (rows are 16-byte aligned: pitch % 16 == 0, x0 % 64 == 0);
+  // zero the score tile
+  for (int i = tid; i < (PW2 / 16) * PH2; i += kFastThreads) {
+    const int r = i / (PW2 / 16), c = i % (PW2 / 16);
+    const int gx = x0 - HX + 16 * c, gy = y0 - HY + r;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (gx >= 0 && gx + 16 <= pitch && gy >= 0 && gy < L.h)
+      v = *reinterpret_cast<const uint4*>(img + (long long)gy * pitch + gx);
+    reinterpret_cast<uint4*>(px)[i] = v;
   }
-  for (int i = tid; i < SP * SH / 4; i += 256) reinterpret_cast<uint32_t*>(sc)[i] = 0;
+  for (int i = tid; i < (SP * SH + 2 * SCO) / 4; i += kFastThreads) reinterpret_cast<uint32_t*>(sc)[i] = 0;
   __syncthreads();
 
+  if (dbg & 1) return;
   // phase 1: cardinal prefilter on 4 px per lane
   const uint32_t* T = reinterpret_cast<const uint32_t*>(px);
-  const int lane = tid & 63;
   const int txlo = max(-1, 3 - x0), txhi = min(TW, L.w - 4 - x0);   // scored tile-x range
-  for (int i0 = 0; i0 < GPR * SH; i0 += 256) {
+  for (int i0 = 0; i0 < GPR * SH; i0 += kFastThreads) {
     const int i = i0 + tid;
     const int ic = i < GPR * SH ? i : GPR * SH - 1;   // idle lanes recompute the last task, masked below
     const int sr = ic / GPR, gq = ic % GPR;        // score row, 4-px group
@@ -209,93 +232,100 @@ __global__ __launch_bounds__(256) void k_fast(OrbGeometry g, FrameSrc src, const
     const uint32_t b8 = __builtin_amdgcn_lerp(l8, kLerpBright, 0), b12 = __builtin_amdgcn_lerp(l12, kLerpBright, 0);
     const uint32_t n0 = __builtin_amdgcn_lerp(l0, kLerpNotDark, 0), n4 = __builtin_amdgcn_lerp(l4, kLerpNotDark, 0);
     const uint32_t n8 = __builtin_amdgcn_lerp(l8, kLerpNotDark, 0), n12 = __builtin_amdgcn_lerp(l12, kLerpNotDark, 0);
-    uint32_t cnd = (((b0 | b8) & (b4 | b12)) | ~((n0 & n8) | (n4 & n12))) & 0x80808080u;
     // FAST_t scores only rows/cols 3 .. dim-4; the score tile spans tile +- 1
+    uint32_t vm = 0;
     {
       const int gy = y0 + ty;
       int first = txlo - tx0, last = txhi - tx0;         // valid bytes: first .. last
       first = first < 0 ? 0 : first;
       last = last > 3 ? 3 : last;
-      uint32_t vm = 0;
       if (i < GPR * SH && gy >= 3 && gy < L.h - 3 && first <= last)
         vm = (0x80808080u << (8 * first)) & (0x80808080u >> (8 * (3 - last)));
-      cnd &= vm;
     }
-    // ordered, wave-aggregated append (lane order = x order, so phase 2's LDS reads stay bank-friendly)
-    const unsigned long long q0 = __ballot(cnd & 0x80u), q1 = __ballot(cnd & 0x8000u);
-    const unsigned long long q2 = __ballot(cnd & 0x800000u), q3 = __ballot(cnd & 0x80000000u);
-    const uint32_t total = __popcll(q0) + __popcll(q1) + __popcll(q2) + __popcll(q3);
-    if (total) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&n1, total);
-      base = __shfl(base, 0);
-      uint32_t k = base + mbcnt64(q0) + mbcnt64(q1) + mbcnt64(q2) + mbcnt64(q3);
-      const uint32_t e0 = (uint32_t)(sr * SP + tx0 + 1);
-      if (cnd & 0x80u) list1[k++] = (uint16_t)e0;
-      if (cnd & 0x8000u) list1[k++] = (uint16_t)(e0 + 1);
-      if (cnd & 0x800000u) list1[k++] = (uint16_t)(e0 + 2);
-      if (cnd & 0x80000000u) list1[k++] = (uint16_t)(e0 + 3);
-    }
+    const uint32_t cb = ((b0 | b8) & (b4 | b12)) & vm;
+    const uint32_t cd = ~((n0 & n8) | (n4 & n12)) & vm;
+    const uint32_t e0 = (uint32_t)(sr * SP + tx0 + 1);
+    // lane order = x order, so phase 2's LDS reads stay bank-friendly
+    const uint32_t slots = reserve_packed(__popc(cb) | (__popc(cd) << 16), &nbd, lane);
+    uint32_t k = slots & 0xFFFFu;
+    if (cb & 0x80u) list1[k++] = (uint16_t)e0;
+    if (cb & 0x8000u) list1[k++] = (uint16_t)(e0 + 1);
+    if (cb & 0x800000u) list1[k++] = (uint16_t)(e0 + 2);
+    if (cb & 0x80000000u) list1[k++] = (uint16_t)(e0 + 3);
+    k = kList1Cap - 1 - (slots >> 16);
+    if (cd & 0x80u) list1[k--] = (uint16_t)e0;
+    if (cd & 0x8000u) list1[k--] = (uint16_t)(e0 + 1);
+    if (cd & 0x800000u) list1[k--] = (uint16_t)(e0 + 2);
+    if (cd & 0x80000000u) list1[k--] = (uint16_t)(e0 + 3);
   }
   __syncthreads();
 
-  // phase 2: exact score on the survivors
-  const uint32_t m1 = n1;
-  for (uint32_t i0 = 0; i0 < m1; i0 += 256) {
-    const uint32_t i = i0 + tid;
-    int e = 0, s = 0;
-    if (i < m1) {
-      e = list1[i];
-      const int sy = e / SP, sx = e - sy * SP;
-      s = fast_score_exact(&px[(sy - 1 + HY) * PW2 + (sx - 1 + HX)]);
-      if (s) sc[e] = (uint8_t)s;
-    }
-    const unsigned long long q = __ballot(s != 0);
-    if (q) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&n2, (uint32_t)__popcll(q));
-      base = __shfl(base, 0);
-      if (s) list2[base + mbcnt64(q)] = (uint16_t)e;
-    }
+  if (dbg & 2) return;
+  // phase 2: exact score of the survivors, one polarity per loop, written into the (zeroed) score tile
+  const uint32_t mb = nbd & 0xFFFFu, md = nbd >> 16;
+  for (uint32_t i = tid; i < mb; i += kFastThreads) {
+    const int e = list1[i];
+    const int sy = e / SP, sx = e - sy * SP;
+    const int s = fast_score_pol<true>(&px[(sy - 1 + HY) * PW2 + (sx - 1 + HX)]);
+    if (s) sc[SCO + e] = (uint8_t)s;
+  }
+  for (uint32_t i = tid; i < md; i += kFastThreads) {
+    const int e = list1[kList1Cap - 1 - i];
+    const int sy = e / SP, sx = e - sy * SP;
+    const int s = fast_score_pol<false>(&px[(sy - 1 + HY) * PW2 + (sx - 1 + HX)]);
+    if (s) sc[SCO + e] = (uint8_t)s;
   }
   __syncthreads();
 
-  // phase 3: strict 3x3 NMS + runByImageBorder(31) on the corners
-  const uint32_t m2 = n2;
-  for (uint32_t i0 = 0; i0 < m2; i0 += 256) {
-    const uint32_t i = i0 + tid;
-    bool keep = false;
-    int gx = 0, gy = 0, s = 0;
-    if (i < m2) {
-      const int e = list2[i];
-      const int sy = e / SP, sx = e - sy * SP;
-      gx = x0 + sx - 1;
-      gy = y0 + sy - 1;
-      // halo entries only serve as neighbours
-      if (sx >= 1 && sx <= TW && sy >= 1 && sy <= TH && gx >= kEdge && gx < L.w - kEdge && gy >= kEdge &&
-          gy < L.h - kEdge) {
-        const uint8_t* q = &sc[e];
-        s = q[0];
-        keep = s > q[-1] && s > q[1] && s > q[-SP - 1] && s > q[-SP] && s > q[-SP + 1] && s > q[SP - 1] &&
-               s > q[SP] && s > q[SP + 1];
+  if (dbg & 4) return;
+  // phase 3: strict 3x3 NMS + runByImageBorder(31), dense on 4 scores per lane: "c > n" per byte is bit 7 of
+  // lerp(c, ~n) = (c + 255 - n) >> 1; non-corners hold 0 and can never be strictly greater.
+  {
+    const uint32_t* S = reinterpret_cast<const uint32_t*>(sc) + SCO / 4;
+    // output columns sx = 1 .. TW that also pass the 31-px border: [sxlo, sxhi]
+    const int sxlo = max(1, kEdge - x0 + 1), sxhi = min(TW, L.w - kEdge - x0);
+    for (int i0 = 0; i0 < (SP / 4) * TH; i0 += kFastThreads) {
+      const int i = i0 + tid;
+      const int ic = i < (SP / 4) * TH ? i : 0;
+      const int r = ic / (SP / 4) + 1, j = ic % (SP / 4);     // score row 1 .. TH, dword column
+      const int w = r * (SP / 4) + j;
+      const uint32_t C = S[w];
+      uint32_t keep = 0;
+      const int gy = y0 + r - 1;
+      if (i < (SP / 4) * TH && C != 0 && gy >= kEdge && gy < L.h - kEdge) {
+        const uint32_t Cl = S[w - 1], Cr = S[w + 1];
+        const uint32_t U = S[w - SP / 4], Ul = S[w - SP / 4 - 1], Ur = S[w - SP / 4 + 1];
+        const uint32_t D = S[w + SP / 4], Dl = S[w + SP / 4 - 1], Dr = S[w + SP / 4 + 1];
+        keep = __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(C, Cl, 3), 0);
+        keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(Cr, C, 1), 0);
+        keep &= __builtin_amdgcn_lerp(C, ~U, 0);
+        keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(U, Ul, 3), 0);
+        keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(Ur, U, 1), 0);
+        keep &= __builtin_amdgcn_lerp(C, ~D, 0);
+        keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(D, Dl, 3), 0);
+        keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(Dr, D, 1), 0);
+        int first = sxlo - 4 * j, last = sxhi - 4 * j;
+        first = first < 0 ? 0 : first;
+        last = last > 3 ? 3 : last;
+        keep &= first <= last ? (0x80808080u << (8 * first)) & (0x80808080u >> (8 * (3 - last))) : 0u;
       }
-    }
-    const unsigned long long q = __ballot(keep);
-    if (q) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&lcount, (uint32_t)__popcll(q));
-      base = __shfl(base, 0);
-      if (keep) llist[base + mbcnt64(q)] = make_uint2(((uint32_t)gy << 16) | (uint32_t)gx, (uint32_t)s);
+      const uint32_t mine = __popc(keep);
+      uint32_t k = reserve_packed(mine, &lcount, lane);
+      const uint32_t key = ((uint32_t)gy << 16) | (uint32_t)(x0 + 4 * j - 1);
+      if (keep & 0x80u) llist[k++] = make_uint2(key, C & 0xFFu);
+      if (keep & 0x8000u) llist[k++] = make_uint2(key + 1, (C >> 8) & 0xFFu);
+      if (keep & 0x800000u) llist[k++] = make_uint2(key + 2, (C >> 16) & 0xFFu);
+      if (keep & 0x80000000u) llist[k++] = make_uint2(key + 3, C >> 24);
     }
   }
   __syncthreads();
   const uint32_t n = lcount;
-  if (n == 0) return;
+  if (n == 0 || (dbg & 8)) return;
   if (tid == 0) gbase = atomicAdd(&cand_cnt[slot * kOrbLevels + l], n);
   __syncthreads();
   const uint32_t base = gbase;
   uint2* out = cand + (long long)slot * g.cand_total + L.cand_off;
-  for (uint32_t i = tid; i < n; i += 256)
+  for (uint32_t i = tid; i < n; i += kFastThreads)
     if (base + i < (uint32_t)L.cand_cap) out[base + i] = llist[i];
 }
 
@@ -518,37 +548,43 @@ constexpr int HP = 40;
 __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
                                                   msf_keypoint* kp, const uint32_t* kp_cnt, uint8_t* desc,
                                                   int half_up) {
-  __shared__ uint8_t raw_s[4][PD * PP];
-  __shared__ uint16_t hb_s[4][PD * HP];
+  __shared__ __attribute__((aligned(16))) uint8_t raw_s[4][PD * PP + 16];
+  __shared__ __attribute__((aligned(16))) uint16_t hb_s[4][PD * HP];
   const int fi = blockIdx.y, slot = src.slot0 + fi;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t count = min(kp_cnt[slot], (uint32_t)kKpCap);
   uint8_t* raw = raw_s[wave];
   uint16_t* hb = hb_s[wave];
+  uint32_t* raw32 = reinterpret_cast<uint32_t*>(raw);
   for (uint32_t k0 = blockIdx.x * 4; k0 < count; k0 += gridDim.x * 4) {
     const uint32_t k = k0 + wave;
     const bool active = k < count;
     msf_keypoint* K = kp + (long long)slot * kKpCap + k;
-    int l = 0, cx = 0, cy = 0, pitch = 0;
+    int l = 0, cx = 0, cy = 0, pitch = 0, xo = 0;
     const uint8_t* img = nullptr;
     if (active) {
       l = K->octave; cx = K->lx; cy = K->ly;
       img = level_ptr(g, src, pyr, fi, l, &pitch);
-      // raw patch, radius 22 (keypoints sit >= 31 px inside the level, so this never leaves it)
-      for (int i = lane; i < PD * PD; i += 64) {
-        const int r = i / PD, c = i % PD;
-        raw[r * PP + c] = img[(long long)(cy - PR + r) * pitch + (cx - PR + c)];
+      // raw patch, radius 22, fetched as aligned dwords: columns ax .. ax+47 hold x = cx-22 .. cx+22 at byte
+      // offset xo (keypoints sit >= 31 px inside the level, so this never leaves the row)
+      const int ax = (cx - PR) & ~3;
+      xo = (cx - PR) - ax;
+      const uint8_t* base = img + (long long)(cy - PR) * pitch + ax;
+      for (int i = lane; i < PD * (PP / 4); i += 64) {
+        const int r = i / (PP / 4), c = i % (PP / 4);
+        raw32[i] = *reinterpret_cast<const uint32_t*>(base + (long long)r * pitch + 4 * c);
       }
     }
     __syncthreads();
     float angle = 0.f;
     if (active) {
-      // ICAngles (orb.cpp): lanes 0..30 take one row of the 31-px disc each
+      // ICAngles (orb.cpp): lanes 0..30 take one row of the 31-px disc each.  volatile: single-byte LDS reads
+      // (the compiler would otherwise fuse neighbours into misaligned wide reads, which the LDS replays)
       int m10 = 0, m01 = 0;
       if (lane < 31) {
         const int v = lane - 15;
         const int dmax = c_umax[v < 0 ? -v : v];
-        const uint8_t* row = raw + (PR + v) * PP + PR;
+        const volatile uint8_t* row = raw + (PR + v) * PP + xo + PR;
         int rs = 0;
         for (int u = -dmax; u <= dmax; u++) {
           const int p = row[u];
@@ -563,12 +599,25 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
         m01 += __shfl_xor(m01, o);
       }
       angle = fast_atan2_deg((float)m01, (float)m10);
-      // 7-tap row pass of GaussianBlur(7x7, sigma 2) in its 8u integer form (18 34 49 55 49 34 18)
-      for (int i = lane; i < PD * HB; i += 64) {
-        const int r = i / HB, c = i % HB;
-        const uint8_t* p = raw + r * PP + c;
-        const uint32_t s = 18u * (p[0] + p[6]) + 34u * (p[1] + p[5]) + 49u * (p[2] + p[4]) + 55u * p[3];
-        hb[r * HP + c] = (uint16_t)s;  // <= 255 * 257 = 65535
+      // 7-tap row pass of GaussianBlur(7x7, sigma 2) in its 8u integer form (18 34 49 55 49 34 18): 4 outputs per
+      // lane from three aligned dwords, taps applied with v_dot4_u32_u8 on byte windows cut by v_alignbyte
+      constexpr uint32_t kTapLo = 18u | (34u << 8) | (49u << 16) | (55u << 24);
+      constexpr uint32_t kTapHi = 49u | (34u << 8) | (18u << 16);
+      uint32_t* hb32 = reinterpret_cast<uint32_t*>(hb);
+      for (int i = lane; i < PD * 10; i += 64) {
+        const int r = i / 10, gq = i % 10;
+        const uint32_t* d = raw32 + r * (PP / 4) + gq;
+        const uint32_t d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];
+        const uint32_t e0 = __builtin_amdgcn_alignbyte(d1, d0, xo), e1 = __builtin_amdgcn_alignbyte(d2, d1, xo);
+        const uint32_t e2 = __builtin_amdgcn_alignbyte(d3, d2, xo);
+        uint32_t sres[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const uint32_t lo = __builtin_amdgcn_alignbyte(e1, e0, j), hi = __builtin_amdgcn_alignbyte(e2, e1, j);
+          sres[j] = __builtin_amdgcn_udot4(lo, kTapLo, __builtin_amdgcn_udot4(hi, kTapHi, 0u, false), false);
+        }
+        hb32[r * (HP / 2) + 2 * gq] = sres[0] | (sres[1] << 16);        // each <= 255 * 257 = 65535
+        hb32[r * (HP / 2) + 2 * gq + 1] = sres[2] | (sres[3] << 16);
       }
     }
     __syncthreads();
@@ -853,7 +902,7 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
     hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, g, src, d_pyr_, d_tab_, l, dbg_resize);
   }
   if (ev_ok_) hipEventRecord(ev_[1], st);
-  hipLaunchKernelGGL(k_fast, dim3(g.total_tiles, n), dim3(256), 0, st, g, src, d_pyr_, d_cand_cnt_, d_cand_);
+  hipLaunchKernelGGL(k_fast, dim3(g.total_tiles, n), dim3(kFastThreads), 0, st, g, src, d_pyr_, d_cand_cnt_, d_cand_, dbg_resize >> 4);
   if (ev_ok_) hipEventRecord(ev_[2], st);
   hipLaunchKernelGGL(k_thr_harris, dim3(g.nlevels, n), dim3(256), 0, st, g, src, d_pyr_, d_cand_cnt_, d_cand_,
                      d_s1_cnt_, d_s1_, d_status_);
