@@ -143,284 +143,293 @@ __global__ __launch_bounds__(256) void k_tokens(const float* __restrict__ bb, co
   tok[idx] = bb[((long long)img * DM + c) * NTOK + t] + pe[c * NTOK + t];
 }
 
-// ------------------------------------------------------------------ linear-attention encoder block
+// ------------------------------------------------------------------ linear-attention encoder block (MFMA)
+// All products of a block are 16-wide tiles of v_mfma_f32_16x16x4_f32 (exact f32).  Two k-slot orders let every
+// operand be used where it already is, with no transposes and no LDS round trips for activations:
+//   P8: operand rows that come from memory: slot (s, kq) <-> feature 8*kq + s, so a lane reads 8 contiguous floats;
+//   PD: operands that are MFMA results in registers (lane = column, regs = rows 4*(lane>>4)+r of each 16-row tile):
+//       slot (s', g) <-> feature 16*(s'/4) + 4*g + (s'%4), i.e. exactly the register the lane already holds.
+// Weights are re-ordered to those slot orders once on the host (pack_weight).
 struct BlockW {
-  const float *wq, *wk, *wv, *wm, *w0, *w1, *n1w, *n1b, *n2w, *n2b;
+  const float *wq_p, *wk_p, *wv_p, *wm_p, *w0_p, *w1_p;   // permuted: [(mtile*KS + slot)*64 + lane]
+  const float *n1w, *n1b, *n2w, *n2b;
 };
 
 __device__ __forceinline__ float elu1(float x) { return (x > 0.f ? x : expf(x) - 1.f) + 1.f; }
-
-// phase A: K = elu(s Wk) + 1, V = (s Wv) / 1200, KV = sum_t K_t^T V_t (32x32), Ksum = sum_t K_t.  One workgroup per
-// source sequence.
-__global__ __launch_bounds__(256) void k_attn_kv(const float* __restrict__ src, long long seq_stride, BlockW w,
-                                                 float* __restrict__ kv /*[n][1056]*/) {
-  __shared__ float sWk[DM * DM], sWv[DM * DM];
-  __shared__ float sK[64 * (DM + 1)], sV[64 * (DM + 1)];
-  const int tid = threadIdx.x;
-  const float* s = src + (long long)blockIdx.x * seq_stride;
-  for (int i = tid; i < DM * DM; i += 256) { sWk[i] = w.wk[i]; sWv[i] = w.wv[i]; }
-  // thread owns KV[d][e0..e0+3]
-  const int d = tid >> 3, e0 = (tid & 7) * 4;
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f, ksum = 0.f;
-  __syncthreads();
-  for (int t0 = 0; t0 < NTOK; t0 += 64) {
-    const int nt = min(64, NTOK - t0);
-    // 64 tokens x 32 outputs x {K, V}: thread computes token (tid & 63), outputs j = (tid >> 6) * 8 .. +8
-    {
-      const int t = tid & 63, j0 = (tid >> 6) * 8;
-      float kk[8], vv[8];
-#pragma unroll
-      for (int j = 0; j < 8; j++) { kk[j] = 0.f; vv[j] = 0.f; }
-      if (t < nt) {
-        const float* row = s + (long long)(t0 + t) * DM;
-        for (int p = 0; p < DM; p++) {
-          const float xv = row[p];
-#pragma unroll
-          for (int j = 0; j < 8; j++) {
-            kk[j] += xv * sWk[p * DM + j0 + j];
-            vv[j] += xv * sWv[p * DM + j0 + j];
-          }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        sK[t * (DM + 1) + j0 + j] = t < nt ? elu1(kk[j]) : 0.f;
-        sV[t * (DM + 1) + j0 + j] = t < nt ? vv[j] / 1200.0f : 0.f;
-      }
-    }
-    __syncthreads();
-    for (int t = 0; t < nt; t++) {
-      const float kd = sK[t * (DM + 1) + d];
-      acc0 += kd * sV[t * (DM + 1) + e0];
-      acc1 += kd * sV[t * (DM + 1) + e0 + 1];
-      acc2 += kd * sV[t * (DM + 1) + e0 + 2];
-      acc3 += kd * sV[t * (DM + 1) + e0 + 3];
-      if ((tid & 7) == 0) ksum += kd;
-    }
-    __syncthreads();
-  }
-  float* o = kv + (long long)blockIdx.x * (DM * DM + DM);
-  o[d * DM + e0] = acc0; o[d * DM + e0 + 1] = acc1; o[d * DM + e0 + 2] = acc2; o[d * DM + e0 + 3] = acc3;
-  if ((tid & 7) == 0) o[DM * DM + d] = ksum;
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float quad_sum(float v) {   // sum over the 4 lane groups that share lane & 15
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
 }
 
-// phase B: one lane per token; weights are wave-uniform LDS broadcasts.
-__device__ __forceinline__ void layer_norm32(float* v, const float* w, const float* b) {
-  float mean = 0.f;
+// phase A: K = elu(s Wk) + 1, V = (s Wv) / 1200, KV = sum_t K_t^T V_t, Ksum = sum_t K_t.  One workgroup per source
+// sequence, 4 waves x 16-token tiles; tokens on MFMA rows so K and V tiles feed the KV product straight from registers.
+__global__ __launch_bounds__(256) void k_attn_kv(const float* __restrict__ src, long long seq_stride, BlockW w,
+                                                 float* __restrict__ kv /*[n][1056]: KV in PD order | Ksum*/) {
+  __shared__ float sWk[DM * DM], sWv[DM * DM];
+  __shared__ float red[4][DM * DM + DM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tl = lane & 15, g = lane >> 4;
+  const float* s = src + (long long)blockIdx.x * seq_stride;
+  for (int i = tid; i < DM * DM; i += 256) { sWk[i] = w.wk_p[i]; sWv[i] = w.wv_p[i]; }
+  __syncthreads();
+  f32x4 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < DM; i++) mean += v[i];
-  mean /= (float)DM;
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float ksum[2] = {0.f, 0.f};
+  for (int tile = wave; tile < NTOK / 16; tile += 4) {
+    const float* xr = s + (long long)(tile * 16 + tl) * DM + 8 * g;
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(xr), x1 = *reinterpret_cast<const f32x4*>(xr + 4);
+    const float xa[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    f32x4 K[2], V[2];
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+      K[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      V[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sI = 0; sI < 8; sI++) {
+        K[n] = mfma4(xa[sI], sWk[(n * 8 + sI) * 64 + lane], K[n]);
+        V[n] = mfma4(xa[sI], sWv[(n * 8 + sI) * 64 + lane], V[n]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        K[n][r] = elu1(K[n][r]);
+        V[n][r] = V[n][r] / 1200.0f;
+        ksum[n] += K[n][r];
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+      for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[m][n] = mfma4(K[m][r], V[n][r], acc[m][n]);   // k-slot = token 4g + r
+  }
+  // per-wave partials -> LDS (plain [d][e]) ; Ksum[16n + tl] summed over the lane groups
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) red[wave][(16 * m + 4 * g + r) * DM + 16 * n + tl] = acc[m][n][r];
+#pragma unroll
+  for (int n = 0; n < 2; n++) {
+    const float t = quad_sum(ksum[n]);
+    if (g == 0) red[wave][DM * DM + 16 * n + tl] = t;
+  }
+  __syncthreads();
+  for (int i = tid; i < DM * DM + DM; i += 256) red[0][i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+  __syncthreads();
+  float* o = kv + (long long)blockIdx.x * (DM * DM + DM);
+  for (int i = tid; i < DM * DM; i += 256) {     // KV as the A operand of msg = KV^T Q, PD slot order over d
+    const int ln = i & 63, sl = (i >> 6) & 7, me = i >> 9;
+    const int d = 16 * (sl >> 2) + 4 * (ln >> 4) + (sl & 3), e = 16 * me + (ln & 15);
+    o[i] = red[0][d * DM + e];
+  }
+  if (tid < DM) o[DM * DM + tid] = red[0][DM * DM + tid];
+}
+
+// LayerNorm over the 32 features of a token held as v[2] (rows 16m + 4g + r of column lane & 15)
+__device__ __forceinline__ void layer_norm_cols(f32x4* v, const float* w, const float* b, int g) {
+  float sum = 0.f;
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) sum += v[m][r];
+  const float mean = quad_sum(sum) / (float)DM;
   float var = 0.f;
 #pragma unroll
-  for (int i = 0; i < DM; i++) { const float c = v[i] - mean; var += c * c; }
-  var /= (float)DM;
-  const float den = sqrtf(var + 1.0000000116860974e-07f);
+  for (int m = 0; m < 2; m++)
 #pragma unroll
-  for (int i = 0; i < DM; i++) v[i] = (v[i] - mean) / den * w[i] + b[i];
+    for (int r = 0; r < 4; r++) { const float c = v[m][r] - mean; var += c * c; }
+  const float den = sqrtf(quad_sum(var) / (float)DM + 1.0000000116860974e-07f);
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int f = 16 * m + 4 * g + r;
+      v[m][r] = (v[m][r] - mean) / den * w[f] + b[f];
+    }
 }
 
-__global__ __launch_bounds__(64) void k_attn_update(const float* __restrict__ xsrc, long long x_stride,
-                                                    const float* __restrict__ kv, BlockW w, float* __restrict__ dst,
-                                                    long long d_stride) {
-  __shared__ __attribute__((aligned(16))) float sW[DM * DM * 3 + 64 * 64 + 64 * DM + 4 * DM + DM];
-  float* sWq = sW;
-  float* sKV = sWq + DM * DM;
-  float* sWm = sKV + DM * DM;
-  float* sW0 = sWm + DM * DM;
-  float* sW1 = sW0 + 64 * 64;
-  float* sLN = sW1 + 64 * DM;   // n1w n1b n2w n2b
-  float* sKs = sLN + 4 * DM;
-  const int seq = blockIdx.y, lane = threadIdx.x;
+// phase B: features on MFMA rows, tokens on columns; one wave carries 16 tokens through the whole block.
+constexpr int kUpdTilesPerWave = 2;
+__global__ __launch_bounds__(256) void k_attn_update(const float* __restrict__ xsrc, long long x_stride,
+                                                     const float* __restrict__ kv, BlockW w, float* __restrict__ dst,
+                                                     long long d_stride) {
+  __shared__ float sWq[DM * DM], sKV[DM * DM], sWm[DM * DM], sW0[64 * 64], sW1[64 * DM];
+  __shared__ float sLN[4 * DM], sKs[DM];
+  const int seq = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tl = lane & 15, g = lane >> 4;
   const float* kvp = kv + (long long)seq * (DM * DM + DM);
-  for (int i = lane; i < DM * DM; i += 64) { sWq[i] = w.wq[i]; sKV[i] = kvp[i]; sWm[i] = w.wm[i]; }
-  for (int i = lane; i < 64 * 64; i += 64) sW0[i] = w.w0[i];
-  for (int i = lane; i < 64 * DM; i += 64) sW1[i] = w.w1[i];
-  if (lane < DM) {
-    sLN[lane] = w.n1w[lane]; sLN[DM + lane] = w.n1b[lane]; sLN[2 * DM + lane] = w.n2w[lane]; sLN[3 * DM + lane] = w.n2b[lane];
-    sKs[lane] = kvp[DM * DM + lane];
+  for (int i = tid; i < DM * DM; i += 256) { sWq[i] = w.wq_p[i]; sKV[i] = kvp[i]; sWm[i] = w.wm_p[i]; }
+  for (int i = tid; i < 64 * 64; i += 256) sW0[i] = w.w0_p[i];
+  for (int i = tid; i < 64 * DM; i += 256) sW1[i] = w.w1_p[i];
+  if (tid < DM) {
+    sLN[tid] = w.n1w[tid]; sLN[DM + tid] = w.n1b[tid]; sLN[2 * DM + tid] = w.n2w[tid]; sLN[3 * DM + tid] = w.n2b[tid];
+    sKs[tid] = kvp[DM * DM + tid];
   }
   __syncthreads();
-  const int t = blockIdx.x * 64 + lane;
-  if (t >= NTOK) return;
-  const float* xr = xsrc + (long long)seq * x_stride + (long long)t * DM;
-  float x[DM], q[DM];
+  for (int it = 0; it < kUpdTilesPerWave; it++) {
+    const int tile = (blockIdx.x * kUpdTilesPerWave + it) * 4 + wave;
+    if (tile >= NTOK / 16) break;
+    const float* xr = xsrc + (long long)seq * x_stride + (long long)(tile * 16 + tl) * DM;
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(xr + 8 * g), b1 = *reinterpret_cast<const f32x4*>(xr + 8 * g + 4);
+    const float xb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};                 // P8 slots
+    const f32x4 xd0 = *reinterpret_cast<const f32x4*>(xr + 4 * g), xd1 = *reinterpret_cast<const f32x4*>(xr + 16 + 4 * g);
+    // q = Wq^T x ; Q = elu(q) + 1 ; Z = 1 / (Q . Ksum + eps)
+    f32x4 q[2];
+    float zp = 0.f;
 #pragma unroll
-  for (int i = 0; i < DM; i += 4) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + i);
-    x[i] = v.x; x[i + 1] = v.y; x[i + 2] = v.z; x[i + 3] = v.w;
+    for (int m = 0; m < 2; m++) {
+      q[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sI = 0; sI < 8; sI++) q[m] = mfma4(sWq[(m * 8 + sI) * 64 + lane], xb[sI], q[m]);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        q[m][r] = elu1(q[m][r]);
+        zp += q[m][r] * sKs[16 * m + 4 * g + r];
+      }
+    }
+    const float z = 1.0f / (quad_sum(zp) + 9.999999974752427e-07f);
+    // msg = (KV^T Q) * Z * 1200
+    f32x4 ms[2];
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+      ms[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sI = 0; sI < 8; sI++) ms[m] = mfma4(sKV[(m * 8 + sI) * 64 + lane], q[sI >> 2][sI & 3], ms[m]);
+#pragma unroll
+      for (int r = 0; r < 4; r++) ms[m][r] = ms[m][r] * z * 1200.0f;
+    }
+    // merge + LN1
+    f32x4 mg[2];
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+      mg[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sI = 0; sI < 8; sI++) mg[m] = mfma4(sWm[(m * 8 + sI) * 64 + lane], ms[sI >> 2][sI & 3], mg[m]);
+    }
+    layer_norm_cols(mg, sLN, sLN + DM, g);
+    // MLP on [x | mg]: 64 -> 64 (ReLU) -> 32, LN2, residual
+    f32x4 h[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      h[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sI = 0; sI < 8; sI++) h[m] = mfma4(sW0[(m * 16 + sI) * 64 + lane], xb[sI], h[m]);
+#pragma unroll
+      for (int sI = 0; sI < 8; sI++) h[m] = mfma4(sW0[(m * 16 + 8 + sI) * 64 + lane], mg[sI >> 2][sI & 3], h[m]);
+#pragma unroll
+      for (int r = 0; r < 4; r++) h[m][r] = fmaxf(h[m][r], 0.f);
+    }
+    f32x4 o[2];
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+      o[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sI = 0; sI < 16; sI++) o[m] = mfma4(sW1[(m * 16 + sI) * 64 + lane], h[sI >> 2][sI & 3], o[m]);
+    }
+    layer_norm_cols(o, sLN + 2 * DM, sLN + 3 * DM, g);
+    float* dr = dst + (long long)seq * d_stride + (long long)(tile * 16 + tl) * DM;
+    *reinterpret_cast<f32x4*>(dr + 4 * g) = xd0 + o[0];
+    *reinterpret_cast<f32x4*>(dr + 16 + 4 * g) = xd1 + o[1];
   }
-  // q = x Wq; Q = elu(q) + 1
-#pragma unroll
-  for (int j = 0; j < DM; j++) q[j] = 0.f;
-#pragma unroll
-  for (int p = 0; p < DM; p++)
-#pragma unroll
-    for (int j = 0; j < DM; j++) q[j] += x[p] * sWq[p * DM + j];
-  float z = 0.f;
-#pragma unroll
-  for (int j = 0; j < DM; j++) { q[j] = elu1(q[j]); z += q[j] * sKs[j]; }
-  z = 1.0f / (z + 9.999999974752427e-07f);
-  // msg = (Q KV) * Z * 1200
-  float msg[DM];
-#pragma unroll
-  for (int e = 0; e < DM; e++) msg[e] = 0.f;
-#pragma unroll
-  for (int dd = 0; dd < DM; dd++)
-#pragma unroll
-    for (int e = 0; e < DM; e++) msg[e] += q[dd] * sKV[dd * DM + e];
-#pragma unroll
-  for (int e = 0; e < DM; e++) msg[e] = msg[e] * z * 1200.0f;
-  // merge + LN1
-  float mg[DM];
-#pragma unroll
-  for (int j = 0; j < DM; j++) mg[j] = 0.f;
-#pragma unroll
-  for (int p = 0; p < DM; p++)
-#pragma unroll
-    for (int j = 0; j < DM; j++) mg[j] += msg[p] * sWm[p * DM + j];
-  layer_norm32(mg, sLN, sLN + DM);
-  // MLP on [x | mg]: 64 -> 64 (ReLU) -> 32, LN2, residual
-  float h[64];
-#pragma unroll
-  for (int j = 0; j < 64; j++) h[j] = 0.f;
-#pragma unroll
-  for (int p = 0; p < DM; p++)
-#pragma unroll
-    for (int j = 0; j < 64; j++) h[j] += x[p] * sW0[p * 64 + j];
-#pragma unroll
-  for (int p = 0; p < DM; p++)
-#pragma unroll
-    for (int j = 0; j < 64; j++) h[j] += mg[p] * sW0[(DM + p) * 64 + j];
-  float o[DM];
-#pragma unroll
-  for (int j = 0; j < DM; j++) o[j] = 0.f;
-#pragma unroll
-  for (int p = 0; p < 64; p++) {
-    const float hv = fmaxf(h[p], 0.f);
-#pragma unroll
-    for (int j = 0; j < DM; j++) o[j] += hv * sW1[p * DM + j];
-  }
-  layer_norm32(o, sLN + 2 * DM, sLN + 3 * DM);
-  float* dr = dst + (long long)seq * d_stride + (long long)t * DM;
-#pragma unroll
-  for (int i = 0; i < DM; i += 4)
-    *reinterpret_cast<f32x4*>(dr + i) = f32x4{x[i] + o[i], x[i + 1] + o[i + 1], x[i + 2] + o[i + 2], x[i + 3] + o[i + 3]};
 }
 
-// ------------------------------------------------------------------ matching head
-// s_ij = ((fa_i / sqrt(32)) . (fb_j / sqrt(32))) / 0.1.  Row statistics (max, sum of exp) of S; calling it with the
-// operands swapped gives the column statistics with bit-identical s_ij (same products, same order).
-constexpr int STRIP = 16;
+// ------------------------------------------------------------------ matching head (MFMA)
+// s_ij = ((f0_i / sqrt(32)) . (f1_j / sqrt(32))) / 0.1 on 16x16 tiles, P8 slot order on both operands.
+__global__ __launch_bounds__(256) void k_scale_feats(const float* __restrict__ in, float* __restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = in[i] / 5.656854f;
+}
+
+__device__ __forceinline__ void load8(const float* p, float* v) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// Row statistics (max, sum of exp) of S = A B^T / 0.1; called with (f0s, f1s) for the rows and with (f1s, f0s) for
+// the columns: the products commute and are summed in the same order, so both calls see bit-identical s_ij.
 __global__ __launch_bounds__(256) void k_sim_stats(const float* __restrict__ fa, const float* __restrict__ fb,
                                                    long long pair_stride, float* __restrict__ stats /*[pair][2][1200]*/,
                                                    long long stats_stride) {
-  __shared__ float sA[STRIP * DM];
-  __shared__ float red[STRIP][256 / 64][2];
-  const int pair = blockIdx.y, i0 = blockIdx.x * STRIP, tid = threadIdx.x;
+  const int pair = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tl = lane & 15, g = lane >> 4;
+  const int it = blockIdx.x * 4 + wave;
+  if (it >= NTOK / 16) return;
   const float* A = fa + (long long)pair * pair_stride;
   const float* B = fb + (long long)pair * pair_stride;
-  for (int i = tid; i < STRIP * DM; i += 256) sA[i] = A[(long long)i0 * DM + i] / 5.656854f;
-  __syncthreads();
-  float mx[STRIP], sm[STRIP];
+  float a[8];
+  load8(A + (long long)(it * 16 + tl) * DM + 8 * g, a);
+  float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, sm[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int jt = 0; jt < NTOK / 16; jt++) {
+    float b[8];
+    load8(B + (long long)(jt * 16 + tl) * DM + 8 * g, b);
+    f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int r = 0; r < STRIP; r++) { mx[r] = -INFINITY; sm[r] = 0.f; }
-  for (int j = tid; j < NTOK; j += 256) {
-    float b[DM];
+    for (int sI = 0; sI < 8; sI++) d = mfma4(a[sI], b[sI], d);
 #pragma unroll
-    for (int p = 0; p < DM; p += 4) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(B + (long long)j * DM + p);
-      b[p] = v.x / 5.656854f; b[p + 1] = v.y / 5.656854f; b[p + 2] = v.z / 5.656854f; b[p + 3] = v.w / 5.656854f;
-    }
-#pragma unroll
-    for (int r = 0; r < STRIP; r++) {
-      float s = 0.f;
-#pragma unroll
-      for (int p = 0; p < DM; p++) s += sA[r * DM + p] * b[p];
-      s = s / 0.1f;
-      // online softmax statistics
+    for (int r = 0; r < 4; r++) {
+      const float s = d[r] / 0.1f;
       if (s > mx[r]) { sm[r] = sm[r] * expf(mx[r] - s) + 1.f; mx[r] = s; }
       else sm[r] += expf(s - mx[r]);
     }
   }
-  // combine across the workgroup
-  const int lane = tid & 63, wave = tid >> 6;
+  // combine the 16 lanes (columns) that share each row
 #pragma unroll
-  for (int r = 0; r < STRIP; r++) {
+  for (int r = 0; r < 4; r++) {
     float m = mx[r], s = sm[r];
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
+    for (int o = 1; o < 16; o <<= 1) {
       const float m2 = __shfl_xor(m, o), s2 = __shfl_xor(s, o);
       const float mm = fmaxf(m, m2);
-      s = (m == -INFINITY ? 0.f : s * expf(m - mm)) + (m2 == -INFINITY ? 0.f : s2 * expf(m2 - mm));
+      s = s * expf(m - mm) + s2 * expf(m2 - mm);
       m = mm;
     }
-    if (lane == 0) { red[r][wave][0] = m; red[r][wave][1] = s; }
-  }
-  __syncthreads();
-  if (tid < STRIP) {
-    float m = -INFINITY, s = 0.f;
-    for (int w = 0; w < 4; w++) {
-      const float m2 = red[tid][w][0], s2 = red[tid][w][1];
-      const float mm = fmaxf(m, m2);
-      s = (m == -INFINITY ? 0.f : s * expf(m - mm)) + (m2 == -INFINITY ? 0.f : s2 * expf(m2 - mm));
-      m = mm;
+    if (tl == 0) {
+      float* st = stats + (long long)pair * stats_stride;
+      st[it * 16 + 4 * g + r] = m;
+      st[NTOK + it * 16 + 4 * g + r] = s;
     }
-    float* st = stats + (long long)pair * stats_stride;
-    st[i0 + tid] = m;
-    st[NTOK + i0 + tid] = s;
   }
 }
 
-// conf_ij = softmax_i(s)_ij * softmax_j(s)_ij, '> threshold' -> bit mask; the 5.76 MB confidence matrix is never
-// written (except for the debug pair).
-__global__ __launch_bounds__(256) void k_conf_mask(const float* __restrict__ f0, const float* __restrict__ f1,
+// conf_ij = softmax_i(s)_ij * softmax_j(s)_ij, '> threshold' -> bit mask (16-bit chunk per row and column tile);
+// the 5.76 MB confidence matrix is never written (except for the debug pair).
+__global__ __launch_bounds__(256) void k_conf_mask(const float* __restrict__ f0s, const float* __restrict__ f1s,
                                                    long long pair_stride, const float* __restrict__ rstats,
                                                    const float* __restrict__ cstats, long long stats_stride,
                                                    float threshold, uint32_t* __restrict__ mask, float* conf_dbg,
                                                    int dbg_pair) {
-  __shared__ float sA[STRIP * DM];
-  __shared__ float sRm[STRIP], sRs[STRIP];
-  const int pair = blockIdx.y, i0 = blockIdx.x * STRIP, tid = threadIdx.x, lane = tid & 63;
-  const float* A = f0 + (long long)pair * pair_stride;
-  const float* B = f1 + (long long)pair * pair_stride;
+  const int pair = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tl = lane & 15, g = lane >> 4;
+  const int it = blockIdx.x * 4 + wave;
+  if (it >= NTOK / 16) return;
+  const float* A = f0s + (long long)pair * pair_stride;
+  const float* B = f1s + (long long)pair * pair_stride;
   const float* rs = rstats + (long long)pair * stats_stride;
   const float* cs = cstats + (long long)pair * stats_stride;
-  for (int i = tid; i < STRIP * DM; i += 256) sA[i] = A[(long long)i0 * DM + i] / 5.656854f;
-  if (tid < STRIP) { sRm[tid] = rs[i0 + tid]; sRs[tid] = rs[NTOK + i0 + tid]; }
-  __syncthreads();
-  uint32_t* mk = mask + (long long)pair * NTOK * MASK_WORDS;
+  uint16_t* mk = reinterpret_cast<uint16_t*>(mask + (long long)pair * NTOK * MASK_WORDS);
   float* dbg = (conf_dbg && pair == dbg_pair) ? conf_dbg : nullptr;
-  for (int j0 = 0; j0 < 1280; j0 += 256) {   // 5 x 256 columns cover the 38 mask words (1216 bits) of a row
-    const int j = j0 + tid;
-    const bool ok = j < NTOK;
-    float b[DM];
-    float cm = 0.f, csum = 1.f;
-    if (ok) {
+  float a[8], rm[4], rsum[4];
+  load8(A + (long long)(it * 16 + tl) * DM + 8 * g, a);
 #pragma unroll
-      for (int p = 0; p < DM; p += 4) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(B + (long long)j * DM + p);
-        b[p] = v.x / 5.656854f; b[p + 1] = v.y / 5.656854f; b[p + 2] = v.z / 5.656854f; b[p + 3] = v.w / 5.656854f;
-      }
-      cm = cs[j]; csum = cs[NTOK + j];
-    } else {
+  for (int r = 0; r < 4; r++) { rm[r] = rs[it * 16 + 4 * g + r]; rsum[r] = rs[NTOK + it * 16 + 4 * g + r]; }
+  for (int jt = 0; jt < NTOK / 16; jt++) {
+    float b[8];
+    const int j = jt * 16 + tl;
+    load8(B + (long long)j * DM + 8 * g, b);
+    const float cm = cs[j], csum = cs[NTOK + j];
+    f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int p = 0; p < DM; p++) b[p] = 0.f;
-    }
+    for (int sI = 0; sI < 8; sI++) d = mfma4(a[sI], b[sI], d);
 #pragma unroll
-    for (int r = 0; r < STRIP; r++) {
-      float s = 0.f;
-#pragma unroll
-      for (int p = 0; p < DM; p++) s += sA[r * DM + p] * b[p];
-      s = s / 0.1f;
-      const float conf = (expf(s - cm) / csum) * (expf(s - sRm[r]) / sRs[r]);
-      const bool hit = ok && conf > threshold;   // strict '>' (dnnfeaturematcher.cpp:75)
-      const unsigned long long bal = __ballot(hit);
-      if (j0 + (tid & ~63) < NTOK) {
-        const int word = (j0 + (tid & ~63)) >> 5;
-        if (lane == 0) mk[(i0 + r) * MASK_WORDS + word] = (uint32_t)bal;
-        if (lane == 32 && word + 1 < MASK_WORDS) mk[(i0 + r) * MASK_WORDS + word + 1] = (uint32_t)(bal >> 32);
-      }
-      if (dbg && ok) dbg[(long long)(i0 + r) * NTOK + j] = conf;
+    for (int r = 0; r < 4; r++) {
+      const float s = d[r] / 0.1f;
+      const float conf = (expf(s - cm) / csum) * (expf(s - rm[r]) / rsum[r]);
+      const unsigned long long bal = __ballot(conf > threshold);   // strict '>' (dnnfeaturematcher.cpp:75)
+      if (tl == 0) mk[(long long)(it * 16 + 4 * g + r) * (2 * MASK_WORDS) + jt] = (uint16_t)(bal >> (16 * g));
+      if (dbg) dbg[(long long)(it * 16 + 4 * g + r) * NTOK + j] = conf;
     }
   }
 }
@@ -491,17 +500,17 @@ struct LoftrPipeline::Impl {
   BlockW blk[8];
   // workspace (per chunk of pairs)
   float *bufA = nullptr, *bufB = nullptr, *bufC = nullptr, *bufD = nullptr;
-  float *tok[4] = {nullptr, nullptr, nullptr, nullptr};  // f0 f1 t0 t1, each [chunk][1200][32]
-  float* kv = nullptr;       // [chunk][1056]
-  float* rstats = nullptr;   // [chunk][2][1200]
+  float *tok[4] = {nullptr, nullptr, nullptr, nullptr};  // f0 f1 t0 t1, each [max_pairs][1200][32]
+  float* fsc = nullptr;      // [2][max_pairs][1200][32] features / sqrt(32)
+  float* kv = nullptr;       // [max_pairs][1056]
+  float* rstats = nullptr;   // [max_pairs][2][1200]
   float* cstats = nullptr;
-  uint32_t* mask = nullptr;  // [chunk][1200][38]
+  uint32_t* mask = nullptr;  // [max_pairs][1200][38]
   float* conf_dbg = nullptr; // [1200][1200]
   float* feat_dbg = nullptr; // [2][1200][32]
   int dbg_pair = 0;
   bool have_dbg = false;
-  std::vector<hipEvent_t> ev;  // 4 per chunk
-  int ev_chunks = 0;
+  std::vector<hipEvent_t> ev;  // start, backbone done, transformer done, head done
   bool ev_ok = false, ev_rec = false;
 };
 
@@ -630,15 +639,29 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
   }
   for (int b = 0; b < 8; b++) {
     char nm[32];
-    struct { const char* n; size_t cnt; const float** dst; } items[] = {
-        {"wq", 1024, &P.blk[b].wq}, {"wk", 1024, &P.blk[b].wk}, {"wv", 1024, &P.blk[b].wv},
-        {"wmerge", 1024, &P.blk[b].wm}, {"wmlp0", 4096, &P.blk[b].w0}, {"wmlp1", 2048, &P.blk[b].w1}};
+    // slot orders (see the kernel comments): 0 = P8 (feature 8*kq + s), 1 = PD (feature 16*(s/4) + 4*kq + s%4);
+    // `split`: wmlp0's 64 inputs are [x (P8, 8 slots) | merged message (PD, 8 slots)]
+    struct { const char* n; int in, out; int order; const float** dst; } items[] = {
+        {"wq", 32, 32, 0, &P.blk[b].wq_p}, {"wk", 32, 32, 0, &P.blk[b].wk_p}, {"wv", 32, 32, 0, &P.blk[b].wv_p},
+        {"wmerge", 32, 32, 1, &P.blk[b].wm_p}, {"wmlp0", 64, 64, 2, &P.blk[b].w0_p}, {"wmlp1", 64, 32, 1, &P.blk[b].w1_p}};
     for (auto& it : items) {
       snprintf(nm, sizeof nm, "blk%d.%s", b, it.n);
-      const auto* w = need(nm, it.cnt);
+      const auto* w = need(nm, (size_t)it.in * it.out);
       if (!w) return std::string("io: weights blob lacks ") + nm;
+      const int slots = it.in / 4, mtiles = it.out / 16;
+      std::vector<float> pk((size_t)it.in * it.out);
+      for (int mt = 0; mt < mtiles; mt++)
+        for (int sl = 0; sl < slots; sl++)
+          for (int ln = 0; ln < 64; ln++) {
+            const int kq = ln >> 4;
+            int feat;
+            if (it.order == 0) feat = 8 * kq + sl;
+            else if (it.order == 1) feat = 16 * (sl >> 2) + 4 * kq + (sl & 3);
+            else feat = sl < 8 ? 8 * kq + sl : 32 + 16 * ((sl - 8) >> 2) + 4 * kq + ((sl - 8) & 3);
+            pk[((size_t)mt * slots + sl) * 64 + ln] = (*w)[(size_t)feat * it.out + 16 * mt + (ln & 15)];
+          }
       float* d = nullptr;
-      LF_TRY(upload(*w, &d));
+      LF_TRY(upload(pk, &d));
       *it.dst = d;
     }
     struct { const char* n; const float** dst; } lns[] = {
@@ -663,19 +686,22 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
   LF_TRY(dalloc(&P.bufB, big));
   LF_TRY(dalloc(&P.bufC, big));
   LF_TRY(dalloc(&P.bufD, big / 2));
-  for (int i = 0; i < 4; i++) LF_TRY(dalloc(&P.tok[i], (size_t)P.chunk * NTOK * DM));
-  LF_TRY(dalloc(&P.kv, (size_t)P.chunk * (DM * DM + DM)));
-  LF_TRY(dalloc(&P.rstats, (size_t)P.chunk * 2 * NTOK));
-  LF_TRY(dalloc(&P.cstats, (size_t)P.chunk * 2 * NTOK));
+  for (int i = 0; i < 4; i++) LF_TRY(dalloc(&P.tok[i], (size_t)max_pairs * NTOK * DM));
+  LF_TRY(dalloc(&P.fsc, (size_t)2 * max_pairs * NTOK * DM));
+  LF_TRY(dalloc(&P.kv, (size_t)max_pairs * (DM * DM + DM)));
+  LF_TRY(dalloc(&P.rstats, (size_t)max_pairs * 2 * NTOK));
+  LF_TRY(dalloc(&P.cstats, (size_t)max_pairs * 2 * NTOK));
   {
     float* m = nullptr;
-    LF_TRY(dalloc(&m, (size_t)P.chunk * NTOK * MASK_WORDS));
+    LF_TRY(dalloc(&m, (size_t)max_pairs * NTOK * MASK_WORDS));
     P.mask = reinterpret_cast<uint32_t*>(m);
+    // the last 16-bit chunk of every row (bits 1200 .. 1215) is never written: keep it zero
+    LF_TRY(hipMemset(P.mask, 0, (size_t)max_pairs * NTOK * MASK_WORDS * sizeof(uint32_t)));
   }
   LF_TRY(dalloc(&P.conf_dbg, (size_t)NTOK * NTOK));
   LF_TRY(dalloc(&P.feat_dbg, (size_t)2 * NTOK * DM));
   if (profile) {
-    P.ev.resize((size_t)4 * ((max_pairs + P.chunk - 1) / P.chunk));
+    P.ev.resize(4);
     for (auto& e : P.ev) LF_TRY(hipEventCreate(&e));
     P.ev_ok = true;
   }
@@ -709,16 +735,18 @@ hipError_t LoftrPipeline::match(int n_pairs, const uint8_t* d_a, const uint8_t* 
                                 hipStream_t st) {
   if (!p_) return hipErrorNotInitialized;
   Impl& P = *p_;
+  if (n_pairs > P.max_pairs) return hipErrorInvalidValue;
+  const long long ts = (long long)NTOK * DM;
+  hipEvent_t* ev = P.ev_ok ? P.ev.data() : nullptr;
+  if (ev) hipEventRecord(ev[0], st);
+  // ---- backbone, in chunks of pairs (activations are the big buffers); tokens of all pairs are kept
   for (int p0 = 0; p0 < n_pairs; p0 += P.chunk) {
     const int n = std::min(P.chunk, n_pairs - p0);
     const int ni = 2 * n;  // images: [0, n) = frame 1 of each pair, [n, 2n) = frame 2
-    const bool first = p0 == 0;
-    hipEvent_t* ev = P.ev_ok ? &P.ev[(size_t)4 * (p0 / P.chunk)] : nullptr;
-    if (ev) hipEventRecord(ev[0], st);
-    // the stem reads u8 frames from two arrays: launch it per array
     const ConvDesc* c = P.conv;
     float *a = P.bufA, *b = P.bufB, *cc = P.bufC, *d = P.bufD;
     const long long s8 = 8LL * 240 * 320;
+    // the stem reads u8 frames from two arrays: launch it per array
     launch_conv<1, 8, 7, 2, 64, true, false, true>(c[0], d_a + (long long)p0 * frame_stride, frame_stride, row_stride, nullptr, a, n, st);
     launch_conv<1, 8, 7, 2, 64, true, false, true>(c[0], d_b + (long long)p0 * frame_stride, frame_stride, row_stride, nullptr, a + (long long)n * s8, n, st);
     // layer1 @240x320, 8 ch
@@ -748,50 +776,49 @@ hipError_t LoftrPipeline::match(int n_pairs, const uint8_t* d_a, const uint8_t* 
     launch_conv<32, 32, 3, 1, 16, true, false, false>(c[18], cc, s40, 0, nullptr, b, ni, st);
     launch_conv<32, 32, 3, 1, 16, true, true, false>(c[19], b, s40, 0, cc, a, ni, st);             // a = 244
     launch_conv<32, 32, 1, 1, 16, false, false, false>(c[20], a, s40, 0, nullptr, b, ni, st);      // b = 245
-    if (ev) hipEventRecord(ev[1], st);
-    // tokens: images [0,n) -> tok[0] (feat0), [n,2n) -> tok[1] (feat1)
-    const long long ts = (long long)NTOK * DM;
-    hipLaunchKernelGGL(k_tokens, dim3((n * NTOK * DM + 255) / 256), dim3(256), 0, st, b, P.d_pe, P.tok[0], n);
-    hipLaunchKernelGGL(k_tokens, dim3((n * NTOK * DM + 255) / 256), dim3(256), 0, st, b + (long long)n * s40, P.d_pe, P.tok[1], n);
-    // 8 encoder blocks: (x, source) -> dst   [self, self, cross, cross(updated feat0)] x 2
-    float *f0 = P.tok[0], *f1 = P.tok[1], *t0 = P.tok[2], *t1 = P.tok[3];
-    struct { const float* x; const float* s; float* o; } seq[8] = {
-        {f0, f0, t0}, {f1, f1, t1}, {t0, t1, f0}, {t1, f0, f1}, {f0, f0, t0}, {f1, f1, t1}, {t0, t1, f0}, {t1, f0, f1}};
-    for (int bi = 0; bi < 8; bi++) {
-      hipLaunchKernelGGL(k_attn_kv, dim3(n), dim3(256), 0, st, seq[bi].s, ts, P.blk[bi], P.kv);
-      hipLaunchKernelGGL(k_attn_update, dim3((NTOK + 63) / 64, n), dim3(64), 0, st, seq[bi].x, ts, P.kv, P.blk[bi],
-                         seq[bi].o, ts);
-    }
-    if (ev) hipEventRecord(ev[2], st);
-    // matching head on (f0, f1)
-    hipLaunchKernelGGL(k_sim_stats, dim3(NTOK / STRIP, n), dim3(256), 0, st, f0, f1, ts, P.rstats, 2LL * NTOK);
-    hipLaunchKernelGGL(k_sim_stats, dim3(NTOK / STRIP, n), dim3(256), 0, st, f1, f0, ts, P.cstats, 2LL * NTOK);
-    const bool dbg = first;  // keep pair 0's confidence matrix + features for the parity tests
-    hipLaunchKernelGGL(k_conf_mask, dim3(NTOK / STRIP, n), dim3(256), 0, st, f0, f1, ts, P.rstats, P.cstats,
-                       2LL * NTOK, threshold, P.mask, dbg ? P.conf_dbg : nullptr, 0);
-    hipLaunchKernelGGL(k_decode, dim3(n), dim3(256), 0, st, P.mask, d_out + (long long)p0 * cap, cap, d_n_out + p0);
-    if (dbg) {
-      hipMemcpyAsync(P.feat_dbg, f0, ts * sizeof(float), hipMemcpyDeviceToDevice, st);
-      hipMemcpyAsync(P.feat_dbg + ts, f1, ts * sizeof(float), hipMemcpyDeviceToDevice, st);
-      P.have_dbg = true;
-    }
-    if (ev) { hipEventRecord(ev[3], st); P.ev_rec = true; P.ev_chunks = p0 / P.chunk + 1; }
+    // tokens: images [0,n) -> tok[0] (feat0), [n,2n) -> tok[1] (feat1), at this chunk's pair offset
+    hipLaunchKernelGGL(k_tokens, dim3((n * NTOK * DM + 255) / 256), dim3(256), 0, st, b, P.d_pe, P.tok[0] + p0 * ts, n);
+    hipLaunchKernelGGL(k_tokens, dim3((n * NTOK * DM + 255) / 256), dim3(256), 0, st, b + (long long)n * s40, P.d_pe, P.tok[1] + p0 * ts, n);
   }
+  if (ev) hipEventRecord(ev[1], st);
+  // ---- 8 encoder blocks over all pairs: (x, source) -> dst   [self, self, cross, cross(updated feat0)] x 2
+  const int n = n_pairs;
+  float *f0 = P.tok[0], *f1 = P.tok[1], *t0 = P.tok[2], *t1 = P.tok[3];
+  struct { const float* x; const float* s; float* o; } seq[8] = {
+      {f0, f0, t0}, {f1, f1, t1}, {t0, t1, f0}, {t1, f0, f1}, {f0, f0, t0}, {f1, f1, t1}, {t0, t1, f0}, {t1, f0, f1}};
+  const int upd_blocks = (NTOK / 16 + 4 * kUpdTilesPerWave - 1) / (4 * kUpdTilesPerWave);
+  for (int bi = 0; bi < 8; bi++) {
+    hipLaunchKernelGGL(k_attn_kv, dim3(n), dim3(256), 0, st, seq[bi].s, ts, P.blk[bi], P.kv);
+    hipLaunchKernelGGL(k_attn_update, dim3(upd_blocks, n), dim3(256), 0, st, seq[bi].x, ts, P.kv, P.blk[bi], seq[bi].o, ts);
+  }
+  if (ev) hipEventRecord(ev[2], st);
+  // ---- matching head on (f0, f1)
+  float* f0s = P.fsc;
+  float* f1s = P.fsc + (long long)P.max_pairs * ts;
+  hipLaunchKernelGGL(k_scale_feats, dim3((unsigned)((n * ts + 255) / 256)), dim3(256), 0, st, f0, f0s, n * ts);
+  hipLaunchKernelGGL(k_scale_feats, dim3((unsigned)((n * ts + 255) / 256)), dim3(256), 0, st, f1, f1s, n * ts);
+  const int head_blocks = (NTOK / 16 + 3) / 4;
+  hipLaunchKernelGGL(k_sim_stats, dim3(head_blocks, n), dim3(256), 0, st, f0s, f1s, ts, P.rstats, 2LL * NTOK);
+  hipLaunchKernelGGL(k_sim_stats, dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats, 2LL * NTOK);
+  // pair 0's confidence matrix + features are kept for the parity tests
+  hipLaunchKernelGGL(k_conf_mask, dim3(head_blocks, n), dim3(256), 0, st, f0s, f1s, ts, P.rstats, P.cstats, 2LL * NTOK,
+                     threshold, P.mask, P.conf_dbg, 0);
+  hipLaunchKernelGGL(k_decode, dim3(n), dim3(256), 0, st, P.mask, d_out, cap, d_n_out);
+  hipMemcpyAsync(P.feat_dbg, f0, ts * sizeof(float), hipMemcpyDeviceToDevice, st);
+  hipMemcpyAsync(P.feat_dbg + ts, f1, ts * sizeof(float), hipMemcpyDeviceToDevice, st);
+  P.have_dbg = true;
+  if (ev) { hipEventRecord(ev[3], st); P.ev_rec = true; }
   return hipGetLastError();
 }
 
 int LoftrPipeline::stage_times(const char** names, float* ms, int cap) {
   static const char* kNames[3] = {"backbone_convs", "transformer", "match_head"};
   if (!p_ || !p_->ev_ok || !p_->ev_rec) return 0;
-  if (hipEventSynchronize(p_->ev[(size_t)4 * p_->ev_chunks - 1]) != hipSuccess) return 0;
+  if (hipEventSynchronize(p_->ev[3]) != hipSuccess) return 0;
   int n = 0;
   for (int i = 0; i < 3 && n < cap; i++, n++) {
     names[n] = kNames[i];
-    ms[n] = 0.f;
-    for (int c = 0; c < p_->ev_chunks; c++) {   // sum over the chunks of the last call
-      float t = 0.f;
-      if (hipEventElapsedTime(&t, p_->ev[(size_t)4 * c + i], p_->ev[(size_t)4 * c + i + 1]) == hipSuccess) ms[n] += t;
-    }
+    if (hipEventElapsedTime(&ms[n], p_->ev[i], p_->ev[i + 1]) != hipSuccess) ms[n] = -1.f;
   }
   return n;
 }
