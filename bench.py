@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--ratio", type=float, default=0.6, help="Lowe ratio (the app uses 0.6, src/main.cpp:66)")
     ap.add_argument("--cap", type=int, default=1024, help="match-list capacity per pair")
     ap.add_argument("--matcher", default="orb", choices=["orb", "loftr"])
+    ap.add_argument("--synth-mode", type=int, default=None,
+                    help="synthetic texture: 0 blocky x8 (SURVEY 8d, ORB default), 1 smooth blobs (LoFTR default), 2 blocky x16")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--cpu-pairs-per-thread", type=int, default=2)
     ap.add_argument("--cpu-loftr-pairs", type=int, default=8)
@@ -118,7 +120,8 @@ def main():
             args.pairs = 256
     W, H, P = args.width, args.height, args.pairs
     # synthetic pairs of this rank (pair index = rank * P + i), resident in HBM before timing
-    A, B = synth.synth_batch(rank * P, P, W, H, mode=1 if args.matcher == "loftr" else 0,
+    mode = args.synth_mode if args.synth_mode is not None else (1 if args.matcher == "loftr" else 0)
+    A, B = synth.synth_batch(rank * P, P, W, H, mode=mode,
                              threads=min(16, os.cpu_count() or 1))
     dA, dB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
     if args.matcher == "orb":
@@ -210,7 +213,7 @@ def main():
             "config": {"workload": "%s extract+match, %dx%d pairs, %d pairs/GPU/step resident in HBM, %s"
                                    % (args.matcher.upper(), W, H, P,
                                       "ratio %.2f" % args.ratio if args.matcher == "orb" else "conf threshold %.2f" % args.threshold),
-                       "pairs_per_gpu": P, "width": W, "height": H,
+                       "pairs_per_gpu": P, "width": W, "height": H, "synth_mode": mode,
                        "matches_per_pair_mean": round(float(np.mean([len(l) for l in lists])), 2),
                        "overflow_pairs": int((cnt_h < 0).sum())},
             "roofline": roofline,

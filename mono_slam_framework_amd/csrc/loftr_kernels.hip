@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -580,7 +581,11 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
   p_ = new Impl();
   Impl& P = *p_;
   P.max_pairs = max_pairs;
-  P.chunk = max_pairs < 32 ? max_pairs : 32;
+  {
+    const char* e = getenv("MSF_LOFTR_CHUNK");   // pairs per backbone pass (activation working set)
+    const int want = e ? atoi(e) : 64;
+    P.chunk = max_pairs < want ? max_pairs : (want > 0 ? want : 64);
+  }
   P.profile = profile;
   Blob blob;
   std::string err = load_blob(weights_path && weights_path[0] ? weights_path : default_weights(), &blob);

@@ -50,7 +50,7 @@ __device__ __forceinline__ const uint8_t* level_ptr(const OrbGeometry& g, const 
 // and stores them as one dword.  Taps with weight 0 may read one byte past the image: staged as 0, times 0.
 constexpr int RTW = 64, RTH = 64, RLW = 96, RLH = 84;   // big tiles: the launch is latency-bound, not ALU-bound
 __global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uint8_t* pyr,
-                                                const uint16_t* __restrict__ tab, int l, int dbg) {
+                                                const uint16_t* __restrict__ tab, int l) {
   __shared__ __attribute__((aligned(16))) uint8_t t[RLH * RLW];
   const int fi = blockIdx.z;
   const OrbLevelInfo L = g.lv[l];
@@ -70,12 +70,12 @@ __global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uin
     if (r >= nrow) break;
     const int gx = sx0 + 4 * c, gy = sy0 + r;
     uint32_t v = 0;
-    if (gy < sh && gx + 4 <= spitch && !(dbg & 1)) v = *reinterpret_cast<const uint32_t*>(s + (long long)gy * spitch + gx);
+    if (gy < sh && gx + 4 <= spitch) v = *reinterpret_cast<const uint32_t*>(s + (long long)gy * spitch + gx);
     reinterpret_cast<uint32_t*>(t)[i] = v;
   }
   __syncthreads();
   const int x4 = X0 + 4 * (tid & 15);
-  if (x4 >= L.w || (dbg & 2)) return;
+  if (x4 >= L.w) return;
   // LDS is read as ALIGNED dwords and the two taps are cut out with v_alignbyte: adjacent byte reads get fused
   // by the compiler into misaligned ds_read_u16, which the LDS replays (measured: 5x slower kernel).
   const uint32_t* T = reinterpret_cast<const uint32_t*>(t);
@@ -177,7 +177,7 @@ __device__ __forceinline__ uint32_t reserve_packed(uint32_t mine, uint32_t* coun
 
 constexpr int kFastThreads = 256;   // 320 (two full prefilter passes) measured slower: 5 waves sit unevenly on 4 SIMDs
 __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
-                                                       uint32_t* cand_cnt, uint2* cand, int dbg) {
+                                                       uint32_t* cand_cnt, uint2* cand) {
   __shared__ __attribute__((aligned(16))) uint8_t px[PW2 * PH2];
   __shared__ __attribute__((aligned(16))) uint8_t sc[SP * SH + 2 * SCO];   // one dword of slack either side
   __shared__ uint16_t list1[kList1Cap];
@@ -211,7 +211,6 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
   for (int i = tid; i < (SP * SH + 2 * SCO) / 4; i += kFastThreads) reinterpret_cast<uint32_t*>(sc)[i] = 0;
   __syncthreads();
 
-  if (dbg & 1) return;
   // phase 1: cardinal prefilter on 4 px per lane
   const uint32_t* T = reinterpret_cast<const uint32_t*>(px);
   const int txlo = max(-1, 3 - x0), txhi = min(TW, L.w - 4 - x0);   // scored tile-x range
@@ -244,6 +243,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
     }
     const uint32_t cb = ((b0 | b8) & (b4 | b12)) & vm;
     const uint32_t cd = ~((n0 & n8) | (n4 & n12)) & vm;
+    if (__ballot((cb | cd) != 0u) == 0ull) continue;   // flat region: nothing to append for this wave
     const uint32_t e0 = (uint32_t)(sr * SP + tx0 + 1);
     // lane order = x order, so phase 2's LDS reads stay bank-friendly
     const uint32_t slots = reserve_packed(__popc(cb) | (__popc(cd) << 16), &nbd, lane);
@@ -260,7 +260,6 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
   }
   __syncthreads();
 
-  if (dbg & 2) return;
   // phase 2: exact score of the survivors, one polarity per loop, written into the (zeroed) score tile
   const uint32_t mb = nbd & 0xFFFFu, md = nbd >> 16;
   for (uint32_t i = tid; i < mb; i += kFastThreads) {
@@ -277,7 +276,6 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
   }
   __syncthreads();
 
-  if (dbg & 4) return;
   // phase 3: strict 3x3 NMS + runByImageBorder(31), dense on 4 scores per lane: "c > n" per byte is bit 7 of
   // lerp(c, ~n) = (c + 255 - n) >> 1; non-corners hold 0 and can never be strictly greater.
   {
@@ -292,7 +290,9 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
       const uint32_t C = S[w];
       uint32_t keep = 0;
       const int gy = y0 + r - 1;
-      if (i < (SP / 4) * TH && C != 0 && gy >= kEdge && gy < L.h - kEdge) {
+      const bool live = i < (SP / 4) * TH && C != 0 && gy >= kEdge && gy < L.h - kEdge;
+      if (__ballot(live) == 0ull) continue;              // no corner in these 256 score columns
+      if (live) {
         const uint32_t Cl = S[w - 1], Cr = S[w + 1];
         const uint32_t U = S[w - SP / 4], Ul = S[w - SP / 4 - 1], Ur = S[w - SP / 4 + 1];
         const uint32_t D = S[w + SP / 4], Dl = S[w + SP / 4 - 1], Dr = S[w + SP / 4 + 1];
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
   }
   __syncthreads();
   const uint32_t n = lcount;
-  if (n == 0 || (dbg & 8)) return;
+  if (n == 0) return;
   if (tid == 0) gbase = atomicAdd(&cand_cnt[slot * kOrbLevels + l], n);
   __syncthreads();
   const uint32_t base = gbase;
@@ -895,14 +895,13 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
   if ((e = hipMemsetAsync(d_cand_cnt_ + (size_t)src.slot0 * kOrbLevels, 0, (size_t)n * kOrbLevels * 4, st))) return e;
   if ((e = hipMemsetAsync(d_status_ + src.slot0, 0, (size_t)n * 4, st))) return e;
   if (ev_ok_) hipEventRecord(ev_[0], st);
-  static const int dbg_resize = getenv("MSF_DEBUG_RESIZE") ? atoi(getenv("MSF_DEBUG_RESIZE")) : 0;
   for (int l = 1; l < g.nlevels; l++) {
     const OrbLevelInfo& L = g.lv[l];
     dim3 grid((L.w + RTW - 1) / RTW, (L.h + RTH - 1) / RTH, n);
-    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, g, src, d_pyr_, d_tab_, l, dbg_resize);
+    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, g, src, d_pyr_, d_tab_, l);
   }
   if (ev_ok_) hipEventRecord(ev_[1], st);
-  hipLaunchKernelGGL(k_fast, dim3(g.total_tiles, n), dim3(kFastThreads), 0, st, g, src, d_pyr_, d_cand_cnt_, d_cand_, dbg_resize >> 4);
+  hipLaunchKernelGGL(k_fast, dim3(g.total_tiles, n), dim3(kFastThreads), 0, st, g, src, d_pyr_, d_cand_cnt_, d_cand_);
   if (ev_ok_) hipEventRecord(ev_[2], st);
   hipLaunchKernelGGL(k_thr_harris, dim3(g.nlevels, n), dim3(256), 0, st, g, src, d_pyr_, d_cand_cnt_, d_cand_,
                      d_s1_cnt_, d_s1_, d_status_);
