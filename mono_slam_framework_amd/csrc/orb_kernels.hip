@@ -45,65 +45,59 @@ __device__ __forceinline__ const uint8_t* level_ptr(const OrbGeometry& g, const 
 
 // ------------------------------------------------------------------ K2: pyramid level l from l-1
 // cv::resize(..., INTER_LINEAR_EXACT) restated: 8.8 fixed-point taps from host tables, 16-bit horizontal sums,
-// 32-bit vertical, (v + 32768) >> 16.  A workgroup makes a 64x16 output tile: the source window (<= 24 rows x
-// 96 bytes) is staged in LDS through coalesced dword loads, then each lane blends 4 consecutive output pixels
-// and stores them as one dword.  Taps with weight 0 may read one byte past the image: staged as 0, times 0.
-constexpr int RTW = 64, RTH = 64, RLW = 96, RLH = 84;   // big tiles: the launch is latency-bound, not ALU-bound
+// 32-bit vertical, (v + 32768) >> 16.  A workgroup makes a band of `rth` full output rows: the source rows it needs
+// are staged whole in LDS with 16-byte loads (every fetched cache line is used once; 64-px-wide windows measured
+// 2.7x over-fetch), then each lane blends 4 consecutive output pixels per task and stores them as one dword.
+// LDS is read as ALIGNED dwords and the two taps are cut out with v_alignbyte: adjacent byte reads get fused by
+// the compiler into misaligned ds_read_u16, which the LDS replays (measured: 5x slower kernel).
+// Taps with weight 0 may read one byte past the image: staged as 0 (or padding), times 0.
 __global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uint8_t* pyr,
-                                                const uint16_t* __restrict__ tab, int l) {
-  __shared__ __attribute__((aligned(16))) uint8_t t[RLH * RLW];
-  const int fi = blockIdx.z;
+                                                const uint32_t* __restrict__ tab, int l, int rth, int lds_rows) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t rt[];
+  const int fi = blockIdx.y;
   const OrbLevelInfo L = g.lv[l];
-  const int sh = g.lv[l - 1].h;
+  const int sh = g.lv[l - 1].h, sw16 = (g.lv[l - 1].w + 16 + 15) & ~15;   // staged row: source width + 16 zero/pad bytes
   int spitch;
   const uint8_t* s = level_ptr(g, src, pyr, fi, l - 1, &spitch);
   uint8_t* d = pyr + (long long)(src.slot0 + fi) * g.pyr_bytes + L.pix_off;
-  const uint16_t* xofs = tab + L.tab_off;
-  const uint16_t* xw = xofs + L.w;
-  const uint16_t* yofs = xw + L.w;
-  const uint16_t* yw = yofs + L.h;
-  const int X0 = blockIdx.x * RTW, Y0 = blockIdx.y * RTH, tid = threadIdx.x;
-  const int sx0 = xofs[X0] & ~3, sy0 = yofs[Y0];
-  const int nrow = yofs[min(Y0 + RTH - 1, L.h - 1)] + 2 - sy0;   // <= RLH for any 1.2x level pair
-  for (int i = tid; i < RLH * (RLW / 4); i += 256) {
-    const int r = i / (RLW / 4), c = i % (RLW / 4);
-    if (r >= nrow) break;
-    const int gx = sx0 + 4 * c, gy = sy0 + r;
-    uint32_t v = 0;
-    if (gy < sh && gx + 4 <= spitch) v = *reinterpret_cast<const uint32_t*>(s + (long long)gy * spitch + gx);
-    reinterpret_cast<uint32_t*>(t)[i] = v;
+  const uint32_t* xtab = tab + L.tab_off;      // per x: xofs | w1 << 16
+  const uint32_t* ytab = xtab + ((L.w + 3) & ~3);
+  const int Y0 = blockIdx.x * rth, tid = threadIdx.x;
+  const int ylast = min(Y0 + rth, L.h) - 1;
+  const int sy0 = ytab[Y0] & 0xFFFF;
+  const int nrow = min((int)(ytab[ylast] & 0xFFFF) + 2 - sy0, lds_rows);
+  const int n16 = sw16 >> 4;
+  for (int i = tid; i < nrow * n16; i += 256) {
+    const int r = i / n16, c = i - r * n16;
+    const int gx = 16 * c, gy = sy0 + r;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (gy < sh && gx + 16 <= spitch) v = *reinterpret_cast<const uint4*>(s + (long long)gy * spitch + gx);
+    reinterpret_cast<uint4*>(rt)[i] = v;
   }
   __syncthreads();
-  const int x4 = X0 + 4 * (tid & 15);
-  if (x4 >= L.w) return;
-  // LDS is read as ALIGNED dwords and the two taps are cut out with v_alignbyte: adjacent byte reads get fused
-  // by the compiler into misaligned ds_read_u16, which the LDS replays (measured: 5x slower kernel).
-  const uint32_t* T = reinterpret_cast<const uint32_t*>(t);
-  int wofs[4];
-  uint32_t bsh[4], wx1[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int x = min(x4 + i, L.w - 1);
-    const int cx = xofs[x] - sx0;
-    wofs[i] = cx >> 2;
-    bsh[i] = cx & 3;
-    wx1[i] = xw[x];
-  }
-  for (int y = Y0 + (tid >> 4); y < min(Y0 + RTH, L.h); y += 16) {
-    const uint32_t wy1 = yw[y], wy0 = 256u - wy1;
-    const int rbase = (yofs[y] - sy0) * (RLW / 4);
+  const uint32_t* T = reinterpret_cast<const uint32_t*>(rt);
+  const int n4 = sw16 >> 2, groups = (L.w + 3) >> 2, rows = ylast - Y0 + 1;
+  for (int i = tid; i < rows * groups; i += 256) {
+    const int ry = i / groups, gq = i - ry * groups;
+    const int y = Y0 + ry, x4 = 4 * gq;
+    const uint32_t yt = ytab[y];
+    const uint32_t wy1 = yt >> 16, wy0 = 256u - wy1;
+    const int rbase = ((int)(yt & 0xFFFF) - sy0) * n4;
+    const uint4 xt = *reinterpret_cast<const uint4*>(xtab + x4);   // table is padded to a multiple of 4 entries
+    const uint32_t xe[4] = {xt.x, xt.y, xt.z, xt.w};
     uint32_t packed = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int w0i = rbase + wofs[i];
-      const uint32_t a = __builtin_amdgcn_alignbyte(T[w0i + 1], T[w0i], bsh[i]);                       // row sy:   p[cx], p[cx+1]
-      const uint32_t c = __builtin_amdgcn_alignbyte(T[w0i + RLW / 4 + 1], T[w0i + RLW / 4], bsh[i]);   // row sy+1
-      const uint32_t wx0 = 256u - wx1[i];
-      const uint32_t h0 = wx0 * (a & 0xFFu) + wx1[i] * ((a >> 8) & 0xFFu);
-      const uint32_t h1 = wx0 * (c & 0xFFu) + wx1[i] * ((c >> 8) & 0xFFu);
+    for (int k = 0; k < 4; k++) {
+      const int cx = xe[k] & 0xFFFF;
+      const uint32_t wx1 = xe[k] >> 16, wx0 = 256u - wx1;
+      const int w0i = rbase + (cx >> 2);
+      const uint32_t a = __builtin_amdgcn_alignbyte(T[w0i + 1], T[w0i], cx & 3);            // row sy:   p[cx], p[cx+1]
+      const uint32_t c = __builtin_amdgcn_alignbyte(T[w0i + n4 + 1], T[w0i + n4], cx & 3);  // row sy+1
+      const uint32_t h0 = wx0 * (a & 0xFFu) + wx1 * ((a >> 8) & 0xFFu);
+      const uint32_t h1 = wx0 * (c & 0xFFu) + wx1 * ((c >> 8) & 0xFFu);
       uint32_t v = (h0 * wy0 + h1 * wy1 + 32768u) >> 16;
       v = v > 255u ? 255u : v;
-      packed |= v << (8 * i);
+      packed |= v << (8 * k);
     }
     *reinterpret_cast<uint32_t*>(d + (long long)y * L.pitch + x4) = packed;  // pitch % 16 == 0, pad bytes are never read as pixels
   }
@@ -184,14 +178,23 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
   __shared__ uint2 llist[kTileCandCap];
   __shared__ uint32_t nbd, lcount, gbase;   // nbd: brighter count (low 16) | darker count (high 16)
 
-  const int fi = blockIdx.y;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so workgroup b
+  // takes tile start(b % 8) + b / 8 of the flattened (frame, tile) list: one XCD walks one contiguous run of tiles and
+  // the cache lines neighbouring tiles share are fetched into one L2 instead of eight.  Speed only, any placement works.
+  int G;
+  {
+    const uint32_t total = gridDim.x, lin = blockIdx.x;
+    const uint32_t xcd = lin & 7u, q = total >> 3, r = total & 7u;
+    G = (int)(xcd * q + (xcd < r ? xcd : r) + (lin >> 3));
+  }
+  const int fi = G / g.total_tiles, bt = G - fi * g.total_tiles;
   const int slot = src.slot0 + fi;
   int l = 0;
 #pragma unroll
   for (int i = 1; i < kOrbLevels; i++)
-    if (i < g.nlevels && (int)blockIdx.x >= g.lv[i].tile_base) l = i;
+    if (i < g.nlevels && bt >= g.lv[i].tile_base) l = i;
   const OrbLevelInfo L = g.lv[l];
-  const int t = blockIdx.x - L.tile_base;
+  const int t = bt - L.tile_base;
   const int x0 = (t % L.tiles_x) * TW, y0 = (t / L.tiles_x) * TH;
   int pitch;
   const uint8_t* img = level_ptr(g, src, pyr, fi, l, &pitch);
@@ -743,7 +746,7 @@ static int cv_round_f(float v) { return (int)lrintf(v); }
 static int cv_round_d(double v) { return (int)lrint(v); }
 
 // interpolationLinear<uchar>::getCoeffs (imgproc resize.cpp, INTER_LINEAR_EXACT)
-static void make_table(int src, int dst, uint16_t* ofs, uint16_t* w1) {
+static void make_table(int src, int dst, uint32_t* tab) {
   const double inv_scale = (double)dst / (double)src;
   const double scale = 1.0 / inv_scale;
   for (int d = 0; d < dst; d++) {
@@ -751,15 +754,12 @@ static void make_table(int src, int dst, uint16_t* ofs, uint16_t* w1) {
     const int i = (int)floor(f);
     if (i >= 0 && src > 1) {
       if (i < src - 1) {
-        ofs[d] = (uint16_t)i;
-        w1[d] = (uint16_t)cv_round_d((f - (double)i) * 256.0);
+        tab[d] = (uint32_t)i | ((uint32_t)cv_round_d((f - (double)i) * 256.0) << 16);
       } else {
-        ofs[d] = (uint16_t)(src - 1);
-        w1[d] = 0;
+        tab[d] = (uint32_t)(src - 1);   // replicate the last pixel: weight 0 on the (absent) right/bottom tap
       }
     } else {
-      ofs[d] = 0;
-      w1[d] = 0;
+      tab[d] = 0;                       // replicate the first pixel
     }
   }
 }
@@ -844,27 +844,25 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     L.tile_base = tiles;
     tiles += L.tiles_x * L.tiles_y;
     L.tab_off = tab;
-    if (l > 0) tab += 2 * L.w + 2 * L.h;
+    if (l > 0) tab += ((L.w + 3) & ~3) + ((L.h + 3) & ~3);
   }
   g.pyr_bytes = (pix + 255) & ~255ll;
   g.cand_total = cand;
   g.s1_total = s1;
   g.total_tiles = tiles;
 
-  std::vector<uint16_t> htab(tab > 0 ? tab : 1);
+  std::vector<uint32_t> htab(tab > 0 ? tab : 1, 0u);
   for (int l = 1; l < g.nlevels; l++) {
     const OrbLevelInfo& L = g.lv[l];
-    uint16_t* xofs = htab.data() + L.tab_off;
-    uint16_t* xw = xofs + L.w;
-    uint16_t* yofs = xw + L.w;
-    uint16_t* yw = yofs + L.h;
-    make_table(g.lv[l - 1].w, L.w, xofs, xw);
-    make_table(g.lv[l - 1].h, L.h, yofs, yw);
+    uint32_t* xt = htab.data() + L.tab_off;
+    uint32_t* yt = xt + ((L.w + 3) & ~3);
+    make_table(g.lv[l - 1].w, L.w, xt);
+    make_table(g.lv[l - 1].h, L.h, yt);
   }
   const size_t S = (size_t)max_slots;
   MSF_HIP_TRY(hipMalloc(&d_pyr_, S * g.pyr_bytes));
-  MSF_HIP_TRY(hipMalloc(&d_tab_, htab.size() * sizeof(uint16_t)));
-  MSF_HIP_TRY(hipMemcpy(d_tab_, htab.data(), htab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  MSF_HIP_TRY(hipMalloc(&d_tab_, htab.size() * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMemcpy(d_tab_, htab.data(), htab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   MSF_HIP_TRY(hipMalloc(&d_cand_cnt_, S * kOrbLevels * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMalloc(&d_cand_, S * g.cand_total * sizeof(uint2)));
   MSF_HIP_TRY(hipMalloc(&d_s1_cnt_, S * kOrbLevels * sizeof(uint32_t)));
@@ -897,11 +895,16 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
   if (ev_ok_) hipEventRecord(ev_[0], st);
   for (int l = 1; l < g.nlevels; l++) {
     const OrbLevelInfo& L = g.lv[l];
-    dim3 grid((L.w + RTW - 1) / RTW, (L.h + RTH - 1) / RTH, n);
-    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, g, src, d_pyr_, d_tab_, l);
+    // band height: as many output rows as keep the staged source rows within 60 KB of LDS
+    const int sw16 = (g.lv[l - 1].w + 16 + 15) & ~15;
+    int rth = 16;
+    while (rth > 1 && ((rth * 5 + 3) / 4 + 3) * sw16 > 60000) rth >>= 1;
+    const int lds_rows = (rth * 5 + 3) / 4 + 3;
+    hipLaunchKernelGGL(k_resize, dim3((L.h + rth - 1) / rth, n), dim3(256), (size_t)lds_rows * sw16, st, g, src, d_pyr_,
+                       d_tab_, l, rth, lds_rows);
   }
   if (ev_ok_) hipEventRecord(ev_[1], st);
-  hipLaunchKernelGGL(k_fast, dim3(g.total_tiles, n), dim3(kFastThreads), 0, st, g, src, d_pyr_, d_cand_cnt_, d_cand_);
+  hipLaunchKernelGGL(k_fast, dim3((unsigned)g.total_tiles * (unsigned)n), dim3(kFastThreads), 0, st, g, src, d_pyr_, d_cand_cnt_, d_cand_);
   if (ev_ok_) hipEventRecord(ev_[2], st);
   hipLaunchKernelGGL(k_thr_harris, dim3(g.nlevels, n), dim3(256), 0, st, g, src, d_pyr_, d_cand_cnt_, d_cand_,
                      d_s1_cnt_, d_s1_, d_status_);

@@ -78,7 +78,7 @@ class OrbPipeline {
   bool half_up_ = false, profile_ = false;
   // device storage
   uint8_t* d_pyr_ = nullptr;
-  uint16_t* d_tab_ = nullptr;      // resize tables
+  uint32_t* d_tab_ = nullptr;      // resize tables: per output x / y, source offset | w1 << 16
   uint32_t* d_cand_cnt_ = nullptr; // [slots][8]
   uint2* d_cand_ = nullptr;        // [slots][cand_total] (key, score)
   uint32_t* d_s1_cnt_ = nullptr;   // [slots][8]

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence bench.py's numbers are checked against (run on the GPU box via gpurun):
+#   1. --kernel-trace --stats of the default ORB bench and of the LoFTR bench leg
+#   2. HBM traffic counters of the same commands, in separate --pmc passes (FETCH_SIZE / WRITE_SIZE cannot share a pass)
+# Outputs land under gpurun_out/prof_<tag>/ ; tools/pmc_summary.py + tools/make_traffic_json.py digest them.
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-r01}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp
+ORB="--steps 5 --warmup 1 --no-cpu-baseline"
+LOF="--matcher loftr --steps 5 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/orb_stats -- python3 $R/bench.py $ORB > $OUT/orb_stats.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/loftr_stats -- python3 $R/bench.py $LOF > $OUT/loftr_stats.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/orb_fetch -- python3 $R/bench.py $ORB > $OUT/orb_fetch.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/orb_write -- python3 $R/bench.py $ORB > $OUT/orb_write.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/loftr_fetch -- python3 $R/bench.py $LOF > $OUT/loftr_fetch.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/loftr_write -- python3 $R/bench.py $LOF > $OUT/loftr_write.log 2>&1 || exit 1
+echo collected
