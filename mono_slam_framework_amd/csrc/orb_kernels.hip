@@ -671,7 +671,7 @@ constexpr int kTrainChunk = 1024;  // train descriptors staged per LDS pass (32 
 __global__ __launch_bounds__(256) void k_match(int n_pairs, const int32_t* slot_a, const int32_t* slot_b,
                                                const msf_keypoint* kp, const uint32_t* kp_cnt, const uint8_t* desc,
                                                const uint32_t* status, float ratio, msf_match* out, int cap,
-                                               int32_t* n_out) {
+                                               int32_t* n_out, int chunk) {
   __shared__ __attribute__((aligned(16))) unsigned long long train[kTrainChunk * 4];
   __shared__ uint32_t wave_cnt[4];
   __shared__ uint32_t running;
@@ -699,8 +699,8 @@ __global__ __launch_bounds__(256) void k_match(int n_pairs, const int32_t* slot_
       q0w = qd[0]; q1w = qd[1]; q2w = qd[2]; q3w = qd[3];
     }
     int d0 = 0x7fffffff, d1 = 0x7fffffff, i0 = -1;
-    for (uint32_t t0 = 0; t0 < n2; t0 += kTrainChunk) {
-      const uint32_t tn = min(n2 - t0, (uint32_t)kTrainChunk);
+    for (uint32_t t0 = 0; t0 < n2; t0 += chunk) {
+      const uint32_t tn = min(n2 - t0, (uint32_t)chunk);
       __syncthreads();
       for (uint32_t i = tid; i < tn * 4; i += 256) train[i] = tsrc[(size_t)t0 * 4 + i];
       __syncthreads();
@@ -920,8 +920,15 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
 hipError_t OrbPipeline::match(int n_pairs, const int32_t* d_slot_a, const int32_t* d_slot_b, float ratio,
                               msf_match* d_out, int cap, int32_t* d_n_out, hipStream_t st) {
   if (n_pairs <= 0) return hipSuccess;
+  // train descriptors go through LDS in chunks of kTrainChunk; MSF_ORB_TRAIN_CHUNK shrinks the chunk so tests can
+  // exercise the multi-chunk path with ordinary keypoint counts
+  static const int chunk = [] {
+    const char* e = getenv("MSF_ORB_TRAIN_CHUNK");
+    const int v = e ? atoi(e) : kTrainChunk;
+    return v >= 16 && v <= kTrainChunk ? v : kTrainChunk;
+  }();
   hipLaunchKernelGGL(k_match, dim3(n_pairs), dim3(256), 0, st, n_pairs, d_slot_a, d_slot_b, d_kp_, d_kp_cnt_,
-                     d_desc_, d_status_, ratio, d_out, cap, d_n_out);
+                     d_desc_, d_status_, ratio, d_out, cap, d_n_out, chunk);
   if (ev_ok_) {
     hipEventRecord(ev_[5], st);
     ev_recorded_ = true;

@@ -1,5 +1,7 @@
 """GPU parity tests for the ORB path: every stage of the HIP pipeline against the CPU oracle (bit-exact),
 called through the C ABI (include/msf_abi.h).  Reference path: src/featurematcher.cpp:10-45."""
+import os
+
 import numpy as np
 import pytest
 
@@ -7,6 +9,7 @@ from mono_slam_framework_amd import synth
 from oracle import orb as oracle_orb
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _matcher(w, h, thr=0.8, pairs=1, flags=0):
@@ -158,3 +161,53 @@ def test_errors_are_loud():
         fm.MatchFrames(np.zeros((100, 100), np.uint8), np.zeros((100, 100), np.uint8))
     with pytest.raises(MsfError):
         _matcher(16, 16)
+
+
+def _adversarial_images(w, h):
+    y, x = np.mgrid[0:h, 0:w]
+    chk = (((x // 2) + (y // 2)) % 2 * 200 + 20).astype(np.uint8)             # 2x2 checkerboard: dense corners
+    dots = np.full((h, w), 30, np.uint8)
+    dots[::4, ::4] = 250                                                       # isolated bright dots every 4 px
+    rng = np.random.default_rng(5)
+    salt = (rng.random((h, w)) < 0.08).astype(np.uint8) * 220 + 10             # salt noise
+    return [("checker2", chk), ("dots4", dots), ("salt", salt)]
+
+
+@pytest.mark.parametrize("name,img", _adversarial_images(640, 480), ids=["checker2", "dots4", "salt"])
+def test_adversarial_density_is_exact_or_loud(name, img):
+    """Fixed-capacity device lists may overflow on pathological inputs; then the call must fail loudly
+    (MSF_ERR_CAPACITY), otherwise the result must still be bit-exact."""
+    from mono_slam_framework_amd.matcher import MsfError
+    img2 = np.roll(img, (3, 5), (0, 1))
+    fm = _matcher(640, 480)
+    orc = oracle_orb.FeatureMatcherOracle(0.8)
+    exp = orc.MatchFrames(img, img2)
+    try:
+        got = fm.MatchFrames(img, img2)
+    except MsfError as e:
+        assert e.code == -4
+        return
+    np.testing.assert_array_equal(got, exp)
+    (k1, _), (k2, _) = orc.extract_both(img, img2)
+    assert len(fm.keypoints(0)) == len(k1) and len(fm.keypoints(1)) == len(k2)
+
+
+def test_chunked_match_path():
+    """k_match stages train descriptors through LDS in chunks (1024 by default, reached only with heavy ties);
+    a child process shrinks the chunk so ~500 keypoints cross several chunks, and must still be bit-exact."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from mono_slam_framework_amd import synth\n"
+        "from mono_slam_framework_amd.matcher import FeatureMatcher\n"
+        "from oracle import orb\n"
+        "a, b = synth.synth_pair(21, 640, 480)\n"
+        "got = FeatureMatcher(0.8, 640, 480).MatchFrames(a, b)\n"
+        "exp = orb.FeatureMatcherOracle(0.8).MatchFrames(a, b)\n"
+        "assert len(exp) > 100 and np.array_equal(got, exp)\n"
+    ) % ROOT
+    env = dict(os.environ, MSF_ORB_TRAIN_CHUNK="96")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
