@@ -29,53 +29,73 @@ constexpr int MASK_WORDS = 38;  // ceil(1200 / 32)
 // ------------------------------------------------------------------ convolution (implicit GEMM, f32 MFMA)
 // D[16 px][16 cout] += A[16 px][4 k] * B[4 k][16 cout]; k enumerates (ky, kx, cin) with cin fastest.
 // Block = 4 waves; wave w computes output row oy0 + w, OTW pixels wide, all output channels.
-template <int CIN, int COUT, int KS, int S, int OTW, bool RELU, bool RES, bool U8IN>
+// RP = 2 ("row packing", for COUT = 8): the 16 MFMA columns carry 8 output channels of TWO adjacent output rows; k then
+// spans KS + 1 input rows, with zero weights where a row does not contribute (75 % useful MFMA work instead of 50 %).
+template <int CIN, int COUT, int KS, int S, int OTW, bool RELU, bool RES, bool U8IN, int RP = 1>
 struct ConvCfg {
-  static constexpr int OTH = 4;
+  static_assert(RP == 1 || (RP == 2 && S == 1 && COUT * RP <= 16), "row packing: stride 1, 2 * COUT <= 16");
+  static constexpr int OTH = 4 * RP;
   static constexpr int MT = OTW / 16;
-  static constexpr int NT = (COUT + 15) / 16;
+  static constexpr int NT = (COUT * RP + 15) / 16;
   static constexpr int NPAD = NT * 16;
   static constexpr int PAD = KS / 2;
+  static constexpr int KY = KS + RP - 1;            // input rows spanned by one MFMA column group
   static constexpr int IN_H = (OTH - 1) * S + KS;
   static constexpr int IN_W = (OTW - 1) * S + KS;
-  static constexpr int PITCH = IN_W + 1;
+  // the tile is staged with 16-byte global loads: its first column is the 4-float-aligned x just left of the
+  // window (ox0 * S is a multiple of 16), XO = floats between that column and the window's first column
+  static constexpr int XO = PAD ? 4 - PAD : 0;
+  static constexpr int W4 = (IN_W + XO + 3) / 4;     // float4 per tile row
+  static constexpr int PITCH = 4 * W4;
   // plane stride: == 16 (mod 32) for stride 1, odd for stride 2, so the 16 px x 2 k lanes of a
   // ds_read_b32 group hit 32 distinct banks
   static constexpr int RAW = IN_H * PITCH;
   static constexpr int PLANE = S == 1 ? ((RAW + 15) / 32) * 32 + 16 : (RAW | 1);
-  static constexpr int KTOT = KS * KS * CIN;
+  static constexpr int KTOT = KY * KS * CIN;
   static constexpr int KSTEPS = (KTOT + 3) / 4;
+  static constexpr int G = KSTEPS >= 4 ? 4 : KSTEPS;   // k steps per weight-prefetch group
+  static constexpr int NG = (KSTEPS + G - 1) / G;
 };
 
-template <int CIN, int COUT, int KS, int S, int OTW, bool RELU, bool RES, bool U8IN>
+template <int CIN, int COUT, int KS, int S, int OTW, bool RELU, bool RES, bool U8IN, int RP = 1>
 __global__ __launch_bounds__(256) void k_conv(const void* __restrict__ in_, long long in_img_stride, int in_row_stride,
                                               const float* __restrict__ wB, const float* __restrict__ bias,
                                               const float* __restrict__ res, float* __restrict__ out, int Hin, int Win,
                                               int Hout, int Wout) {
-  using C = ConvCfg<CIN, COUT, KS, S, OTW, RELU, RES, U8IN>;
+  using C = ConvCfg<CIN, COUT, KS, S, OTW, RELU, RES, U8IN, RP>;
   extern __shared__ __attribute__((aligned(16))) float tile[];
   const int img = blockIdx.z;
   const int ox0 = blockIdx.x * OTW, oy0 = blockIdx.y * C::OTH;
   const int ix0 = ox0 * S - C::PAD, iy0 = oy0 * S - C::PAD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-  // stage the input tile (zero padding outside the image)
-  for (int idx = tid; idx < CIN * C::IN_H * C::IN_W; idx += 256) {
-    const int c = idx / (C::IN_H * C::IN_W);
-    const int rem = idx - c * (C::IN_H * C::IN_W);
-    const int r = rem / C::IN_W, x = rem - r * C::IN_W;
-    const int gy = iy0 + r, gx = ix0 + x;
-    float v = 0.f;
-    if (gy >= 0 && gy < Hin && gx >= 0 && gx < Win) {
+  // stage the input tile (zero padding outside the image): one 16-byte global load per 4 columns.  Image widths
+  // are multiples of 4, so a group is either wholly inside or wholly outside the row.
+  const int gx0 = ix0 - C::XO;
+  for (int idx = tid; idx < CIN * C::IN_H * C::W4; idx += 256) {
+    const int c = idx / (C::IN_H * C::W4);
+    const int rem = idx - c * (C::IN_H * C::W4);
+    const int r = rem / C::W4, x4 = rem - r * C::W4;
+    const int gy = iy0 + r, gx = gx0 + 4 * x4;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (gy >= 0 && gy < Hin && gx >= 0 && gx + 4 <= Win) {
       if (U8IN) {
         const uint8_t* p = static_cast<const uint8_t*>(in_) + (long long)img * in_img_stride;
-        v = (float)p[(long long)gy * in_row_stride + gx] * (float)(1.0 / 255.0);  // ConvertImageToFloat
+        const uint32_t q = *reinterpret_cast<const uint32_t*>(p + (long long)gy * in_row_stride + gx);
+        const float k255 = (float)(1.0 / 255.0);                                   // ConvertImageToFloat
+        v = f32x4{(float)(q & 0xFFu) * k255, (float)((q >> 8) & 0xFFu) * k255, (float)((q >> 16) & 0xFFu) * k255,
+                  (float)(q >> 24) * k255};
       } else {
         const float* p = static_cast<const float*>(in_) + (long long)img * in_img_stride;
-        v = p[((long long)c * Hin + gy) * Win + gx];
+        v = *reinterpret_cast<const f32x4*>(p + ((long long)c * Hin + gy) * Win + gx);
       }
     }
-    tile[c * C::PLANE + r * C::PITCH + x] = v;
+    float* t = &tile[c * C::PLANE + r * C::PITCH + 4 * x4];
+    if (S == 1) {
+      *reinterpret_cast<f32x4*>(t) = v;        // PLANE and PITCH are multiples of 4 here
+    } else {
+      t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;   // odd plane stride: scalar LDS writes
+    }
   }
   __syncthreads();
 
@@ -86,37 +106,60 @@ __global__ __launch_bounds__(256) void k_conv(const void* __restrict__ in_, long
 #pragma unroll
     for (int n = 0; n < C::NT; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int step = 0; step < C::KSTEPS; step++) {
-    int a_off;
-    if (CIN % 4 == 0) {
-      const int kk = (step * 4) / CIN;           // (ky, kx) shared by the 4 k of this step
-      const int c = (step * 4) % CIN + kq;
-      const int ky = kk / KS, kx = kk - ky * KS;
-      a_off = c * C::PLANE + (wave * S + ky) * C::PITCH + kx;
-    } else {                                      // stem: CIN = 1, k = ky * KS + kx, padded with zero weights
-      int k = step * 4 + kq;
-      k = k < C::KTOT ? k : C::KTOT - 1;
-      const int ky = k / KS, kx = k - ky * KS;
-      a_off = (wave * S + ky) * C::PITCH + kx;
+  // k loop in groups of G steps with the weight fragments of the NEXT group in flight while this group's MFMAs run
+  // (the weights come straight from global/L1: without the prefetch every MFMA waited on a load issued one MFMA
+  // earlier).  The host pads the packed weights with zero rows up to a whole number of groups.
+  constexpr int G = C::G, NG = C::NG;
+  float bcur[G][C::NT], bnext[G][C::NT];
+#pragma unroll
+  for (int j = 0; j < G; j++)
+#pragma unroll
+    for (int n = 0; n < C::NT; n++) bcur[j][n] = wB[(j * 4 + kq) * C::NPAD + n * 16 + i];
+  for (int grp = 0; grp < NG; grp++) {
+    if (grp + 1 < NG) {
+#pragma unroll
+      for (int j = 0; j < G; j++)
+#pragma unroll
+        for (int n = 0; n < C::NT; n++) bnext[j][n] = wB[(((grp + 1) * G + j) * 4 + kq) * C::NPAD + n * 16 + i];
     }
-    float a[C::MT], b[C::NT];
 #pragma unroll
-    for (int m = 0; m < C::MT; m++) a[m] = tile[a_off + (m * 16 + i) * S];
+    for (int j = 0; j < G; j++) {
+      int step = grp * G + j;
+      step = step < C::KSTEPS ? step : 0;        // padded steps: any valid tile address, the weights are zero
+      int a_off;
+      if (CIN % 4 == 0) {
+        const int kk = (step * 4) / CIN;           // (ky, kx) shared by the 4 k of this step
+        const int c = (step * 4) % CIN + kq;
+        const int ky = kk / KS, kx = kk - ky * KS;
+        a_off = c * C::PLANE + (wave * RP * S + ky) * C::PITCH + kx + C::XO;
+      } else {                                      // stem: CIN = 1, k = ky * KS + kx, padded with zero weights
+        int k = step * 4 + kq;
+        k = k < C::KTOT ? k : C::KTOT - 1;
+        const int ky = k / KS, kx = k - ky * KS;
+        a_off = (wave * S + ky) * C::PITCH + kx + C::XO;
+      }
+      float av[C::MT];
 #pragma unroll
-    for (int n = 0; n < C::NT; n++) b[n] = wB[(step * 4 + kq) * C::NPAD + n * 16 + i];
+      for (int m = 0; m < C::MT; m++) av[m] = tile[a_off + (m * 16 + i) * S];
 #pragma unroll
-    for (int m = 0; m < C::MT; m++)
+      for (int m = 0; m < C::MT; m++)
 #pragma unroll
-      for (int n = 0; n < C::NT; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
+        for (int n = 0; n < C::NT; n++)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bcur[j][n], acc[m][n], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < G; j++)
+#pragma unroll
+      for (int n = 0; n < C::NT; n++) bcur[j][n] = bnext[j][n];
   }
 
   // epilogue: D[row = 4*(lane>>4) + r][col = lane & 15] -> out[img][cout][oy][4 consecutive px]
-  const int oy = oy0 + wave;
-  if (oy >= Hout) return;
 #pragma unroll
   for (int n = 0; n < C::NT; n++) {
-    const int co = n * 16 + i;
-    if (co >= COUT) continue;
+    const int col = n * 16 + i;
+    const int co = RP == 1 ? col : col % COUT;
+    const int oy = oy0 + wave * RP + (RP == 1 ? 0 : col / COUT);
+    if (col >= COUT * RP || oy >= Hout) continue;
     const float bv = bias ? bias[co] : 0.f;
 #pragma unroll
     for (int m = 0; m < C::MT; m++) {
@@ -489,6 +532,7 @@ __global__ __launch_bounds__(256) void k_decode(const uint32_t* __restrict__ mas
 struct ConvDesc {
   int cin, cout, ks, stride, hin, win, hout, wout;
   float* d_w = nullptr;   // [KSTEPS*4][NPAD]
+  float* d_w2 = nullptr;  // row-packed variant (RP = 2) for the 8 -> 8 layers
   float* d_b = nullptr;   // [cout] or null
 };
 
@@ -621,7 +665,8 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
     const auto* w = need(nm, (size_t)c.cout * c.cin * c.ks * c.ks);
     if (!w) return std::string("io: weights blob lacks ") + nm;
     const int ktot = c.ks * c.ks * c.cin, ksteps = (ktot + 3) / 4, npad = ((c.cout + 15) / 16) * 16;
-    std::vector<float> wb((size_t)ksteps * 4 * npad, 0.f);
+    const int grp = ksteps >= 4 ? 4 : ksteps, ksteps_pad = ((ksteps + grp - 1) / grp) * grp;   // = ConvCfg::NG * G
+    std::vector<float> wb((size_t)ksteps_pad * 4 * npad, 0.f);
     for (int co = 0; co < c.cout; co++)
       for (int ci = 0; ci < c.cin; ci++)
         for (int ky = 0; ky < c.ks; ky++)
@@ -630,6 +675,20 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
             wb[(size_t)k * npad + co] = (*w)[(((size_t)co * c.cin + ci) * c.ks + ky) * c.ks + kx];
           }
     LF_TRY(upload(wb, &c.d_w));
+    if (c.cin == 8 && c.cout == 8 && c.ks == 3 && c.stride == 1) {
+      // row-packed weights: k = ((ky4 * 3 + kx) * 8 + ci) over 4 input rows, column = row_sel * 8 + co
+      const int kt2 = 4 * 3 * 8, ks2 = kt2 / 4;   // 24 steps = 6 groups of 4
+      std::vector<float> w2((size_t)ks2 * 4 * 16, 0.f);
+      for (int rs = 0; rs < 2; rs++)
+        for (int co = 0; co < 8; co++)
+          for (int ci = 0; ci < 8; ci++)
+            for (int ky = 0; ky < 3; ky++)
+              for (int kx = 0; kx < 3; kx++) {
+                const int k = ((ky + rs) * 3 + kx) * 8 + ci;   // output row rs sees input rows rs .. rs+2
+                w2[(size_t)k * 16 + rs * 8 + co] = (*w)[(((size_t)co * 8 + ci) * 3 + ky) * 3 + kx];
+              }
+      LF_TRY(upload(w2, &c.d_w2));
+    }
     if (i < 20) {
       snprintf(nm, sizeof nm, "conv%02d.b", i);
       const auto* b = need(nm, c.cout);
@@ -715,22 +774,22 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
 
 namespace {
 
-template <int CIN, int COUT, int KS, int S, int OTW, bool RELU, bool RES, bool U8IN>
+template <int CIN, int COUT, int KS, int S, int OTW, bool RELU, bool RES, bool U8IN, int RP = 1>
 void launch_conv(const ConvDesc& c, const void* in, long long in_img_stride, int in_row_stride, const float* res,
                  float* out, int n_img, hipStream_t st) {
-  using C = ConvCfg<CIN, COUT, KS, S, OTW, RELU, RES, U8IN>;
+  using C = ConvCfg<CIN, COUT, KS, S, OTW, RELU, RES, U8IN, RP>;
   static_assert(S == 2 || (C::PLANE % 32) == 16, "plane stride must be 16 mod 32 for stride-1 convs");
   static_assert(C::PLANE >= C::RAW, "plane too small");
   const size_t lds = (size_t)CIN * C::PLANE * sizeof(float);
-  auto kern = k_conv<CIN, COUT, KS, S, OTW, RELU, RES, U8IN>;
+  auto kern = k_conv<CIN, COUT, KS, S, OTW, RELU, RES, U8IN, RP>;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid((c.wout + OTW - 1) / OTW, (c.hout + C::OTH - 1) / C::OTH, n_img);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, in, in_img_stride, in_row_stride, c.d_w, c.d_b, res, out, c.hin,
-                     c.win, c.hout, c.wout);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, in, in_img_stride, in_row_stride, RP == 2 ? c.d_w2 : c.d_w, c.d_b,
+                     res, out, c.hin, c.win, c.hout, c.wout);
 }
 
 }  // namespace
@@ -755,10 +814,10 @@ hipError_t LoftrPipeline::match(int n_pairs, const uint8_t* d_a, const uint8_t* 
     launch_conv<1, 8, 7, 2, 64, true, false, true>(c[0], d_a + (long long)p0 * frame_stride, frame_stride, row_stride, nullptr, a, n, st);
     launch_conv<1, 8, 7, 2, 64, true, false, true>(c[0], d_b + (long long)p0 * frame_stride, frame_stride, row_stride, nullptr, a + (long long)n * s8, n, st);
     // layer1 @240x320, 8 ch
-    launch_conv<8, 8, 3, 1, 64, true, false, false>(c[1], a, s8, 0, nullptr, b, ni, st);
-    launch_conv<8, 8, 3, 1, 64, true, true, false>(c[2], b, s8, 0, a, cc, ni, st);
-    launch_conv<8, 8, 3, 1, 64, true, false, false>(c[3], cc, s8, 0, nullptr, b, ni, st);
-    launch_conv<8, 8, 3, 1, 64, true, true, false>(c[4], b, s8, 0, cc, a, ni, st);                 // a = 196
+    launch_conv<8, 8, 3, 1, 64, true, false, false, 2>(c[1], a, s8, 0, nullptr, b, ni, st);
+    launch_conv<8, 8, 3, 1, 64, true, true, false, 2>(c[2], b, s8, 0, a, cc, ni, st);
+    launch_conv<8, 8, 3, 1, 64, true, false, false, 2>(c[3], cc, s8, 0, nullptr, b, ni, st);
+    launch_conv<8, 8, 3, 1, 64, true, true, false, 2>(c[4], b, s8, 0, cc, a, ni, st);                 // a = 196
     // layer2 @120x160, 16 ch
     const long long s16 = 16LL * 120 * 160;
     launch_conv<8, 16, 3, 2, 32, true, false, false>(c[5], a, s8, 0, nullptr, b, ni, st);
