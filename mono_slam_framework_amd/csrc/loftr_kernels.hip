@@ -645,7 +645,7 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
     P.allocs.push_back(*d);
     return hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
   };
-  // backbone, index = execution order used by oracle and fixtures
+  // backbone, index = execution order of the graph (and of the weight blob)
   const int spec[21][6] = {
       // cin cout ks stride hin win
       {1, 8, 7, 2, 480, 640},   {8, 8, 3, 1, 240, 320},   {8, 8, 3, 1, 240, 320},   {8, 8, 3, 1, 240, 320},

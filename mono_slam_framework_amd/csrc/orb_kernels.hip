@@ -115,6 +115,7 @@ __global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uin
 constexpr int HX = 16, HY = 4;                     // pixel-tile halo: rows start 16-byte aligned (x0 - 16)
 constexpr int PW2 = TW + 2 * HX, PH2 = TH + 2 * HY;  // 96 x 40
 constexpr int SCO = 4;                              // byte offset of the score tile inside its LDS array
+// the score tile has the pixel tile's geometry (pitch PW2, same origin): one index serves both arrays
 constexpr int GPR = 18;                            // 4-px groups per score row: tile x = 4g-4 .. 4g-1
 constexpr int kList1Cap = 2 * SW * SH;             // brighter-type survivors from the front, darker from the back
 constexpr uint32_t kLerpBright = 0x01010101u * (128 - kFastT / 2);  // L + K >= 256  <=>  L >= 128 + t/2
@@ -132,16 +133,24 @@ __device__ __forceinline__ int fast_score_pol(const uint8_t* p) {
   constexpr int off[16] = {3 * PW2 + 0,  3 * PW2 + 1,  2 * PW2 + 2,  1 * PW2 + 3,  0 * PW2 + 3, -1 * PW2 + 3,
                            -2 * PW2 + 2, -3 * PW2 + 1, -3 * PW2 + 0, -3 * PW2 - 1, -2 * PW2 - 2, -1 * PW2 - 3,
                            0 * PW2 - 3,  1 * PW2 - 3,  2 * PW2 - 2,  3 * PW2 - 1};
-  const int v = p[0];
-  int e[16];
+  // brighter: max over arcs of min(p - v) = (max over arcs of min p) - v ; darker: max of min(v - p) = v - (min of max p):
+  // the window networks run on the raw ring pixels and v is applied once at the end.
+  int q[16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) e[k] = BRIGHT ? (int)p[off[k]] - v : v - (int)p[off[k]];
+  for (int k = 0; k < 16; k++) q[k] = (int)p[off[k]];
   int m3[16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) m3[k] = min(min(e[k], e[(k + 1) & 15]), e[(k + 2) & 15]);
-  int A = -1000;
+  for (int k = 0; k < 16; k++)
+    m3[k] = BRIGHT ? min(min(q[k], q[(k + 1) & 15]), q[(k + 2) & 15]) : max(max(q[k], q[(k + 1) & 15]), q[(k + 2) & 15]);
+  int W = BRIGHT ? -1 : 1000;
 #pragma unroll
-  for (int k = 0; k < 16; k++) A = max(A, min(min(m3[k], m3[(k + 3) & 15]), m3[(k + 6) & 15]));   // arc k .. k+8
+  for (int k = 0; k < 16; k++) {   // arc k .. k+8
+    const int w9 = BRIGHT ? min(min(m3[k], m3[(k + 3) & 15]), m3[(k + 6) & 15])
+                          : max(max(m3[k], m3[(k + 3) & 15]), m3[(k + 6) & 15]);
+    W = BRIGHT ? max(W, w9) : min(W, w9);
+  }
+  const int v = p[0];
+  const int A = BRIGHT ? W - v : v - W;
   return A > kFastT ? A - 1 : 0;   // = max(t, A, B) - 1 for corners, 0 otherwise
 }
 
@@ -173,7 +182,7 @@ constexpr int kFastThreads = 256;   // 320 (two full prefilter passes) measured 
 __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
                                                        uint32_t* cand_cnt, uint2* cand) {
   __shared__ __attribute__((aligned(16))) uint8_t px[PW2 * PH2];
-  __shared__ __attribute__((aligned(16))) uint8_t sc[SP * SH + 2 * SCO];   // one dword of slack either side
+  __shared__ __attribute__((aligned(16))) uint8_t sc[PW2 * PH2 + 2 * SCO];   // one dword of slack either side
   __shared__ uint16_t list1[kList1Cap];
   __shared__ uint2 llist[kTileCandCap];
   __shared__ uint32_t nbd, lcount, gbase;   // nbd: brighter count (low 16) | darker count (high 16)
@@ -211,7 +220,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
       v = *reinterpret_cast<const uint4*>(img + (long long)gy * pitch + gx);
     reinterpret_cast<uint4*>(px)[i] = v;
   }
-  for (int i = tid; i < (SP * SH + 2 * SCO) / 4; i += kFastThreads) reinterpret_cast<uint32_t*>(sc)[i] = 0;
+  for (int i = tid; i < (PW2 * PH2 + 2 * SCO) / 4; i += kFastThreads) reinterpret_cast<uint32_t*>(sc)[i] = 0;
   __syncthreads();
 
   // phase 1: cardinal prefilter on 4 px per lane
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
     const uint32_t cb = ((b0 | b8) & (b4 | b12)) & vm;
     const uint32_t cd = ~((n0 & n8) | (n4 & n12)) & vm;
     if (__ballot((cb | cd) != 0u) == 0ull) continue;   // flat region: nothing to append for this wave
-    const uint32_t e0 = (uint32_t)(sr * SP + tx0 + 1);
+    const uint32_t e0 = (uint32_t)b << 2;   // byte index of the group's first pixel in the pixel / score tile
     // lane order = x order, so phase 2's LDS reads stay bank-friendly
     const uint32_t slots = reserve_packed(__popc(cb) | (__popc(cd) << 16), &nbd, lane);
     uint32_t k = slots & 0xFFFFu;
@@ -267,38 +276,35 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
   const uint32_t mb = nbd & 0xFFFFu, md = nbd >> 16;
   for (uint32_t i = tid; i < mb; i += kFastThreads) {
     const int e = list1[i];
-    const int sy = e / SP, sx = e - sy * SP;
-    const int s = fast_score_pol<true>(&px[(sy - 1 + HY) * PW2 + (sx - 1 + HX)]);
+    const int s = fast_score_pol<true>(&px[e]);
     if (s) sc[SCO + e] = (uint8_t)s;
   }
   for (uint32_t i = tid; i < md; i += kFastThreads) {
     const int e = list1[kList1Cap - 1 - i];
-    const int sy = e / SP, sx = e - sy * SP;
-    const int s = fast_score_pol<false>(&px[(sy - 1 + HY) * PW2 + (sx - 1 + HX)]);
+    const int s = fast_score_pol<false>(&px[e]);
     if (s) sc[SCO + e] = (uint8_t)s;
   }
   __syncthreads();
 
   // phase 3: strict 3x3 NMS + runByImageBorder(31), dense on 4 scores per lane: "c > n" per byte is bit 7 of
-  // lerp(c, ~n) = (c + 255 - n) >> 1; non-corners hold 0 and can never be strictly greater.
+  // lerp(c, ~n) = (c + 255 - n) >> 1; non-corners hold 0 and can never be strictly greater.  The 64 x 32 outputs are
+  // exactly 16 x 32 dwords = two passes of the workgroup.
   {
     const uint32_t* S = reinterpret_cast<const uint32_t*>(sc) + SCO / 4;
-    // output columns sx = 1 .. TW that also pass the 31-px border: [sxlo, sxhi]
-    const int sxlo = max(1, kEdge - x0 + 1), sxhi = min(TW, L.w - kEdge - x0);
-    for (int i0 = 0; i0 < (SP / 4) * TH; i0 += kFastThreads) {
-      const int i = i0 + tid;
-      const int ic = i < (SP / 4) * TH ? i : 0;
-      const int r = ic / (SP / 4) + 1, j = ic % (SP / 4);     // score row 1 .. TH, dword column
-      const int w = r * (SP / 4) + j;
+    constexpr int SPD = PW2 / 4;                                    // score-tile pitch in dwords
+    const int txlo3 = max(0, kEdge - x0), txhi3 = min(TW - 1, L.w - kEdge - 1 - x0);   // 31-px border
+    for (int i = tid; i < (TW / 4) * TH; i += kFastThreads) {
+      const int ty = i / (TW / 4), j = i % (TW / 4);
+      const int w = (ty + HY) * SPD + HX / 4 + j;
       const uint32_t C = S[w];
       uint32_t keep = 0;
-      const int gy = y0 + r - 1;
-      const bool live = i < (SP / 4) * TH && C != 0 && gy >= kEdge && gy < L.h - kEdge;
+      const int gy = y0 + ty;
+      const bool live = C != 0 && gy >= kEdge && gy < L.h - kEdge;
       if (__ballot(live) == 0ull) continue;              // no corner in these 256 score columns
       if (live) {
         const uint32_t Cl = S[w - 1], Cr = S[w + 1];
-        const uint32_t U = S[w - SP / 4], Ul = S[w - SP / 4 - 1], Ur = S[w - SP / 4 + 1];
-        const uint32_t D = S[w + SP / 4], Dl = S[w + SP / 4 - 1], Dr = S[w + SP / 4 + 1];
+        const uint32_t U = S[w - SPD], Ul = S[w - SPD - 1], Ur = S[w - SPD + 1];
+        const uint32_t D = S[w + SPD], Dl = S[w + SPD - 1], Dr = S[w + SPD + 1];
         keep = __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(C, Cl, 3), 0);
         keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(Cr, C, 1), 0);
         keep &= __builtin_amdgcn_lerp(C, ~U, 0);
@@ -307,14 +313,14 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
         keep &= __builtin_amdgcn_lerp(C, ~D, 0);
         keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(D, Dl, 3), 0);
         keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(Dr, D, 1), 0);
-        int first = sxlo - 4 * j, last = sxhi - 4 * j;
+        int first = txlo3 - 4 * j, last = txhi3 - 4 * j;
         first = first < 0 ? 0 : first;
         last = last > 3 ? 3 : last;
         keep &= first <= last ? (0x80808080u << (8 * first)) & (0x80808080u >> (8 * (3 - last))) : 0u;
       }
       const uint32_t mine = __popc(keep);
       uint32_t k = reserve_packed(mine, &lcount, lane);
-      const uint32_t key = ((uint32_t)gy << 16) | (uint32_t)(x0 + 4 * j - 1);
+      const uint32_t key = ((uint32_t)gy << 16) | (uint32_t)(x0 + 4 * j);
       if (keep & 0x80u) llist[k++] = make_uint2(key, C & 0xFFu);
       if (keep & 0x8000u) llist[k++] = make_uint2(key + 1, (C >> 8) & 0xFFu);
       if (keep & 0x800000u) llist[k++] = make_uint2(key + 2, (C >> 16) & 0xFFu);
