@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--cpu-loftr-pairs", type=int, default=8)
     ap.add_argument("--threshold", type=float, default=0.15, help="LoFTR confidence threshold (dnnfeaturematcher.h:11)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the measured configuration); gloo = rehearsal of the N > 1 code path "
+                         "on a box with fewer GPUs than ranks (all ranks share cuda:0, results staged through host)")
     args = ap.parse_args()
 
     import numpy as np
@@ -105,11 +108,17 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")   # where the collective's tensors live
 
     from mono_slam_framework_amd import _lib, synth
     from mono_slam_framework_amd.matcher import DNNFeatureMatcher, FeatureMatcher
@@ -135,7 +144,7 @@ def main():
     offs = torch.zeros((P + 1,), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     from mono_slam_framework_amd.gather import MatchListGather
-    gather = MatchListGather(P, dev) if world > 1 else None
+    gather = MatchListGather(P, cdev) if world > 1 else None
     stage_acc = {}
     gathered = [0]
 
@@ -145,7 +154,7 @@ def main():
         if gather is not None:
             # gather of variable-length match lists to rank 0 (all-gather of offsets, then exact-size
             # ncclSend/ncclRecv over xGMI); no all-reduce in the data path
-            res = gather(packed, offs)
+            res = gather(packed.to(cdev), offs.to(cdev))
             if res is not None:
                 gathered[0] = sum(int(r[0].shape[0]) for r in res)
         if timed:
@@ -166,7 +175,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)   # timing only, outside the timed region
         dt = float(tmax.item())
 
@@ -184,8 +193,16 @@ def main():
             # dominant "kernel" = the 22-launch convolution stack (k_conv<...>) of one call
             flops = P * (LOFTR_CONV_FLOPS_PER_PAIR if dom == "backbone_convs" else LOFTR_FLOPS_PER_PAIR)
             achieved = flops / (stages[dom] * 1e-3) / 1e12
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "traffic_loftr.json")
+            if os.path.exists(tfile):
+                try:
+                    tj = json.load(open(tfile))
+                    traffic = tj.get(dom) if tj.get("_pairs_per_gpu") == P else None
+                except Exception:
+                    traffic = None
             roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 5), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 5), "traffic": traffic,
                         "avg_launch_ms": round(stages[dom], 4), "algorithmic_flops_per_launch": flops,
                         "stage_ms": {k: round(v, 4) for k, v in stages.items()},
                         "pipeline_frac": round(value / world * LOFTR_FLOPS_PER_PAIR / 1e12 / MFMA_F32_PEAK_TFLOPS, 5)}
@@ -195,7 +212,8 @@ def main():
             tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.matcher)
             if os.path.exists(tfile):
                 try:
-                    traffic = json.load(open(tfile)).get(dom)
+                    tj = json.load(open(tfile))
+                    traffic = tj.get(dom) if tj.get("_pairs_per_gpu") == P else None   # measured at the same batch only
                 except Exception:
                     traffic = None
             roofline = {"bound": "hbm" if args.matcher == "orb" else "mfma", "kernel": dom,
@@ -205,6 +223,8 @@ def main():
                         "algorithmic_bytes_per_launch": P * bpp,
                         "stage_ms": {k: round(v, 4) for k, v in stages.items()},
                         "pipeline_frac": round(value / world * bpp / 1e9 / HBM_PEAK_GBS, 5)}
+        if world > 1:
+            assert gathered[0] > 0, "rank 0 gathered no match records"
         line = {
             "metric": "frame-pairs/sec (extract+match)", "value": round(value, 2), "unit": "frame-pairs/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -215,7 +235,9 @@ def main():
                                       "ratio %.2f" % args.ratio if args.matcher == "orb" else "conf threshold %.2f" % args.threshold),
                        "pairs_per_gpu": P, "width": W, "height": H, "synth_mode": mode,
                        "matches_per_pair_mean": round(float(np.mean([len(l) for l in lists])), 2),
-                       "overflow_pairs": int((cnt_h < 0).sum())},
+                       "overflow_pairs": int((cnt_h < 0).sum()),
+                       "gathered_match_records_per_step": gathered[0] if world > 1 else int(offs[P].item()),
+                       "collective_backend": args.backend if world > 1 else None},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline:

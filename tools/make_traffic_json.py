@@ -43,6 +43,7 @@ def main(tag="r01", steps=6):
                 stages[st]["write_kb"] += wk
         out = {s: int((2 * v["fetch_kb_raw"] + v["write_kb"]) * 1024) for s, v in stages.items()}
         out["_raw"] = {s: {"FETCH_SIZE_KB": v["fetch_kb_raw"], "WRITE_SIZE_KB": v["write_kb"]} for s, v in stages.items()}
+        out["_pairs_per_gpu"] = 1024 if which == "orb" else 256   # the bench defaults the passes were run with
         out["_note"] = "HBM bytes per bench step (launch of the stage): 2 * FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, " + tag
         json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_%s.json" % which), "w"), indent=1)
 
