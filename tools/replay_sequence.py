@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Config-5 harness (BASELINE.json configs[4]), call-pattern replay form.
+
+slam_pipeline itself needs OpenCV + g2o + PCL and cannot be built offline here, so this replays the SEQUENCE OF
+MatchFrames CALLS its tracking / mapping loop issues on a synthetic monocular sequence with known motion, through the
+plugged-in GPU matcher, and scores every match list against the ground-truth flow:
+
+  per frame        TrackWithMotionModel      MatchFrames(current, last)              Tracking.cc:444
+                   TrackReferenceKeyFrame    MatchFrames(current, refKF)             Tracking.cc:383
+                   SearchLocalPoints         MatchFrames(current, KF_i) for the local key frames   Tracking.cc:595-632
+  per new keyframe DetectLoopCandidate       MatchFrames(newKF, every KF in the DB)  KeyFrameDatabase.cc:31-50
+                   SearchInNeighbors         MatchFrames(newKF, covisible KFs)       LocalMapping.cc:325-358
+
+The one-vs-many loops go through the extract-once / match-many entry points (msf_extract_device +
+msf_match_slots_device); a sample of them is re-issued as plain MatchFrames calls and must give identical lists
+(the cache must be invisible).  The camera pans over a large synthetic canvas, so the true displacement between two
+frames is known exactly: a match is an inlier when it reproduces that displacement within `tol` pixels.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def make_canvas(w, h, seed=7):
+    """A big textured plane: blocky + smooth layers from the deterministic synthetic generator, tiled."""
+    from mono_slam_framework_amd import synth
+    tw, th = 1280, 720
+    nx, ny = (w + tw - 1) // tw, (h + th - 1) // th
+    canvas = np.zeros((ny * th, nx * tw), np.uint8)
+    k = 0
+    for j in range(ny):
+        for i in range(nx):
+            a, _ = synth.synth_pair(seed * 100 + k, tw, th, mode=2 if (i + j) % 2 else 1, noise=3)
+            canvas[j * th:(j + 1) * th, i * tw:(i + 1) * tw] = a
+            k += 1
+    return canvas[:h, :w]
+
+
+def camera_path(n, w, h, cw, ch):
+    """smooth pan: a few px per frame, staying inside the canvas"""
+    t = np.arange(n)
+    x = (cw - w) / 2 * (1 + 0.9 * np.sin(2 * np.pi * t / 400.0))
+    y = (ch - h) / 2 * (1 + 0.9 * np.sin(2 * np.pi * t / 650.0 + 1.0))
+    return np.round(x).astype(int), np.round(y).astype(int)
+
+
+def inlier_ratio(m, dx, dy, tol):
+    if len(m) == 0:
+        return 0.0, 0
+    d = m[:, 2:4] - m[:, 0:2]
+    ok = (np.abs(d[:, 0] - dx) <= tol) & (np.abs(d[:, 1] - dy) <= tol)
+    return float(ok.mean()), int(ok.sum())
+
+
+def replay(n_frames=1000, width=640, height=480, ratio=0.6, max_local=8, kf_every=12, max_overlap=0.5, tol=3,
+           check_every=25, verbose=False):
+    import torch
+    from mono_slam_framework_amd.matcher import FeatureMatcher
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda", 0)
+    canvas = make_canvas(width * 3, height * 3)
+    xs, ys = camera_path(n_frames, width, height, canvas.shape[1], canvas.shape[0])
+    n_slots = 2 + 64                       # slot 0 = current, 1 = last, 2.. = key frames (ring)
+    fm = FeatureMatcher(ratio, width, height, max_batch_pairs=n_slots // 2)
+    d_out = torch.zeros((64, 1024, 4), dtype=torch.int32, device=dev)
+    d_cnt = torch.zeros((64,), dtype=torch.int32, device=dev)
+    kfs = []                               # (frame index, slot)
+    stats = {"calls": 0, "matches": 0, "inliers": 0, "cache_checks": 0, "lost": 0, "keyframes": 0}
+    worst = 1.0
+    t0 = time.perf_counter()
+    frames = {}
+
+    def frame(i):
+        return np.ascontiguousarray(canvas[ys[i]:ys[i] + height, xs[i]:xs[i] + width])
+
+    def many(cur_slot, others):
+        """MatchFrames(cur, other_k) for all k in one launch over cached features"""
+        sa = torch.full((len(others),), cur_slot, dtype=torch.int32, device=dev)
+        sb = torch.tensor([s for _, s in others], dtype=torch.int32, device=dev)
+        fm.match_slots_device(sa, sb, d_out[:len(others)], d_cnt[:len(others)])
+        cnt = d_cnt[:len(others)].cpu().numpy()
+        out = d_out[:len(others)].cpu().numpy()
+        return [out[k, :cnt[k]] for k in range(len(others))]
+
+    for i in range(n_frames):
+        cur = frame(i)
+        frames[i] = cur
+        fm.extract_device(torch.from_numpy(cur[None]).to(dev), first_slot=0)      # features of the current frame, once
+        if i == 0:
+            fm.extract_device(torch.from_numpy(cur[None]).to(dev), first_slot=2)
+            kfs.append((0, 2))
+            stats["keyframes"] += 1
+            fm.extract_device(torch.from_numpy(cur[None]).to(dev), first_slot=1)
+            continue
+        # local key frames: the most recent ones that still overlap the view (SearchLocalPoints' frustum test)
+        local = [(f, s) for f, s in kfs[-max_local:]
+                 if abs(xs[f] - xs[i]) < width * (1 - max_overlap) and abs(ys[f] - ys[i]) < height * (1 - max_overlap)]
+        others = [(i - 1, 1)] + local       # TrackWithMotionModel + TrackReferenceKeyFrame/SearchLocalPoints
+        lists = many(0, others)
+        for (f, _), m in zip(others, lists):
+            r, k = inlier_ratio(m, xs[i] - xs[f], ys[i] - ys[f], tol)    # frame f is shifted by (x_i - x_f) w.r.t. current
+            stats["calls"] += 1
+            stats["matches"] += len(m)
+            stats["inliers"] += k
+            if len(m) >= 15:                # minLocalMatchCount (SlamParameters.h)
+                worst = min(worst, r)
+            else:
+                stats["lost"] += 1
+        if i % check_every == 0:            # the cache must be invisible: same lists as stateless MatchFrames calls
+            for (f, _), m in list(zip(others, lists))[:2]:
+                ref = fm.MatchFrames(cur, frames[f])
+                assert ref.shape == m.shape and np.array_equal(ref, m), "cached path differs from MatchFrames at frame %d" % i
+                stats["cache_checks"] += 1
+            fm.extract_device(torch.from_numpy(cur[None]).to(dev), first_slot=0)   # MatchFrames reused slots 0/1
+        # new key frame: DetectLoopCandidate + SearchInNeighbors = new KF against every KF in the DB
+        if i % kf_every == 0:
+            slot = 2 + (len(kfs) % 64)
+            fm.extract_device(torch.from_numpy(cur[None]).to(dev), first_slot=slot)
+            db = kfs[-63:]
+            for m, (f, _) in zip(many(slot, db), db):
+                stats["calls"] += 1
+                if abs(xs[f] - xs[i]) < width // 2 and abs(ys[f] - ys[i]) < height // 2 and len(m) >= 15:
+                    r, k = inlier_ratio(m, xs[i] - xs[f], ys[i] - ys[f], tol)
+                    stats["matches"] += len(m)
+                    stats["inliers"] += k
+                    worst = min(worst, r)
+            kfs.append((i, slot))
+            stats["keyframes"] += 1
+        fm.extract_device(torch.from_numpy(cur[None]).to(dev), first_slot=1)      # current becomes last
+        frames.pop(i - max(kf_every * 70, 2), None)
+        if verbose and i % 100 == 0:
+            print("frame %d: %d calls, inlier ratio %.4f" % (i, stats["calls"], stats["inliers"] / max(stats["matches"], 1)))
+    dt = time.perf_counter() - t0
+    stats.update({"frames": n_frames, "seconds": round(dt, 2), "frames_per_sec": round(n_frames / dt, 1),
+                  "match_calls_per_sec": round(stats["calls"] / dt, 1),
+                  "inlier_ratio": round(stats["inliers"] / max(stats["matches"], 1), 4), "worst_list_inlier_ratio": round(worst, 4)})
+    return stats
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+    print(json.dumps(replay(a.frames, verbose=a.verbose)))
