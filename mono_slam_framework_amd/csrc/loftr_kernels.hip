@@ -65,116 +65,152 @@ __global__ __launch_bounds__(256) void k_conv(const void* __restrict__ in_, long
   using C = ConvCfg<CIN, COUT, KS, S, OTW, RELU, RES, U8IN, RP>;
   extern __shared__ __attribute__((aligned(16))) float tile[];
   const int img = blockIdx.z;
-  const int ox0 = blockIdx.x * OTW, oy0 = blockIdx.y * C::OTH;
-  const int ix0 = ox0 * S - C::PAD, iy0 = oy0 * S - C::PAD;
+  const int oy0 = blockIdx.y * C::OTH;
+  const int iy0 = oy0 * S - C::PAD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
 
-  // stage the input tile (zero padding outside the image): one 16-byte global load per 4 columns.  Image widths
-  // are multiples of 4, so a group is either wholly inside or wholly outside the row.
-  const int gx0 = ix0 - C::XO;
-  for (int idx = tid; idx < CIN * C::IN_H * C::W4; idx += 256) {
+  // A workgroup walks all the x tiles of its row band.  The 16-byte global loads of tile t+1 are issued into
+  // registers before the MFMA loop of tile t and committed to LDS after it, so fetch latency, MFMAs and the
+  // epilogue stores of neighbouring tiles overlap (co-resident workgroups start together and would otherwise all
+  // load, then all compute: measured, the phases simply added up).
+  constexpr int TOTAL = CIN * C::IN_H * C::W4;          // float4 groups per tile
+  constexpr int NLD = (TOTAL + 255) / 256;
+  f32x4 pre[NLD];
+  int loff[NLD], x4v[NLD];
+  long long grow[NLD];                                  // element offset of the source row (or -1: outside the image)
+#pragma unroll
+  for (int u = 0; u < NLD; u++) {
+    const int idx = tid + 256 * u;
     const int c = idx / (C::IN_H * C::W4);
     const int rem = idx - c * (C::IN_H * C::W4);
-    const int r = rem / C::W4, x4 = rem - r * C::W4;
-    const int gy = iy0 + r, gx = gx0 + 4 * x4;
-    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (gy >= 0 && gy < Hin && gx >= 0 && gx + 4 <= Win) {
-      if (U8IN) {
-        const uint8_t* p = static_cast<const uint8_t*>(in_) + (long long)img * in_img_stride;
-        const uint32_t q = *reinterpret_cast<const uint32_t*>(p + (long long)gy * in_row_stride + gx);
-        const float k255 = (float)(1.0 / 255.0);                                   // ConvertImageToFloat
-        v = f32x4{(float)(q & 0xFFu) * k255, (float)((q >> 8) & 0xFFu) * k255, (float)((q >> 16) & 0xFFu) * k255,
-                  (float)(q >> 24) * k255};
-      } else {
-        const float* p = static_cast<const float*>(in_) + (long long)img * in_img_stride;
-        v = *reinterpret_cast<const f32x4*>(p + ((long long)c * Hin + gy) * Win + gx);
-      }
-    }
-    float* t = &tile[c * C::PLANE + r * C::PITCH + 4 * x4];
-    if (S == 1) {
-      *reinterpret_cast<f32x4*>(t) = v;        // PLANE and PITCH are multiples of 4 here
-    } else {
-      t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;   // odd plane stride: scalar LDS writes
-    }
+    const int r = rem / C::W4;
+    x4v[u] = rem - r * C::W4;
+    loff[u] = idx < TOTAL ? c * C::PLANE + r * C::PITCH + 4 * x4v[u] : -1;
+    const int gy = iy0 + r;
+    const bool ok = idx < TOTAL && gy >= 0 && gy < Hin;
+    grow[u] = !ok ? -1 : U8IN ? (long long)gy * in_row_stride : ((long long)c * Hin + gy) * Win;
   }
-  __syncthreads();
+  const uint8_t* in8 = static_cast<const uint8_t*>(in_) + (long long)img * in_img_stride;
+  const float* inf = static_cast<const float*>(in_) + (long long)img * in_img_stride;
 
-  const int i = lane & 15, kq = lane >> 4;
-  f32x4 acc[C::MT][C::NT];
-#pragma unroll
-  for (int m = 0; m < C::MT; m++)
-#pragma unroll
-    for (int n = 0; n < C::NT; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // zero padding outside the image: image widths are multiples of 4, so a group is wholly inside or outside the row.
+  // (Keeping the decoded offsets in registers measured faster than re-deriving them per tile, despite the occupancy.)
+#define MSF_CONV_ISSUE(ox0_)                                                                                       \
+  {                                                                                                                \
+    const int gx0_ = (ox0_) * S - C::PAD - C::XO;                                                                  \
+    _Pragma("unroll") for (int u = 0; u < NLD; u++) {                                                              \
+      const int gx = gx0_ + 4 * x4v[u];                                                                            \
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                                         \
+      if (grow[u] >= 0 && gx >= 0 && gx + 4 <= Win) {                                                              \
+        if (U8IN) {                                                                                                \
+          const uint32_t q = *reinterpret_cast<const uint32_t*>(in8 + grow[u] + gx);                               \
+          const float k255 = (float)(1.0 / 255.0); /* ConvertImageToFloat */                                       \
+          v = f32x4{(float)(q & 0xFFu) * k255, (float)((q >> 8) & 0xFFu) * k255, (float)((q >> 16) & 0xFFu) * k255, \
+                    (float)(q >> 24) * k255};                                                                      \
+        } else {                                                                                                   \
+          v = *reinterpret_cast<const f32x4*>(inf + grow[u] + gx);                                                 \
+        }                                                                                                          \
+      }                                                                                                            \
+      pre[u] = v;                                                                                                  \
+    }                                                                                                              \
+  }
 
-  // k loop in groups of G steps with the weight fragments of the NEXT group in flight while this group's MFMAs run
-  // (the weights come straight from global/L1: without the prefetch every MFMA waited on a load issued one MFMA
-  // earlier).  The host pads the packed weights with zero rows up to a whole number of groups.
-  constexpr int G = C::G, NG = C::NG;
-  float bcur[G][C::NT], bnext[G][C::NT];
+  const int ntx = (Wout + OTW - 1) / OTW;
+  MSF_CONV_ISSUE(0)
+  for (int tx = 0; tx < ntx; tx++) {
+    const int ox0 = tx * OTW;
+    __syncthreads();                       // every wave is done reading the previous tile
 #pragma unroll
-  for (int j = 0; j < G; j++)
-#pragma unroll
-    for (int n = 0; n < C::NT; n++) bcur[j][n] = wB[(j * 4 + kq) * C::NPAD + n * 16 + i];
-  for (int grp = 0; grp < NG; grp++) {
-    if (grp + 1 < NG) {
-#pragma unroll
-      for (int j = 0; j < G; j++)
-#pragma unroll
-        for (int n = 0; n < C::NT; n++) bnext[j][n] = wB[(((grp + 1) * G + j) * 4 + kq) * C::NPAD + n * 16 + i];
-    }
-#pragma unroll
-    for (int j = 0; j < G; j++) {
-      int step = grp * G + j;
-      step = step < C::KSTEPS ? step : 0;        // padded steps: any valid tile address, the weights are zero
-      int a_off;
-      if (CIN % 4 == 0) {
-        const int kk = (step * 4) / CIN;           // (ky, kx) shared by the 4 k of this step
-        const int c = (step * 4) % CIN + kq;
-        const int ky = kk / KS, kx = kk - ky * KS;
-        a_off = c * C::PLANE + (wave * RP * S + ky) * C::PITCH + kx + C::XO;
-      } else {                                      // stem: CIN = 1, k = ky * KS + kx, padded with zero weights
-        int k = step * 4 + kq;
-        k = k < C::KTOT ? k : C::KTOT - 1;
-        const int ky = k / KS, kx = k - ky * KS;
-        a_off = (wave * S + ky) * C::PITCH + kx + C::XO;
+    for (int u = 0; u < NLD; u++) {
+      if (loff[u] < 0) continue;
+      float* t = &tile[loff[u]];
+      if (S == 1) {
+        *reinterpret_cast<f32x4*>(t) = pre[u];        // PLANE and PITCH are multiples of 4 here
+      } else {
+        t[0] = pre[u].x; t[1] = pre[u].y; t[2] = pre[u].z; t[3] = pre[u].w;   // odd plane stride: scalar LDS writes
       }
-      float av[C::MT];
-#pragma unroll
-      for (int m = 0; m < C::MT; m++) av[m] = tile[a_off + (m * 16 + i) * S];
-#pragma unroll
-      for (int m = 0; m < C::MT; m++)
-#pragma unroll
-        for (int n = 0; n < C::NT; n++)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bcur[j][n], acc[m][n], 0, 0, 0);
     }
+    __syncthreads();
+    if (tx + 1 < ntx) MSF_CONV_ISSUE(ox0 + OTW)
+
+    f32x4 acc[C::MT][C::NT];
+#pragma unroll
+    for (int m = 0; m < C::MT; m++)
+#pragma unroll
+      for (int n = 0; n < C::NT; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // k loop in groups of G steps with the weight fragments of the NEXT group in flight while this group's MFMAs
+    // run (the weights come straight from global/L1).  The host pads the packed weights with zero rows up to a
+    // whole number of groups.
+    constexpr int G = C::G, NG = C::NG;
+    float bcur[G][C::NT], bnext[G][C::NT];
 #pragma unroll
     for (int j = 0; j < G; j++)
 #pragma unroll
-      for (int n = 0; n < C::NT; n++) bcur[j][n] = bnext[j][n];
-  }
-
-  // epilogue: D[row = 4*(lane>>4) + r][col = lane & 15] -> out[img][cout][oy][4 consecutive px]
+      for (int n = 0; n < C::NT; n++) bcur[j][n] = wB[(j * 4 + kq) * C::NPAD + n * 16 + i];
+    for (int grp = 0; grp < NG; grp++) {
+      if (grp + 1 < NG) {
 #pragma unroll
-  for (int n = 0; n < C::NT; n++) {
-    const int col = n * 16 + i;
-    const int co = RP == 1 ? col : col % COUT;
-    const int oy = oy0 + wave * RP + (RP == 1 ? 0 : col / COUT);
-    if (col >= COUT * RP || oy >= Hout) continue;
-    const float bv = bias ? bias[co] : 0.f;
+        for (int j = 0; j < G; j++)
 #pragma unroll
-    for (int m = 0; m < C::MT; m++) {
-      const int px = ox0 + m * 16 + kq * 4;
-      if (px >= Wout) continue;
-      const long long o = (((long long)img * COUT + co) * Hout + oy) * Wout + px;
-      f32x4 v = acc[m][n];
-      v += f32x4{bv, bv, bv, bv};
-      if (RES) v += *reinterpret_cast<const f32x4*>(res + o);
-      if (RELU) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          for (int n = 0; n < C::NT; n++) bnext[j][n] = wB[(((grp + 1) * G + j) * 4 + kq) * C::NPAD + n * 16 + i];
       }
-      *reinterpret_cast<f32x4*>(out + o) = v;
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        int step = grp * G + j;
+        step = step < C::KSTEPS ? step : 0;        // padded steps: any valid tile address, the weights are zero
+        int a_off;
+        if (CIN % 4 == 0) {
+          const int kk = (step * 4) / CIN;           // (ky, kx) shared by the 4 k of this step
+          const int c = (step * 4) % CIN + kq;
+          const int ky = kk / KS, kx = kk - ky * KS;
+          a_off = c * C::PLANE + (wave * RP * S + ky) * C::PITCH + kx + C::XO;
+        } else {                                      // stem: CIN = 1, k = ky * KS + kx, padded with zero weights
+          int k = step * 4 + kq;
+          k = k < C::KTOT ? k : C::KTOT - 1;
+          const int ky = k / KS, kx = k - ky * KS;
+          a_off = (wave * S + ky) * C::PITCH + kx + C::XO;
+        }
+        float av[C::MT];
+#pragma unroll
+        for (int m = 0; m < C::MT; m++) av[m] = tile[a_off + (m * 16 + i) * S];
+#pragma unroll
+        for (int m = 0; m < C::MT; m++)
+#pragma unroll
+          for (int n = 0; n < C::NT; n++)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bcur[j][n], acc[m][n], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < G; j++)
+#pragma unroll
+        for (int n = 0; n < C::NT; n++) bcur[j][n] = bnext[j][n];
+    }
+
+    // epilogue: D[row = 4*(lane>>4) + r][col = lane & 15] -> out[img][cout][oy][4 consecutive px]
+#pragma unroll
+    for (int n = 0; n < C::NT; n++) {
+      const int col = n * 16 + i;
+      const int co = RP == 1 ? col : col % COUT;
+      const int oy = oy0 + wave * RP + (RP == 1 ? 0 : col / COUT);
+      if (col >= COUT * RP || oy >= Hout) continue;
+      const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+      for (int m = 0; m < C::MT; m++) {
+        const int px = ox0 + m * 16 + kq * 4;
+        if (px >= Wout) continue;
+        const long long o = (((long long)img * COUT + co) * Hout + oy) * Wout + px;
+        f32x4 v = acc[m][n];
+        v += f32x4{bv, bv, bv, bv};
+        if (RES) v += *reinterpret_cast<const f32x4*>(res + o);
+        if (RELU) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<f32x4*>(out + o) = v;
+      }
     }
   }
+#undef MSF_CONV_ISSUE
 }
 
 // ------------------------------------------------------------------ tokens: + positional encoding, n c h w -> n (h w) c
@@ -787,7 +823,7 @@ void launch_conv(const ConvDesc& c, const void* in, long long in_img_stride, int
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dim3 grid((c.wout + OTW - 1) / OTW, (c.hout + C::OTH - 1) / C::OTH, n_img);
+  dim3 grid(1, (c.hout + C::OTH - 1) / C::OTH, n_img);   // a workgroup walks the x tiles of its row band
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, in, in_img_stride, in_row_stride, RP == 2 ? c.d_w2 : c.d_w, c.d_b,
                      res, out, c.hin, c.win, c.hout, c.wout);
 }
