@@ -430,6 +430,7 @@ __device__ __forceinline__ void load8(const float* p, float* v) {
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 
+// exp is the hardware v_exp_f32 path (__expf, ~2 ulp): confidences move by < 1e-6, far inside the 1e-3 bar.
 // Row statistics (max, sum of exp) of S = A B^T / 0.1; called with (f0s, f1s) for the rows and with (f1s, f0s) for
 // the columns: the products commute and are summed in the same order, so both calls see bit-identical s_ij.
 __global__ __launch_bounds__(256) void k_sim_stats(const float* __restrict__ fa, const float* __restrict__ fb,
@@ -452,8 +453,8 @@ __global__ __launch_bounds__(256) void k_sim_stats(const float* __restrict__ fa,
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const float s = d[r] / 0.1f;
-      if (s > mx[r]) { sm[r] = sm[r] * expf(mx[r] - s) + 1.f; mx[r] = s; }
-      else sm[r] += expf(s - mx[r]);
+      if (s > mx[r]) { sm[r] = sm[r] * __expf(mx[r] - s) + 1.f; mx[r] = s; }
+      else sm[r] += __expf(s - mx[r]);
     }
   }
   // combine the 16 lanes (columns) that share each row
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(256) void k_sim_stats(const float* __restrict__ fa,
     for (int o = 1; o < 16; o <<= 1) {
       const float m2 = __shfl_xor(m, o), s2 = __shfl_xor(s, o);
       const float mm = fmaxf(m, m2);
-      s = s * expf(m - mm) + s2 * expf(m2 - mm);
+      s = s * __expf(m - mm) + s2 * __expf(m2 - mm);
       m = mm;
     }
     if (tl == 0) {
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(256) void k_conf_mask(const float* __restrict__ f0s
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const float s = d[r] / 0.1f;
-      const float conf = (expf(s - cm) / csum) * (expf(s - rm[r]) / rsum[r]);
+      const float conf = (__expf(s - cm) / csum) * (__expf(s - rm[r]) / rsum[r]);
       const unsigned long long bal = __ballot(conf > threshold);   // strict '>' (dnnfeaturematcher.cpp:75)
       if (tl == 0) mk[(long long)(it * 16 + 4 * g + r) * (2 * MASK_WORDS) + jt] = (uint16_t)(bal >> (16 * g));
       if (dbg) dbg[(long long)(it * 16 + 4 * g + r) * NTOK + j] = conf;
