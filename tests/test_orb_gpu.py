@@ -211,3 +211,37 @@ def test_chunked_match_path():
     env = dict(os.environ, MSF_ORB_TRAIN_CHUNK="96")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_random_sizes_and_textures_parity():
+    """Many small frames of arbitrary sizes (odd widths, levels that vanish below 2*31 px, different textures):
+    match lists and extracted features stay bit-exact."""
+    rng = np.random.default_rng(2026)
+    sizes = [(64, 64), (65, 97), (127, 64), (200, 150), (257, 193), (333, 64), (401, 203), (96, 400), (511, 129)]
+    for _ in range(6):
+        sizes.append((int(rng.integers(64, 520)), int(rng.integers(64, 400))))
+    for n, (w, h) in enumerate(sizes):
+        kind = n % 4
+        if kind == 0:
+            a, b = synth.synth_pair(400 + n, w, h, mode=0)
+        elif kind == 1:
+            a, b = synth.synth_pair(400 + n, w, h, mode=1, noise=3)
+        elif kind == 2:
+            a = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+            b = np.roll(a, (2, -3), (0, 1))
+        else:
+            y, x = np.mgrid[0:h, 0:w]
+            a = (((x // 7 + y // 5) % 2) * 120 + (x * 3 + y) % 64).astype(np.uint8)
+            b = a[::-1].copy()
+        fm = _matcher(w, h, thr=0.75)
+        orc = oracle_orb.FeatureMatcherOracle(0.75)
+        exp = orc.MatchFrames(a, b)
+        got = fm.MatchFrames(a, b)
+        np.testing.assert_array_equal(got, exp, err_msg="%dx%d kind %d" % (w, h, kind))
+        (k1, d1), (k2, d2) = orc.extract_both(a, b)
+        for slot, (ko, do) in ((0, (k1, d1)), (1, (k2, d2))):
+            kg = fm.keypoints(slot)
+            assert len(kg) == len(ko), "%dx%d kind %d slot %d" % (w, h, kind, slot)
+            np.testing.assert_array_equal(kg["angle"].view(np.uint32), ko["angle"].view(np.uint32))
+            np.testing.assert_array_equal(fm.descriptors(slot), do)
+        fm.close()
