@@ -37,6 +37,12 @@ struct Point2i {
 struct MatchResult {  // MatchFramesResult without the frame pointers
   std::vector<Point2i> keyPoints1, keyPoints2;
   size_t GetNumMatches() const { return keyPoints1.size(); }
+  void DeleteMatch(size_t idx) {  // slam_pipeline/include/FeatureMatcher.h:31-38
+    if (idx < GetNumMatches()) {
+      keyPoints1.erase(keyPoints1.begin() + idx);
+      keyPoints2.erase(keyPoints2.begin() + idx);
+    }
+  }
 };
 
 class HipMatcherBase {

@@ -22,14 +22,14 @@ namespace msf {
 constexpr int kEdge = 31;          // edgeThreshold
 constexpr int kFastT = 20;         // fastThreshold
 constexpr int TW = 64, TH = 32;    // FAST output tile
-constexpr int PW = TW + 8, PH = TH + 8;      // pixel tile (halo 4: ring 3 + NMS 1)
-constexpr int SW = TW + 2, SH = TH + 2, SP = 68;  // score tile (halo 1), pitch 68
+constexpr int SW = TW + 2, SH = TH + 2;    // scored region: tile + 1 halo (NMS neighbours)
 constexpr int kTileCandCap = TW * TH / 4;    // strict 3x3 maxima: at most one per 2x2
 
 constexpr uint32_t kStatusOverflow = 1u;
 
 __constant__ __attribute__((aligned(16))) signed char c_pattern[1024];
-__constant__ int c_umax[16];
+constexpr int kDiscPad = 768;          // 749 disc pixels of ICAngles, padded with null entries to 12 x 64
+__constant__ uint32_t c_disc[kDiscPad]; // (offset in the 45 x 48 raw patch) | u << 16 | v << 24
 
 // ------------------------------------------------------------------ helpers
 __device__ __forceinline__ const uint8_t* level_ptr(const OrbGeometry& g, const FrameSrc& src,
@@ -559,8 +559,11 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
                                                   int half_up) {
   __shared__ __attribute__((aligned(16))) uint8_t raw_s[4][PD * PP + 16];
   __shared__ __attribute__((aligned(16))) uint16_t hb_s[4][PD * HP];
+  __shared__ uint32_t disc_s[kDiscPad];
   const int fi = blockIdx.y, slot = src.slot0 + fi;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < kDiscPad; i += 256) disc_s[i] = c_disc[i];
+  __syncthreads();
   const uint32_t count = min(kp_cnt[slot], (uint32_t)kKpCap);
   uint8_t* raw = raw_s[wave];
   uint16_t* hb = hb_s[wave];
@@ -587,20 +590,19 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
     __syncthreads();
     float angle = 0.f;
     if (active) {
-      // ICAngles (orb.cpp): lanes 0..30 take one row of the 31-px disc each.  volatile: single-byte LDS reads
-      // (the compiler would otherwise fuse neighbours into misaligned wide reads, which the LDS replays)
+      // ICAngles (orb.cpp): the 749 pixels of the 31-px disc are spread over all 64 lanes through a table of
+      // (offset, u, v); integer moments, so the summation order is free.  volatile: single-byte LDS reads (the
+      // compiler would otherwise fuse neighbours into misaligned wide reads, which the LDS replays)
       int m10 = 0, m01 = 0;
-      if (lane < 31) {
-        const int v = lane - 15;
-        const int dmax = c_umax[v < 0 ? -v : v];
-        const volatile uint8_t* row = raw + (PR + v) * PP + xo + PR;
-        int rs = 0;
-        for (int u = -dmax; u <= dmax; u++) {
-          const int p = row[u];
-          m10 += u * p;
-          rs += p;
+      {
+        const volatile uint8_t* pc = raw + xo;
+#pragma unroll
+        for (int it = 0; it < kDiscPad / 64; it++) {
+          const uint32_t e = disc_s[it * 64 + lane];
+          const int p = pc[e & 0xFFFFu];
+          m10 += (int)(signed char)(e >> 16) * p;
+          m01 += (int)(signed char)(e >> 24) * p;
         }
-        m01 = v * rs;
       }
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) {
@@ -882,7 +884,17 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   MSF_HIP_TRY(hipMemset(d_cand_cnt_, 0, S * kOrbLevels * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMemset(d_s1_cnt_, 0, S * kOrbLevels * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), k_orb_bit_pattern_31, 1024));
-  MSF_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), g.umax, sizeof(int) * 16));
+  {
+    std::vector<uint32_t> disc(kDiscPad, 0u);   // null entries: offset 0, u = v = 0 contribute nothing
+    int n = 0;
+    for (int v = -15; v <= 15; v++) {
+      const int d = g.umax[v < 0 ? -v : v];
+      for (int u = -d; u <= d; u++)
+        disc[n++] = (uint32_t)((22 + v) * 48 + 22 + u) | ((uint32_t)(uint8_t)(int8_t)u << 16) | ((uint32_t)(uint8_t)(int8_t)v << 24);
+    }
+    if (n > kDiscPad) return "ORB: disc table overflow";
+    MSF_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_disc), disc.data(), sizeof(uint32_t) * kDiscPad));
+  }
   if (profile_) {
     for (auto& e : ev_) MSF_HIP_TRY(hipEventCreate(&e));
     ev_ok_ = true;
