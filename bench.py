@@ -63,14 +63,16 @@ def cpu_baseline_loftr(args, A, B, gpu_lists):
     """LoFTR CPU baseline: the C restatement (OpenMP over its convolutions), pairs one after another."""
     import numpy as np
     from oracle import loftr as oracle_loftr
+    cores = oracle_loftr.set_threads(min(os.cpu_count() or 1, args.cpu_threads))
     orc = oracle_loftr.DNNFeatureMatcherOracle(args.threshold)
     n = min(len(A), args.cpu_loftr_pairs)
     t0 = time.perf_counter()
     res = [orc.MatchFrames(A[i], B[i]) for i in range(n)]
     dt = time.perf_counter() - t0
     mism = sum(0 if (len(m) == len(gpu_lists[i]) and np.array_equal(m, gpu_lists[i])) else 1 for i, m in enumerate(res))
-    return {"value": round(n / dt, 3), "unit": "frame-pairs/sec", "cores": os.cpu_count(), "kind": "port",
-            "sample": "%d of the same 640x480 pairs, oracle/loftr_oracle.c (f32 C restatement, OpenMP), %.1f s" % (n, dt),
+    return {"value": round(n / dt, 3), "unit": "frame-pairs/sec", "cores": cores, "kind": "port",
+            "sample": "%d of the same 640x480 pairs, oracle/loftr_oracle.c (f32 C restatement, OpenMP with %d threads), %.1f s"
+                      % (n, cores, dt),
             "match_list_mismatches_vs_gpu": mism}
 
 

@@ -23,7 +23,7 @@ namespace msf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int NTOK = 1200, DM = 32, FH = 30, FW = 40;
+constexpr int NTOK = 1200, DM = 32, FW = 40;   // 30 x 40 coarse cells of 16 px
 constexpr int MASK_WORDS = 38;  // ceil(1200 / 32)
 
 // ------------------------------------------------------------------ convolution (implicit GEMM, f32 MFMA)

@@ -56,6 +56,8 @@ int run_device(msf_handle* h, int n_pairs, const uint8_t* d_a, const uint8_t* d_
   if (((uintptr_t)d_a | (uintptr_t)d_b | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 15)
     return fail(h, MSF_ERR_INVALID_ARG, "device frames must be 16-byte aligned with strides multiple of 16");
   if (row_stride < h->cfg.image_width) return fail(h, MSF_ERR_INVALID_ARG, "row_stride < image_width");
+  if (frame_stride < row_stride * (long long)h->cfg.image_height)
+    return fail(h, MSF_ERR_INVALID_ARG, "frame_stride < row_stride * image_height (frames would overlap)");
   if (h->cfg.kind == MSF_KIND_ORB) {
     msf::FrameSrc src{d_a, d_b, n_pairs, 0, frame_stride, (int)row_stride};
     hipError_t e = h->orb.extract(src, 2 * n_pairs, st);
@@ -118,9 +120,9 @@ int msf_create(const msf_config* cfg, msf_handle** out) {
     err = h->loftr.init(cfg->weights_path, cfg->max_batch_pairs, profile);
   }
   if (!err.empty()) {
-    const bool io = err.rfind("io:", 0) == 0;
+    const bool io = err.rfind("io:", 0) == 0, arg = err.rfind("arg:", 0) == 0;
     delete h;
-    return fail(nullptr, io ? MSF_ERR_IO : MSF_ERR_HIP, err);
+    return fail(nullptr, io ? MSF_ERR_IO : arg ? MSF_ERR_INVALID_ARG : MSF_ERR_HIP, err);
   }
   if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) {
     delete h;

@@ -551,7 +551,6 @@ __device__ __forceinline__ void det_sincosf(float t, float* s, float* c) {
 constexpr int PR = 22;             // patch radius: 19 (rotated pattern reach) + 3 (blur taps)
 constexpr int PD = 2 * PR + 1;     // 45
 constexpr int PP = 48;             // raw patch pitch
-constexpr int HB = PD - 6;         // 39 horizontally blurred columns
 constexpr int HP = 40;
 
 __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
@@ -790,8 +789,8 @@ void OrbPipeline::destroy() {
   } while (0)
 
 std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_half_up, bool profile) {
-  if (width < 64 || height < 64 || width > 8192 || height > 8192) return "ORB: image size must be in [64, 8192]";
-  if (max_slots < 2) return "ORB: max_slots < 2";
+  if (width < 64 || height < 64 || width > 8192 || height > 8192) return "arg: ORB image size must be in [64, 8192] x [64, 8192]";
+  if (max_slots < 2) return "arg: ORB max_slots < 2";
   max_slots_ = max_slots;
   half_up_ = blur_half_up;
   profile_ = profile;

@@ -24,8 +24,14 @@ def lib():
         L.loftr_oracle_destroy.argtypes = [C.c_void_p]
         L.loftr_oracle_run.argtypes = [C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t] + [C.c_void_p] * 5
         L.loftr_oracle_decode.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_int]
+        L.loftr_oracle_set_threads.argtypes = [C.c_int]
         _lib = L
     return _lib
+
+
+def set_threads(n):
+    """OpenMP threads used by the restatement; returns the count in effect."""
+    return lib().loftr_oracle_set_threads(int(n))
 
 
 class DNNFeatureMatcherOracle:

@@ -23,6 +23,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define NTOK 1200
 #define DM 32
@@ -47,6 +50,17 @@ static const float* get(const loftr_oracle* o, const char* name, unsigned expect
       return o->data + o->recs[i].off;
     }
   return NULL;
+}
+
+/* number of OpenMP threads the convolutions / similarity loops use (for an honest cpu_baseline `cores`) */
+int loftr_oracle_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n;
+  return 1;
+#endif
 }
 
 loftr_oracle* loftr_oracle_create(const char* path) {

@@ -11,6 +11,7 @@
 extern "C" {
 #endif
 typedef struct loftr_oracle loftr_oracle;
+int loftr_oracle_set_threads(int n);   /* returns the thread count in effect */
 loftr_oracle* loftr_oracle_create(const char* weights_blob_path);
 void loftr_oracle_destroy(loftr_oracle* o);
 /* conf: [1200*1200] (required); sim [1200*1200], feat0/feat1 [1200*32], tok [2*1200*32] optional (NULL) */
