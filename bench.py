@@ -242,7 +242,7 @@ def main():
                        "collective_backend": args.backend if world > 1 else None},
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 of the 1-GPU run only
             line["cpu_baseline"] = (cpu_baseline if args.matcher == "orb" else cpu_baseline_loftr)(args, A, B, lists)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -57,11 +57,16 @@ struct ConvCfg {
   static constexpr int NG = (KSTEPS + G - 1) / G;
 };
 
-template <int CIN, int COUT, int KS, int S, int OTW, bool RELU, bool RES, bool U8IN, int RP = 1>
+// SC: the 1x1 stride-2 shortcut convolution of a down-sampling BasicBlock reads exactly the centre taps of the block's
+// 3x3 stride-2 convolution, so it rides along: extra accumulators fed only in the centre-tap k steps, second output
+// (bias, no ReLU).  Saves a full pass over the block input and a launch.
+template <int CIN, int COUT, int KS, int S, int OTW, bool RELU, bool RES, bool U8IN, int RP = 1, bool SC = false>
 __global__ __launch_bounds__(256) void k_conv(const void* __restrict__ in_, long long in_img_stride, int in_row_stride,
                                               const float* __restrict__ wB, const float* __restrict__ bias,
                                               const float* __restrict__ res, float* __restrict__ out, int Hin, int Win,
-                                              int Hout, int Wout) {
+                                              int Hout, int Wout, const float* __restrict__ wSC,
+                                              const float* __restrict__ biasSC, float* __restrict__ outSC) {
+  static_assert(!SC || (KS == 3 && S == 2 && RP == 1 && CIN % 4 == 0), "shortcut fusion: 3x3 stride-2 blocks only");
   using C = ConvCfg<CIN, COUT, KS, S, OTW, RELU, RES, U8IN, RP>;
   extern __shared__ __attribute__((aligned(16))) float tile[];
   const int img = blockIdx.z;
@@ -134,11 +139,11 @@ __global__ __launch_bounds__(256) void k_conv(const void* __restrict__ in_, long
     __syncthreads();
     if (tx + 1 < ntx) MSF_CONV_ISSUE(ox0 + OTW)
 
-    f32x4 acc[C::MT][C::NT];
+    f32x4 acc[C::MT][C::NT], accS[C::MT][C::NT];
 #pragma unroll
     for (int m = 0; m < C::MT; m++)
 #pragma unroll
-      for (int n = 0; n < C::NT; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int n = 0; n < C::NT; n++) { acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f}; accS[m][n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     // k loop in groups of G steps with the weight fragments of the NEXT group in flight while this group's MFMAs
     // run (the weights come straight from global/L1).  The host pads the packed weights with zero rows up to a
@@ -180,6 +185,19 @@ __global__ __launch_bounds__(256) void k_conv(const void* __restrict__ in_, long
 #pragma unroll
           for (int n = 0; n < C::NT; n++)
             acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bcur[j][n], acc[m][n], 0, 0, 0);
+        if (SC) {
+          constexpr int kCentre0 = (KS * (KS / 2) + KS / 2) * CIN / 4;   // first k step of tap (1, 1)
+          const int sstep = grp * G + j - kCentre0;
+          if (sstep >= 0 && sstep < CIN / 4) {
+#pragma unroll
+            for (int n = 0; n < C::NT; n++) {
+              const float bs = wSC[(sstep * 4 + kq) * C::NPAD + n * 16 + i];
+#pragma unroll
+              for (int m = 0; m < C::MT; m++)
+                accS[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bs, accS[m][n], 0, 0, 0);
+            }
+          }
+        }
       }
 #pragma unroll
       for (int j = 0; j < G; j++)
@@ -207,6 +225,10 @@ __global__ __launch_bounds__(256) void k_conv(const void* __restrict__ in_, long
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
         *reinterpret_cast<f32x4*>(out + o) = v;
+        if (SC) {
+          const float bs = biasSC[co];
+          *reinterpret_cast<f32x4*>(outSC + o) = accS[m][n] + f32x4{bs, bs, bs, bs};
+        }
       }
     }
   }
@@ -811,14 +833,14 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
 
 namespace {
 
-template <int CIN, int COUT, int KS, int S, int OTW, bool RELU, bool RES, bool U8IN, int RP = 1>
+template <int CIN, int COUT, int KS, int S, int OTW, bool RELU, bool RES, bool U8IN, int RP = 1, bool SC = false>
 void launch_conv(const ConvDesc& c, const void* in, long long in_img_stride, int in_row_stride, const float* res,
-                 float* out, int n_img, hipStream_t st) {
+                 float* out, int n_img, hipStream_t st, const ConvDesc* sc = nullptr, float* out_sc = nullptr) {
   using C = ConvCfg<CIN, COUT, KS, S, OTW, RELU, RES, U8IN, RP>;
   static_assert(S == 2 || (C::PLANE % 32) == 16, "plane stride must be 16 mod 32 for stride-1 convs");
   static_assert(C::PLANE >= C::RAW, "plane too small");
   const size_t lds = (size_t)CIN * C::PLANE * sizeof(float);
-  auto kern = k_conv<CIN, COUT, KS, S, OTW, RELU, RES, U8IN, RP>;
+  auto kern = k_conv<CIN, COUT, KS, S, OTW, RELU, RES, U8IN, RP, SC>;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -826,7 +848,7 @@ void launch_conv(const ConvDesc& c, const void* in, long long in_img_stride, int
   }
   dim3 grid(1, (c.hout + C::OTH - 1) / C::OTH, n_img);   // a workgroup walks the x tiles of its row band
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, in, in_img_stride, in_row_stride, RP == 2 ? c.d_w2 : c.d_w, c.d_b,
-                     res, out, c.hin, c.win, c.hout, c.wout);
+                     res, out, c.hin, c.win, c.hout, c.wout, sc ? sc->d_w : nullptr, sc ? sc->d_b : nullptr, out_sc);
 }
 
 }  // namespace
@@ -857,22 +879,19 @@ hipError_t LoftrPipeline::match(int n_pairs, const uint8_t* d_a, const uint8_t* 
     launch_conv<8, 8, 3, 1, 64, true, true, false, 2>(c[4], b, s8, 0, cc, a, ni, st);                 // a = 196
     // layer2 @120x160, 16 ch
     const long long s16 = 16LL * 120 * 160;
-    launch_conv<8, 16, 3, 2, 32, true, false, false>(c[5], a, s8, 0, nullptr, b, ni, st);
-    launch_conv<8, 16, 1, 2, 32, false, false, false>(c[7], a, s8, 0, nullptr, d, ni, st);          // shortcut
+    launch_conv<8, 16, 3, 2, 32, true, false, false, 1, true>(c[5], a, s8, 0, nullptr, b, ni, st, &c[7], d);   // + shortcut -> d
     launch_conv<16, 16, 3, 1, 32, true, true, false>(c[6], b, s16, 0, d, cc, ni, st);              // cc = 205
     launch_conv<16, 16, 3, 1, 32, true, false, false>(c[8], cc, s16, 0, nullptr, b, ni, st);
     launch_conv<16, 16, 3, 1, 32, true, true, false>(c[9], b, s16, 0, cc, a, ni, st);              // a = 212
     // layer3 @60x80, 32 ch
     const long long s32 = 32LL * 60 * 80;
-    launch_conv<16, 32, 3, 2, 16, true, false, false>(c[10], a, s16, 0, nullptr, b, ni, st);
-    launch_conv<16, 32, 1, 2, 16, false, false, false>(c[12], a, s16, 0, nullptr, d, ni, st);
+    launch_conv<16, 32, 3, 2, 16, true, false, false, 1, true>(c[10], a, s16, 0, nullptr, b, ni, st, &c[12], d);
     launch_conv<32, 32, 3, 1, 16, true, true, false>(c[11], b, s32, 0, d, cc, ni, st);             // cc = 221
     launch_conv<32, 32, 3, 1, 16, true, false, false>(c[13], cc, s32, 0, nullptr, b, ni, st);
     launch_conv<32, 32, 3, 1, 16, true, true, false>(c[14], b, s32, 0, cc, a, ni, st);             // a = 228
     // layer4 @30x40, 32 ch
     const long long s40 = 32LL * 30 * 40;
-    launch_conv<32, 32, 3, 2, 16, true, false, false>(c[15], a, s32, 0, nullptr, b, ni, st);
-    launch_conv<32, 32, 1, 2, 16, false, false, false>(c[17], a, s32, 0, nullptr, d, ni, st);
+    launch_conv<32, 32, 3, 2, 16, true, false, false, 1, true>(c[15], a, s32, 0, nullptr, b, ni, st, &c[17], d);
     launch_conv<32, 32, 3, 1, 16, true, true, false>(c[16], b, s40, 0, d, cc, ni, st);             // cc = 237
     launch_conv<32, 32, 3, 1, 16, true, false, false>(c[18], cc, s40, 0, nullptr, b, ni, st);
     launch_conv<32, 32, 3, 1, 16, true, true, false>(c[19], b, s40, 0, cc, a, ni, st);             // a = 244
