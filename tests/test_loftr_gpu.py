@@ -90,3 +90,25 @@ def test_wrong_size_is_unsupported():
     with pytest.raises(MsfError) as e:
         DNNFeatureMatcher(threshold=0.15, image_width=1280, image_height=720)
     assert e.value.code == -3
+
+
+def test_device_batch_across_backbone_chunks():
+    """An HBM-resident batch larger than one backbone chunk (64 pairs): every pair's list equals the single-pair
+    result regardless of its position, and KAT (ii) placed anywhere in the batch gives its golden list."""
+    import torch
+    n = 70
+    A, B = synth.synth_batch(900, n, 640, 480, mode=1)
+    A[66], B[66] = G["img0_ii"], G["img1_ii"]
+    dm = _dm(0.15, pairs=n)
+    dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+    out = torch.zeros((n, 2048, 4), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros((n,), dtype=torch.int32, device="cuda")
+    dm.match_batch_device(dA, dB, out, cnt, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    out, cnt = out.cpu().numpy(), cnt.cpu().numpy()
+    single = _dm(0.15)
+    for i in (0, 31, 63, 64, 66, 69):
+        ref = single.MatchFrames(A[i], B[i], cap=8192)
+        assert cnt[i] == len(ref)
+        np.testing.assert_array_equal(out[i, :cnt[i]], ref)
+    np.testing.assert_array_equal(out[66, :cnt[66]], G["matches_ii_015"])

@@ -245,3 +245,40 @@ def test_random_sizes_and_textures_parity():
             np.testing.assert_array_equal(kg["angle"].view(np.uint32), ko["angle"].view(np.uint32))
             np.testing.assert_array_equal(fm.descriptors(slot), do)
         fm.close()
+
+
+def test_full_size_batch_properties():
+    """At the bench's frame size, on an HBM-resident batch: results are deterministic, independent of a pair's
+    position in the batch (pairs never interact), and reproduce the known shift of the synthetic pairs."""
+    import torch
+    w, h, n = 1280, 720, 48
+    A, B = synth.synth_batch(700, n, w, h)
+    fm = _matcher(w, h, thr=0.6, pairs=n)
+    dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+
+    def run(a, b):
+        out = torch.zeros((n, 1024, 4), dtype=torch.int32, device="cuda")
+        cnt = torch.zeros((n,), dtype=torch.int32, device="cuda")
+        fm.match_batch_device(a, b, out, cnt, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return out.cpu().numpy(), cnt.cpu().numpy()
+
+    o1, c1 = run(dA, dB)
+    o2, c2 = run(dA, dB)
+    np.testing.assert_array_equal(c1, c2)
+    np.testing.assert_array_equal(o1, o2)
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(3))
+    o3, c3 = run(dA[perm].contiguous(), dB[perm].contiguous())
+    np.testing.assert_array_equal(c3, c1[perm.numpy()])
+    for k, p in enumerate(perm.numpy()):
+        np.testing.assert_array_equal(o3[k, :c3[k]], o1[p, :c1[p]])
+    assert (c1 > 50).all()
+    for i in range(n):
+        dx, dy = synth.pair_shift(700 + i)
+        d = o1[i, :c1[i], 2:4] - o1[i, :c1[i], 0:2]
+        good = (np.abs(d[:, 0] + dx) <= 4) & (np.abs(d[:, 1] + dy) <= 4)   # frame B = canvas shifted by (+dx, +dy)
+        assert good.mean() > 0.9, (i, good.mean())
+    # two spot checks against the oracle at full size
+    orc = oracle_orb.FeatureMatcherOracle(0.6)
+    for i in (0, n - 1):
+        np.testing.assert_array_equal(o1[i, :c1[i]], orc.MatchFrames(A[i], B[i]))
