@@ -118,9 +118,11 @@ __global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uin
 //     ((0,3),(3,0),(0,-3),(-3,0)), so "some adjacent cardinal pair is all-brighter or all-darker" is necessary.
 //     Per-byte threshold tests use v_lerp_u8 as a carry-free byte adder: lerp(p, ~c) = (p + 255 - c) >> 1, and a
 //     second lerp against a constant puts the compare result in bit 7 of each byte.  Conservative (superset).
-//  2. survivors (compacted in LDS) get the exact cornerScore<16>: max over the 16 arcs of min9(d) / min9(-d)
-//     through min3/max3 networks; score > threshold <=> FAST_t's 9-contiguous test.
-//  3. strict 3x3 NMS + runByImageBorder on the corner list only.
+//  2. survivors (compacted in LDS, one list per polarity) get the exact cornerScore<16>: max over the 16 arcs of the
+//     minimum over the arc, through min3/max3 window networks on the raw ring pixels; score > threshold <=> FAST_t's
+//     9-contiguous test.  Scores go into a zeroed score tile.
+//  3. strict 3x3 NMS + runByImageBorder, dense on 4 scores per lane (two passes over the 64 x 32 outputs).
+// The kernel is VALU-issue bound: what counts is the number of vector instructions.
 constexpr int HX = 16, HY = 4;                     // pixel-tile halo: rows start 16-byte aligned (x0 - 16)
 constexpr int PW2 = TW + 2 * HX, PH2 = TH + 2 * HY;  // 96 x 40
 constexpr int SCO = 4;                              // byte offset of the score tile inside its LDS array
