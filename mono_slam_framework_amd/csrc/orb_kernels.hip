@@ -24,6 +24,7 @@ constexpr int kFastT = 20;         // fastThreshold
 constexpr int TW = 64, TH = 32;    // FAST output tile
 constexpr int SW = TW + 2, SH = TH + 2;    // scored region: tile + 1 halo (NMS neighbours)
 constexpr int kTileCandCap = TW * TH / 4;    // strict 3x3 maxima: at most one per 2x2
+constexpr int kTileX0 = 16, kTileY0 = kEdge;  // tile grid origin: first output column 31 rounded down to the 16-byte load grid
 
 constexpr uint32_t kStatusOverflow = 1u;
 
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
     if (i < g.nlevels && bt >= g.lv[i].tile_base) l = i;
   const OrbLevelInfo L = g.lv[l];
   const int t = bt - L.tile_base;
-  const int x0 = (t % L.tiles_x) * TW, y0 = (t / L.tiles_x) * TH;
+  const int x0 = kTileX0 + (t % L.tiles_x) * TW, y0 = kTileY0 + (t / L.tiles_x) * TH;
   int pitch;
   const uint8_t* img = level_ptr(g, src, pyr, fi, l, &pitch);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -236,7 +237,10 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
 
   // phase 1: cardinal prefilter on 4 px per lane
   const uint32_t* T = reinterpret_cast<const uint32_t*>(px);
-  const int txlo = max(-1, 3 - x0), txhi = min(TW, L.w - 4 - x0);   // scored tile-x range
+  // Scored domain: FAST_t scores rows/cols 3 .. dim-4, but runByImageBorder(31) discards everything outside
+  // [31, dim-31), so only those pixels and their NMS neighbours ([30, dim-30)) can matter; the rest keeps score 0.
+  constexpr int kLo = kEdge - 1;
+  const int txlo = max(-1, kLo - x0), txhi = min(TW, L.w - kLo - 1 - x0);   // scored tile-x range
   for (int i0 = 0; i0 < GPR * SH; i0 += kFastThreads) {
     const int i = i0 + tid;
     const int ic = i < GPR * SH ? i : GPR * SH - 1;   // idle lanes recompute the last task, masked below
@@ -254,14 +258,14 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
     const uint32_t b8 = __builtin_amdgcn_lerp(l8, kLerpBright, 0), b12 = __builtin_amdgcn_lerp(l12, kLerpBright, 0);
     const uint32_t n0 = __builtin_amdgcn_lerp(l0, kLerpNotDark, 0), n4 = __builtin_amdgcn_lerp(l4, kLerpNotDark, 0);
     const uint32_t n8 = __builtin_amdgcn_lerp(l8, kLerpNotDark, 0), n12 = __builtin_amdgcn_lerp(l12, kLerpNotDark, 0);
-    // FAST_t scores only rows/cols 3 .. dim-4; the score tile spans tile +- 1
+    // the score tile spans tile +- 1
     uint32_t vm = 0;
     {
       const int gy = y0 + ty;
       int first = txlo - tx0, last = txhi - tx0;         // valid bytes: first .. last
       first = first < 0 ? 0 : first;
       last = last > 3 ? 3 : last;
-      if (i < GPR * SH && gy >= 3 && gy < L.h - 3 && first <= last)
+      if (i < GPR * SH && gy >= kLo && gy < L.h - kLo && first <= last)
         vm = (0x80808080u << (8 * first)) & (0x80808080u >> (8 * (3 - last)));
     }
     const uint32_t cb = ((b0 | b8) & (b4 | b12)) & vm;
@@ -857,8 +861,11 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     cand += cap;
     L.s1_off = s1;
     s1 += kS1Cap;
-    L.tiles_x = (L.w + TW - 1) / TW;
-    L.tiles_y = (L.h + TH - 1) / TH;
+    // FAST tiles cover only the pixels runByImageBorder(31) can keep, [31, w-31) x [31, h-31) (17 % fewer tiles on
+    // the 720p pyramid than tiling the whole level); levels without such pixels get no tiles
+    L.tiles_x = L.w > 2 * kEdge ? (L.w - kEdge - kTileX0 + TW - 1) / TW : 0;
+    L.tiles_y = L.h > 2 * kEdge ? (L.h - 2 * kEdge + TH - 1) / TH : 0;
+    if (L.tiles_x == 0 || L.tiles_y == 0) L.tiles_x = L.tiles_y = 0;
     L.tile_base = tiles;
     tiles += L.tiles_x * L.tiles_y;
     L.tab_off = tab;
@@ -932,7 +939,9 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
                        d_tab_, l, rth, lds_rows);
   }
   if (ev_ok_) hipEventRecord(ev_[1], st);
-  hipLaunchKernelGGL(k_fast, dim3((unsigned)g.total_tiles * (unsigned)n), dim3(kFastThreads), 0, st, g, src, d_pyr_, d_cand_cnt_, d_cand_);
+  if (g.total_tiles > 0)
+    hipLaunchKernelGGL(k_fast, dim3((unsigned)g.total_tiles * (unsigned)n), dim3(kFastThreads), 0, st, g, src, d_pyr_, d_cand_cnt_,
+                       d_cand_);
   if (ev_ok_) hipEventRecord(ev_[2], st);
   hipLaunchKernelGGL(k_thr_harris, dim3(g.nlevels, n), dim3(256), 0, st, g, src, d_pyr_, d_cand_cnt_, d_cand_,
                      d_s1_cnt_, d_s1_, d_status_);
