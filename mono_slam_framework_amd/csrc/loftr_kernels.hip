@@ -518,6 +518,12 @@ __global__ __launch_bounds__(256) void k_conf_mask(const float* __restrict__ f0s
   load8(A + (long long)(it * 16 + tl) * DM + 8 * g, a);
 #pragma unroll
   for (int r = 0; r < 4; r++) { rm[r] = rs[it * 16 + 4 * g + r]; rsum[r] = rs[NTOK + it * 16 + 4 * g + r]; }
+  // conf <= softmax_j(s)_ij = exp(s - rm) / rsum, so s < rm + log(threshold * rsum) (minus a margin that covers
+  // the rounding of this bound) can never pass: tiles where no lane reaches the bound skip the exact evaluation.
+  float lim[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+    lim[r] = threshold > 0.f ? rm[r] + __logf(threshold * rsum[r]) - 1e-2f : -__builtin_inff();
   for (int jt = 0; jt < NTOK / 16; jt++) {
     float b[8];
     const int j = jt * 16 + tl;
@@ -526,6 +532,14 @@ __global__ __launch_bounds__(256) void k_conf_mask(const float* __restrict__ f0s
     f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int sI = 0; sI < 8; sI++) d = mfma4(a[sI], b[sI], d);
+    const bool reach = d[0] * 10.f >= lim[0] || d[1] * 10.f >= lim[1] || d[2] * 10.f >= lim[2] || d[3] * 10.f >= lim[3];
+    if (!dbg && !__any(reach)) {
+      if (tl == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) mk[(long long)(it * 16 + 4 * g + r) * (2 * MASK_WORDS) + jt] = 0;
+      }
+      continue;
+    }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const float s = d[r] / 0.1f;
