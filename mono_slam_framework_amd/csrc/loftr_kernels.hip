@@ -65,12 +65,17 @@ __global__ __launch_bounds__(256) void k_conv(const void* __restrict__ in_, long
                                               const float* __restrict__ wB, const float* __restrict__ bias,
                                               const float* __restrict__ res, float* __restrict__ out, int Hin, int Win,
                                               int Hout, int Wout, const float* __restrict__ wSC,
-                                              const float* __restrict__ biasSC, float* __restrict__ outSC) {
+                                              const float* __restrict__ biasSC, float* __restrict__ outSC,
+                                              int n_bands) {
   static_assert(!SC || (KS == 3 && S == 2 && RP == 1 && CIN % 4 == 0), "shortcut fusion: 3x3 stride-2 blocks only");
   using C = ConvCfg<CIN, COUT, KS, S, OTW, RELU, RES, U8IN, RP>;
   extern __shared__ __attribute__((aligned(16))) float tile[];
-  const int img = blockIdx.z;
-  const int oy0 = blockIdx.y * C::OTH;
+  // Workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.  Re-number them so one XCD owns a
+  // contiguous run of (image, band) units: the halo rows two neighbouring bands share are then fetched from HBM once.
+  const int nwg = gridDim.x, per = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7;
+  const int unit = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+  const int img = unit / n_bands;
+  const int oy0 = (unit - img * n_bands) * C::OTH;
   const int iy0 = oy0 * S - C::PAD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
@@ -860,9 +865,10 @@ void launch_conv(const ConvDesc& c, const void* in, long long in_img_stride, int
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dim3 grid(1, (c.hout + C::OTH - 1) / C::OTH, n_img);   // a workgroup walks the x tiles of its row band
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, in, in_img_stride, in_row_stride, RP == 2 ? c.d_w2 : c.d_w, c.d_b,
-                     res, out, c.hin, c.win, c.hout, c.wout, sc ? sc->d_w : nullptr, sc ? sc->d_b : nullptr, out_sc);
+  const int n_bands = (c.hout + C::OTH - 1) / C::OTH;     // a workgroup walks the x tiles of its row band
+  hipLaunchKernelGGL(kern, dim3(n_bands * n_img), dim3(256), lds, st, in, in_img_stride, in_row_stride,
+                     RP == 2 ? c.d_w2 : c.d_w, c.d_b, res, out, c.hin, c.win, c.hout, c.wout, sc ? sc->d_w : nullptr,
+                     sc ? sc->d_b : nullptr, out_sc, n_bands);
 }
 
 }  // namespace
