@@ -125,6 +125,28 @@ int msf_extract_device(msf_handle* h, int32_t n_frames, const uint8_t* d_frames,
 int msf_match_slots_device(msf_handle* h, int32_t n_pairs, const int32_t* d_slot_a, const int32_t* d_slot_b,
                            msf_match* d_out, int32_t cap_per_pair, int32_t* d_n_out, void* stream);
 
+/* "next" row 3 of SURVEY.md 8f: KeyFrameMatchDatabase scoring (slam_pipeline/src/KeyFrameDatabase.cc:23-53).
+ * msf_set_mappoints replaces the content of map slot [0, 2*max_batch_pairs) with a frame's KeyPointMap occupancy:
+ * `keys` (HOST pointer) are the pixel keys y*cols + x that hold a map point (KeyPointMap.cc:36-52).
+ * msf_count_mappoint_matches_device: d_num_mp[i] = number of the first min(d_n_matches[i], cap_per_pair) matches of
+ * pair i whose endpoint 1 is set in map slot d_map_a[i] and endpoint 2 in map slot d_map_b[i]
+ * (MatchFramesResult::GetMapPoint1/2 both non-null, FeatureMatcher.h:23-29, KeyFrameDatabase.cc:37-44). */
+int msf_set_mappoints(msf_handle* h, int32_t map_slot, const int32_t* keys, int32_t n_keys);
+int msf_count_mappoint_matches_device(msf_handle* h, int32_t n_pairs, const msf_match* d_matches,
+                                      int32_t cap_per_pair, const int32_t* d_n_matches, const int32_t* d_map_a,
+                                      const int32_t* d_map_b, int32_t* d_num_mp, void* stream);
+
+/* One-vs-many host entry points for KeyFrameMatchDatabase (KeyFrameDatabase.cc:31-32, 63-64: a loop of
+ * MatchFrames(X, KF_i) with X fixed).  msf_store_frame uploads a host frame into resident frame slot
+ * [0, 2*max_batch_pairs) and, for ORB, extracts its features once into the feature slot of the same index.
+ * msf_match_one_to_many matches the frame in `query_slot` against the n <= max_batch_pairs frames in `slots`
+ * (HOST array) in one launch sequence: num_matches[i] (HOST) as msf_match_batch's n_out; num_mp[i] (HOST, optional)
+ * = matches with a map point at both endpoints, map slots being the frame slots; out (HOST, optional)
+ * [n][cap_per_pair] receives the lists. */
+int msf_store_frame(msf_handle* h, int32_t slot, const msf_image* img);
+int msf_match_one_to_many(msf_handle* h, int32_t query_slot, int32_t n, const int32_t* slots, int32_t* num_matches,
+                          int32_t* num_mp, msf_match* out, int32_t cap_per_pair);
+
 /* Packs [n_pairs][cap_per_pair] match lists + counts into one contiguous device list:
  * d_offsets[i] = start of pair i, d_offsets[n_pairs] = total; pairs with n_out < 0 contribute nothing.
  * This is the payload of the multi-GPU gather of match lists (and of MatchFramesResult's vectors). */

@@ -71,28 +71,32 @@ class HipMatcherBase {
 
   const char* LastError() const { return msf_last_error(h_); }
   msf_handle* handle() { return h_; }
+  int max_batch_pairs() const { return max_pairs_; }   // capacity of the one-vs-many callers (hip_keyframe_database.h)
+  int result_cap() const { return cap_; }
 
  protected:
-  explicit HipMatcherBase(const msf_config& cfg, int cap) : cap_(cap) {
+  explicit HipMatcherBase(const msf_config& cfg, int cap) : cap_(cap), max_pairs_(cfg.max_batch_pairs) {
     if (msf_create(&cfg, &h_) != MSF_OK)
       throw std::runtime_error(std::string("msf_create: ") + msf_last_error(nullptr));  // the reference's ctor throws too (Ort::Session)
   }
   msf_handle* h_ = nullptr;
   int cap_;
+  int max_pairs_;
   std::vector<msf_match> buf_;
 };
 
 // ::FeatureMatcher(float threshold = 0.8f)  (featurematcher.h:9)
 class HipFeatureMatcher : public HipMatcherBase {
  public:
-  explicit HipFeatureMatcher(float threshold = 0.8f, int image_width = 640, int image_height = 480, int device = 0)
-      : HipMatcherBase(make(threshold, image_width, image_height, device), 2048) {}
+  explicit HipFeatureMatcher(float threshold = 0.8f, int image_width = 640, int image_height = 480, int device = 0,
+                             int max_batch_pairs = 1)
+      : HipMatcherBase(make(threshold, image_width, image_height, device, max_batch_pairs), 2048) {}
 
  private:
-  static msf_config make(float thr, int w, int h, int dev) {
+  static msf_config make(float thr, int w, int h, int dev, int max_pairs) {
     msf_config c;
     msf_default_config(&c, MSF_KIND_ORB);
-    c.threshold = thr; c.image_width = w; c.image_height = h; c.device = dev;
+    c.threshold = thr; c.image_width = w; c.image_height = h; c.device = dev; c.max_batch_pairs = max_pairs;
     return c;
   }
 };
@@ -104,16 +108,17 @@ class HipDNNFeatureMatcher : public HipMatcherBase {
  public:
   explicit HipDNNFeatureMatcher(const std::string& model_file_path = "", float threshold = 0.15f,
                                 int64_t image_width = 640, int64_t image_height = 480, int model_resolution = 16,
-                                int device = 0)
-      : HipMatcherBase(make(model_file_path, threshold, image_width, image_height, model_resolution, device), 4096),
+                                int device = 0, int max_batch_pairs = 1)
+      : HipMatcherBase(make(model_file_path, threshold, image_width, image_height, model_resolution, device,
+                            max_batch_pairs), 4096),
         path_(model_file_path) {}
 
  private:
-  static msf_config make(const std::string& path, float thr, int64_t w, int64_t h, int res, int dev) {
+  static msf_config make(const std::string& path, float thr, int64_t w, int64_t h, int res, int dev, int max_pairs) {
     if (res != 16) throw std::runtime_error("LoFTR_teacher works at 1/16 resolution only");
     msf_config c;
     msf_default_config(&c, MSF_KIND_LOFTR);
-    c.threshold = thr; c.image_width = (int)w; c.image_height = (int)h; c.device = dev;
+    c.threshold = thr; c.image_width = (int)w; c.image_height = (int)h; c.device = dev; c.max_batch_pairs = max_pairs;
     c.weights_path = path.empty() ? nullptr : path.c_str();
     return c;
   }

@@ -14,6 +14,9 @@
 namespace msf {
 hipError_t pack_matches(int n, const msf_match* d_in, int cap, const int32_t* d_cnt, msf_match* d_packed,
                         int32_t* d_offsets, hipStream_t st);
+hipError_t count_mappoint_matches(int n, const msf_match* d_matches, int cap, const int32_t* d_cnt,
+                                  const int32_t* d_map_a, const int32_t* d_map_b, const uint32_t* d_maps, int n_maps,
+                                  int map_words, int width, int height, int32_t* d_num_mp, hipStream_t st);
 }
 
 namespace {
@@ -34,6 +37,14 @@ struct msf_handle {
   int stage_pitch = 0;
   long long stage_frame = 0;
   int stage_cap = 0;
+  // KeyPointMap occupancy bitmaps (allocated by the first msf_set_mappoints): [n_maps][map_words]
+  uint32_t* d_maps = nullptr;
+  int n_maps = 0, map_words = 0;
+  std::vector<uint32_t> map_stage;
+  // resident frame store of the one-vs-many entry points (allocated by the first msf_store_frame): [2*max_pairs] frames
+  uint8_t* d_store = nullptr;
+  int32_t* d_idx = nullptr;     // [3][max_pairs]: query slot per pair, train slot per pair, map-point counts
+  std::vector<int32_t> idx_stage;
 };
 
 namespace {
@@ -69,6 +80,32 @@ int run_device(msf_handle* h, int n_pairs, const uint8_t* d_a, const uint8_t* d_
   hipError_t e = h->loftr.match(n_pairs, d_a, d_b, frame_stride, (int)row_stride, h->cfg.threshold, d_out, cap,
                                 d_n_out, st);
   if (e != hipSuccess) return hip_fail(h, "loftr match", e);
+  return MSF_OK;
+}
+
+int ensure_stage(msf_handle* h) {
+  if (h->d_stage) return MSF_OK;
+  const int W = h->cfg.image_width, H = h->cfg.image_height, maxp = h->cfg.max_batch_pairs;
+  hipError_t e;
+  h->stage_pitch = (W + 15) & ~15;
+  h->stage_frame = (long long)h->stage_pitch * H;
+  h->stage_cap = kStageCap;
+  if ((e = hipMalloc(&h->d_stage, (size_t)2 * maxp * h->stage_frame)) != hipSuccess) return hip_fail(h, "hipMalloc stage", e);
+  if ((e = hipMalloc(&h->d_out, (size_t)maxp * h->stage_cap * sizeof(msf_match))) != hipSuccess) return hip_fail(h, "hipMalloc out", e);
+  if ((e = hipMalloc(&h->d_n, (size_t)maxp * sizeof(int32_t))) != hipSuccess) return hip_fail(h, "hipMalloc n", e);
+  return MSF_OK;
+}
+
+int ensure_maps(msf_handle* h) {
+  if (h->d_maps) return MSF_OK;
+  const int n_maps = 2 * h->cfg.max_batch_pairs;
+  const long long n_px = (long long)h->cfg.image_width * h->cfg.image_height;
+  h->map_words = (int)((n_px + 31) / 32);
+  const size_t bytes = (size_t)n_maps * h->map_words * sizeof(uint32_t);
+  hipError_t e;
+  if ((e = hipMalloc(&h->d_maps, bytes)) != hipSuccess) return hip_fail(h, "hipMalloc(map bitmaps)", e);
+  if ((e = hipMemsetAsync(h->d_maps, 0, bytes, h->stream)) != hipSuccess) return hip_fail(h, "hipMemsetAsync", e);
+  h->n_maps = n_maps;
   return MSF_OK;
 }
 
@@ -141,6 +178,9 @@ void msf_destroy(msf_handle* h) {
   hipFree(h->d_stage);
   hipFree(h->d_out);
   hipFree(h->d_n);
+  hipFree(h->d_maps);
+  hipFree(h->d_store);
+  hipFree(h->d_idx);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
@@ -184,14 +224,7 @@ int msf_match_batch(msf_handle* h, int32_t n_pairs, const msf_image* a, const ms
         a[i].stride < W || b[i].stride < W)
       return fail(h, MSF_ERR_INVALID_ARG, "msf_match_batch: image size differs from the handle's, or null data");
   }
-  if (!h->d_stage) {
-    h->stage_pitch = (W + 15) & ~15;
-    h->stage_frame = (long long)h->stage_pitch * H;
-    h->stage_cap = kStageCap;
-    if ((e = hipMalloc(&h->d_stage, (size_t)2 * maxp * h->stage_frame)) != hipSuccess) return hip_fail(h, "hipMalloc stage", e);
-    if ((e = hipMalloc(&h->d_out, (size_t)maxp * h->stage_cap * sizeof(msf_match))) != hipSuccess) return hip_fail(h, "hipMalloc out", e);
-    if ((e = hipMalloc(&h->d_n, (size_t)maxp * sizeof(int32_t))) != hipSuccess) return hip_fail(h, "hipMalloc n", e);
-  }
+  if (int rc = ensure_stage(h)) return rc;
   hipStream_t st = h->stream;
   std::vector<msf_match> tmp;
   std::vector<int32_t> cnt(maxp);
@@ -277,6 +310,133 @@ int msf_pack_matches_device(msf_handle* h, int32_t n_pairs, const msf_match* d_i
   if ((e = msf::pack_matches(n_pairs, d_in, cap_per_pair, d_n_out, d_packed, d_offsets, st)) != hipSuccess)
     return hip_fail(h, "pack_matches", e);
   if (!stream && (e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(h, "hipStreamSynchronize", e);
+  return MSF_OK;
+}
+
+int msf_set_mappoints(msf_handle* h, int32_t map_slot, const int32_t* keys, int32_t n_keys) {
+  if (!h) return MSF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  const int n_maps = 2 * h->cfg.max_batch_pairs;
+  const long long n_px = (long long)h->cfg.image_width * h->cfg.image_height;
+  if (map_slot < 0 || map_slot >= n_maps || n_keys < 0 || (n_keys > 0 && !keys))
+    return fail(h, MSF_ERR_INVALID_ARG, "msf_set_mappoints: bad argument");
+  hipError_t e = hipSetDevice(h->cfg.device);
+  if (e != hipSuccess) return hip_fail(h, "hipSetDevice", e);
+  if (int rc = ensure_maps(h)) return rc;
+  h->map_stage.assign(h->map_words, 0u);
+  for (int i = 0; i < n_keys; i++) {
+    // KeyPointMap::SetMapPoint ignores points outside the image (KeyPointMap.cc:38-39); a key is y*cols + x
+    if (keys[i] < 0 || keys[i] >= n_px) return fail(h, MSF_ERR_INVALID_ARG, "msf_set_mappoints: key outside the image");
+    h->map_stage[keys[i] >> 5] |= 1u << (keys[i] & 31);
+  }
+  e = hipMemcpyAsync(h->d_maps + (size_t)map_slot * h->map_words, h->map_stage.data(),
+                     (size_t)h->map_words * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream);
+  if (e != hipSuccess) return hip_fail(h, "hipMemcpyAsync(map bitmap)", e);
+  if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return hip_fail(h, "hipStreamSynchronize", e);
+  return MSF_OK;
+}
+
+int msf_count_mappoint_matches_device(msf_handle* h, int32_t n_pairs, const msf_match* d_matches,
+                                      int32_t cap_per_pair, const int32_t* d_n_matches, const int32_t* d_map_a,
+                                      const int32_t* d_map_b, int32_t* d_num_mp, void* stream) {
+  if (!h) return MSF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (n_pairs < 0 || !d_matches || !d_n_matches || !d_map_a || !d_map_b || !d_num_mp || cap_per_pair < 1)
+    return fail(h, MSF_ERR_INVALID_ARG, "msf_count_mappoint_matches_device: bad argument");
+  if (!h->d_maps) return fail(h, MSF_ERR_INVALID_ARG, "msf_count_mappoint_matches_device: no map slot was ever set");
+  hipError_t e = hipSetDevice(h->cfg.device);
+  if (e != hipSuccess) return hip_fail(h, "hipSetDevice", e);
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  e = msf::count_mappoint_matches(n_pairs, d_matches, cap_per_pair, d_n_matches, d_map_a, d_map_b, h->d_maps, h->n_maps,
+                                  h->map_words, h->cfg.image_width, h->cfg.image_height, d_num_mp, st);
+  if (e != hipSuccess) return hip_fail(h, "count_mappoint_matches", e);
+  if (!stream && (e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(h, "hipStreamSynchronize", e);
+  return MSF_OK;
+}
+
+int msf_store_frame(msf_handle* h, int32_t slot, const msf_image* img) {
+  if (!h) return MSF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  const int W = h->cfg.image_width, H = h->cfg.image_height, maxp = h->cfg.max_batch_pairs;
+  if (slot < 0 || slot >= 2 * maxp || !img || !img->data || img->width != W || img->height != H || img->stride < W)
+    return fail(h, MSF_ERR_INVALID_ARG, "msf_store_frame: slot outside [0, 2*max_batch_pairs) or image size differs from the handle's");
+  hipError_t e = hipSetDevice(h->cfg.device);
+  if (e != hipSuccess) return hip_fail(h, "hipSetDevice", e);
+  if (int rc = ensure_stage(h)) return rc;
+  if (!h->d_store) {
+    if ((e = hipMalloc(&h->d_store, (size_t)2 * maxp * h->stage_frame)) != hipSuccess) return hip_fail(h, "hipMalloc(frame store)", e);
+    if ((e = hipMalloc(&h->d_idx, (size_t)3 * maxp * sizeof(int32_t))) != hipSuccess) return hip_fail(h, "hipMalloc(idx)", e);
+  }
+  hipStream_t st = h->stream;
+  uint8_t* dst = h->d_store + (size_t)slot * h->stage_frame;
+  if ((e = hipMemcpy2DAsync(dst, h->stage_pitch, img->data, img->stride, W, H, hipMemcpyHostToDevice, st)) != hipSuccess)
+    return hip_fail(h, "hipMemcpy2DAsync", e);
+  if (h->cfg.kind == MSF_KIND_ORB) {   // features are extracted once, here
+    msf::FrameSrc src{dst, dst, 1, slot, h->stage_frame, h->stage_pitch};
+    if ((e = h->orb.extract(src, 1, st)) != hipSuccess) return hip_fail(h, "orb extract", e);
+  }
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(h, "hipStreamSynchronize", e);
+  return MSF_OK;
+}
+
+int msf_match_one_to_many(msf_handle* h, int32_t query_slot, int32_t n, const int32_t* slots, int32_t* num_matches,
+                          int32_t* num_mp, msf_match* out, int32_t cap_per_pair) {
+  if (!h) return MSF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  const int maxp = h->cfg.max_batch_pairs;
+  if (n < 0 || (n > 0 && (!slots || !num_matches)) || (out && cap_per_pair < 1))
+    return fail(h, MSF_ERR_INVALID_ARG, "msf_match_one_to_many: bad argument");
+  if (n == 0) return MSF_OK;
+  if (n > maxp) return fail(h, MSF_ERR_INVALID_ARG, "msf_match_one_to_many: n exceeds max_batch_pairs");
+  if (!h->d_store) return fail(h, MSF_ERR_INVALID_ARG, "msf_match_one_to_many: no frame was stored");
+  if (query_slot < 0 || query_slot >= 2 * maxp) return fail(h, MSF_ERR_INVALID_ARG, "msf_match_one_to_many: bad query slot");
+  for (int i = 0; i < n; i++)
+    if (slots[i] < 0 || slots[i] >= 2 * maxp) return fail(h, MSF_ERR_INVALID_ARG, "msf_match_one_to_many: bad slot");
+  if (num_mp && !h->d_maps) return fail(h, MSF_ERR_INVALID_ARG, "msf_match_one_to_many: no map slot was ever set");
+  hipError_t e = hipSetDevice(h->cfg.device);
+  if (e != hipSuccess) return hip_fail(h, "hipSetDevice", e);
+  hipStream_t st = h->stream;
+  h->idx_stage.resize((size_t)2 * maxp);
+  for (int i = 0; i < n; i++) { h->idx_stage[i] = query_slot; h->idx_stage[maxp + i] = slots[i]; }
+  if ((e = hipMemcpyAsync(h->d_idx, h->idx_stage.data(), (size_t)2 * maxp * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess)
+    return hip_fail(h, "hipMemcpyAsync(idx)", e);
+  if (h->cfg.kind == MSF_KIND_ORB) {
+    if ((e = h->orb.match(n, h->d_idx, h->d_idx + maxp, h->cfg.threshold, h->d_out, h->stage_cap, h->d_n, st)) != hipSuccess)
+      return hip_fail(h, "orb match", e);
+  } else {
+    // the graph takes the two frames of a pair together: gather (query, keyframe_i) pairs from the store
+    uint8_t* dA = h->d_stage;
+    uint8_t* dB = h->d_stage + (size_t)maxp * h->stage_frame;
+    for (int i = 0; i < n; i++) {
+      if ((e = hipMemcpyAsync(dA + (size_t)i * h->stage_frame, h->d_store + (size_t)query_slot * h->stage_frame,
+                              (size_t)h->stage_frame, hipMemcpyDeviceToDevice, st)) != hipSuccess) return hip_fail(h, "hipMemcpyAsync", e);
+      if ((e = hipMemcpyAsync(dB + (size_t)i * h->stage_frame, h->d_store + (size_t)slots[i] * h->stage_frame,
+                              (size_t)h->stage_frame, hipMemcpyDeviceToDevice, st)) != hipSuccess) return hip_fail(h, "hipMemcpyAsync", e);
+    }
+    int rc = run_device(h, n, dA, dB, h->stage_frame, h->stage_pitch, h->d_out, h->stage_cap, h->d_n, st);
+    if (rc != MSF_OK) return rc;
+  }
+  if (num_mp) {
+    e = msf::count_mappoint_matches(n, h->d_out, h->stage_cap, h->d_n, h->d_idx, h->d_idx + maxp, h->d_maps, h->n_maps,
+                                    h->map_words, h->cfg.image_width, h->cfg.image_height, h->d_idx + 2 * maxp, st);
+    if (e != hipSuccess) return hip_fail(h, "count_mappoint_matches", e);
+    if ((e = hipMemcpyAsync(num_mp, h->d_idx + 2 * maxp, (size_t)n * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(h, "hipMemcpyAsync", e);
+  }
+  if ((e = hipMemcpyAsync(num_matches, h->d_n, (size_t)n * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(h, "hipMemcpyAsync", e);
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(h, "hipStreamSynchronize", e);
+  bool capacity = false;
+  for (int i = 0; i < n; i++) {
+    const int32_t c = num_matches[i];
+    if (c < 0) { capacity = true; continue; }
+    const int avail = c < h->stage_cap ? c : h->stage_cap;
+    if (out) {
+      if (avail < c && cap_per_pair > avail) capacity = true;
+      const int w = avail < cap_per_pair ? avail : cap_per_pair;
+      if (w > 0 && (e = hipMemcpy(out + (size_t)i * cap_per_pair, h->d_out + (size_t)i * h->stage_cap,
+                                  (size_t)w * sizeof(msf_match), hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(h, "hipMemcpy", e);
+    }
+  }
+  if (capacity) return fail(h, MSF_ERR_CAPACITY, "a fixed-capacity device list overflowed for at least one pair");
   return MSF_OK;
 }
 

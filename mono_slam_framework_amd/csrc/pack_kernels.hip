@@ -47,4 +47,47 @@ hipError_t pack_matches(int n, const msf_match* d_in, int cap, const int32_t* d_
   return hipGetLastError();
 }
 
+// KeyFrameMatchDatabase::DetectLoopCandidate's inner loop (slam_pipeline/src/KeyFrameDatabase.cc:37-44): the number
+// of matches whose two endpoints both carry a map point.  KeyPointMap::GetMapPoint (KeyPointMap.cc:56-87) reduces to
+// an exact lookup of the key y*cols + x (its neighbourhood loop re-reads the centre), out-of-image points have none.
+// One wave per pair; occupancy is a bitmap per frame.
+__global__ __launch_bounds__(256) void k_count_mp(int n, const msf_match* __restrict__ matches, int cap,
+                                                  const int32_t* __restrict__ cnt, const int32_t* __restrict__ map_a,
+                                                  const int32_t* __restrict__ map_b, const uint32_t* __restrict__ maps,
+                                                  int n_maps, int map_words, int width, int height,
+                                                  int32_t* __restrict__ num_mp) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (p >= n) return;
+  const int m = min(max(cnt[p], 0), cap);
+  const int sa = map_a[p], sb = map_b[p];
+  int c = 0;
+  if (sa >= 0 && sa < n_maps && sb >= 0 && sb < n_maps) {
+    const uint32_t* A = maps + (long long)sa * map_words;
+    const uint32_t* B = maps + (long long)sb * map_words;
+    const int4* src = reinterpret_cast<const int4*>(matches + (long long)p * cap);
+    for (int i = lane; i < m; i += 64) {
+      const int4 q = src[i];   // x1, y1, x2, y2
+      bool hit = (unsigned)q.x < (unsigned)width && (unsigned)q.y < (unsigned)height &&
+                 (unsigned)q.z < (unsigned)width && (unsigned)q.w < (unsigned)height;
+      if (hit) {
+        const int ka = q.y * width + q.x, kb = q.w * width + q.z;
+        hit = ((A[ka >> 5] >> (ka & 31)) & 1u) && ((B[kb >> 5] >> (kb & 31)) & 1u);
+      }
+      c += hit;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) c += __shfl_xor(c, o);
+  if (lane == 0) num_mp[p] = c;
+}
+
+hipError_t count_mappoint_matches(int n, const msf_match* d_matches, int cap, const int32_t* d_cnt,
+                                  const int32_t* d_map_a, const int32_t* d_map_b, const uint32_t* d_maps, int n_maps,
+                                  int map_words, int width, int height, int32_t* d_num_mp, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_count_mp, dim3((n + 3) / 4), dim3(256), 0, st, n, d_matches, cap, d_cnt, d_map_a, d_map_b, d_maps,
+                     n_maps, map_words, width, height, d_num_mp);
+  return hipGetLastError();
+}
+
 }  // namespace msf

@@ -110,6 +110,38 @@ class _Matcher:
                                                     d_n_out.data_ptr(), d_packed.data_ptr(), d_offsets.data_ptr(),
                                                     stream))
 
+    def set_mappoints(self, map_slot, keys):
+        """KeyPointMap occupancy of one frame: `keys` = pixel keys y*cols + x that hold a map point."""
+        keys = np.ascontiguousarray(np.asarray(keys, np.int32).reshape(-1))
+        self._check(self._L.msf_set_mappoints(self._h, map_slot, keys.ctypes.data, keys.size))
+
+    def count_mappoint_matches_device(self, d_out, d_n_out, d_map_a, d_map_b, d_num_mp, stream=None):
+        """d_num_mp[i] = matches of pair i with a map point at both endpoints (KeyFrameDatabase.cc:37-44)."""
+        self._check(self._L.msf_count_mappoint_matches_device(
+            self._h, d_out.shape[0], d_out.data_ptr(), d_out.shape[1], d_n_out.data_ptr(), d_map_a.data_ptr(),
+            d_map_b.data_ptr(), d_num_mp.data_ptr(), stream))
+
+    def store_frame(self, slot, frame):
+        """Uploads a host frame into resident frame slot `slot` (ORB: and extracts its features once)."""
+        img = self._image(frame)
+        self._check(self._L.msf_store_frame(self._h, slot, C.byref(img)))
+
+    def match_one_to_many(self, query_slot, slots, with_map_points=False, cap=0):
+        """MatchFrames(frame[query_slot], frame[s]) for s in slots, one launch sequence.
+        -> (num_matches[n], num_mp[n] or None, lists or None)"""
+        slots = np.ascontiguousarray(np.asarray(slots, np.int32).reshape(-1))
+        n = slots.size
+        num = np.zeros((n,), np.int32)
+        nmp = np.zeros((n,), np.int32) if with_map_points else None
+        out = np.zeros((n, cap), _lib.MATCH_DTYPE) if cap else None
+        self._check(self._L.msf_match_one_to_many(self._h, query_slot, n, slots.ctypes.data, num.ctypes.data,
+                                                  nmp.ctypes.data if with_map_points else None,
+                                                  out.ctypes.data if cap else None, cap))
+        lists = None
+        if cap:
+            lists = [out[i, :min(max(num[i], 0), cap)].view(np.int32).reshape(-1, 4).copy() for i in range(n)]
+        return num, nmp, lists
+
     def stage_times(self):
         names = (C.c_char_p * 16)()
         ms = (C.c_float * 16)()

@@ -9,17 +9,17 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build(tmp_path):
+def _build(tmp_path, name="test_host_mirror"):
     from mono_slam_framework_amd import build
     from oracle import orb as oracle_orb
     lib = build.lib_path()
     synth = build.ensure_synth()
     osol = oracle_orb.build()
-    exe = str(tmp_path / "test_host_mirror")
+    exe = str(tmp_path / name)
     pkg = os.path.join(ROOT, "mono_slam_framework_amd")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
                            "-I", os.path.join(pkg, "csrc"), "-I", os.path.join(ROOT, "oracle"),
-                           os.path.join(ROOT, "tests", "cpp", "test_host_mirror.cpp"), lib, synth, osol,
+                           os.path.join(ROOT, "tests", "cpp", name + ".cpp"), lib, synth, osol,
                            "-Wl,-rpath," + pkg, "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
                            "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-o", exe])
     return exe
@@ -37,5 +37,22 @@ def test_host_mirror_builds_and_fails_loudly_without_gpu(tmp_path):
 @pytest.mark.gpu
 def test_host_mirror_parity_on_gpu(tmp_path):
     exe = _build(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_keyframe_database_mirror_builds_and_fails_loudly_without_gpu(tmp_path):
+    import torch
+    exe = _build(tmp_path, "test_keyframe_db")
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "no HIP device" in r.stdout
+
+
+@pytest.mark.gpu
+def test_keyframe_database_mirror_parity_on_gpu(tmp_path):
+    """csrc/hip_keyframe_database.h vs the reference's KeyFrameDatabase.cc loops over the CPU ORB oracle"""
+    exe = _build(tmp_path, "test_keyframe_db")
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
