@@ -503,6 +503,19 @@ __global__ __launch_bounds__(256) void k_sim_stats(const float* __restrict__ fa,
   }
 }
 
+// working copies of cached per-frame tokens for the pairs (slot_a[i], slot_b[i]): z = 0 -> f0, z = 1 -> f1
+__global__ __launch_bounds__(256) void k_gather_tokens(const float* __restrict__ cache, const int32_t* __restrict__ slot_a,
+                                                       const int32_t* __restrict__ slot_b, int n_slots,
+                                                       float* __restrict__ f0, float* __restrict__ f1) {
+  const int i = blockIdx.x * 256 + threadIdx.x, pair = blockIdx.y;
+  if (i >= NTOK * DM / 4) return;
+  int slot = blockIdx.z ? slot_b[pair] : slot_a[pair];
+  slot = min(max(slot, 0), n_slots - 1);
+  const f32x4* src = reinterpret_cast<const f32x4*>(cache + (long long)slot * NTOK * DM);
+  f32x4* dst = reinterpret_cast<f32x4*>((blockIdx.z ? f1 : f0) + (long long)pair * NTOK * DM);
+  dst[i] = src[i];
+}
+
 // conf_ij = softmax_i(s)_ij * softmax_j(s)_ij, '> threshold' -> bit mask (16-bit chunk per row and column tile);
 // the 5.76 MB confidence matrix is never written (except for the debug pair).
 __global__ __launch_bounds__(256) void k_conf_mask(const float* __restrict__ f0s, const float* __restrict__ f1s,
@@ -624,6 +637,7 @@ struct LoftrPipeline::Impl {
   // workspace (per chunk of pairs)
   float *bufA = nullptr, *bufB = nullptr, *bufC = nullptr, *bufD = nullptr;
   float *tok[4] = {nullptr, nullptr, nullptr, nullptr};  // f0 f1 t0 t1, each [max_pairs][1200][32]
+  float* tok_cache = nullptr;  // [2*max_pairs][1200][32] backbone tokens per frame slot (extract / match_slots)
   float* fsc = nullptr;      // [2][max_pairs][1200][32] features / sqrt(32)
   float* kv = nullptr;       // [max_pairs][1056]
   float* rstats = nullptr;   // [max_pairs][2][1200]
@@ -829,6 +843,7 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
   LF_TRY(dalloc(&P.bufC, big));
   LF_TRY(dalloc(&P.bufD, big / 2));
   for (int i = 0; i < 4; i++) LF_TRY(dalloc(&P.tok[i], (size_t)max_pairs * NTOK * DM));
+  LF_TRY(dalloc(&P.tok_cache, (size_t)2 * max_pairs * NTOK * DM));
   LF_TRY(dalloc(&P.fsc, (size_t)2 * max_pairs * NTOK * DM));
   LF_TRY(dalloc(&P.kv, (size_t)max_pairs * (DM * DM + DM)));
   LF_TRY(dalloc(&P.rstats, (size_t)max_pairs * 2 * NTOK));
@@ -873,6 +888,16 @@ void launch_conv(const ConvDesc& c, const void* in, long long in_img_stride, int
 
 }  // namespace
 
+namespace {
+
+// Backbone (ConvertImageToFloat + 21 convs + positional encoding) for one chunk of images: nA frames from srcA
+// followed by nB frames from srcB (either may be 0); their tokens go to tokA / tokB.  A frame's tokens do not depend
+// on the frame it is paired with, which is what the per-frame token cache below rests on.
+void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* tokA, const uint8_t* srcB, int nB,
+                  float* tokB, long long frame_stride, int row_stride, hipStream_t st);
+
+}  // namespace
+
 hipError_t LoftrPipeline::match(int n_pairs, const uint8_t* d_a, const uint8_t* d_b, long long frame_stride,
                                 int row_stride, float threshold, msf_match* d_out, int cap, int32_t* d_n_out,
                                 hipStream_t st) {
@@ -885,42 +910,90 @@ hipError_t LoftrPipeline::match(int n_pairs, const uint8_t* d_a, const uint8_t* 
   // ---- backbone, in chunks of pairs (activations are the big buffers); tokens of all pairs are kept
   for (int p0 = 0; p0 < n_pairs; p0 += P.chunk) {
     const int n = std::min(P.chunk, n_pairs - p0);
-    const int ni = 2 * n;  // images: [0, n) = frame 1 of each pair, [n, 2n) = frame 2
-    const ConvDesc* c = P.conv;
-    float *a = P.bufA, *b = P.bufB, *cc = P.bufC, *d = P.bufD;
-    const long long s8 = 8LL * 240 * 320;
-    // the stem reads u8 frames from two arrays: launch it per array
-    launch_conv<1, 8, 7, 2, 64, true, false, true>(c[0], d_a + (long long)p0 * frame_stride, frame_stride, row_stride, nullptr, a, n, st);
-    launch_conv<1, 8, 7, 2, 64, true, false, true>(c[0], d_b + (long long)p0 * frame_stride, frame_stride, row_stride, nullptr, a + (long long)n * s8, n, st);
-    // layer1 @240x320, 8 ch
-    launch_conv<8, 8, 3, 1, 64, true, false, false, 2>(c[1], a, s8, 0, nullptr, b, ni, st);
-    launch_conv<8, 8, 3, 1, 64, true, true, false, 2>(c[2], b, s8, 0, a, cc, ni, st);
-    launch_conv<8, 8, 3, 1, 64, true, false, false, 2>(c[3], cc, s8, 0, nullptr, b, ni, st);
-    launch_conv<8, 8, 3, 1, 64, true, true, false, 2>(c[4], b, s8, 0, cc, a, ni, st);                 // a = 196
-    // layer2 @120x160, 16 ch
-    const long long s16 = 16LL * 120 * 160;
-    launch_conv<8, 16, 3, 2, 32, true, false, false, 1, true>(c[5], a, s8, 0, nullptr, b, ni, st, &c[7], d);   // + shortcut -> d
-    launch_conv<16, 16, 3, 1, 32, true, true, false>(c[6], b, s16, 0, d, cc, ni, st);              // cc = 205
-    launch_conv<16, 16, 3, 1, 32, true, false, false>(c[8], cc, s16, 0, nullptr, b, ni, st);
-    launch_conv<16, 16, 3, 1, 32, true, true, false>(c[9], b, s16, 0, cc, a, ni, st);              // a = 212
-    // layer3 @60x80, 32 ch
-    const long long s32 = 32LL * 60 * 80;
-    launch_conv<16, 32, 3, 2, 16, true, false, false, 1, true>(c[10], a, s16, 0, nullptr, b, ni, st, &c[12], d);
-    launch_conv<32, 32, 3, 1, 16, true, true, false>(c[11], b, s32, 0, d, cc, ni, st);             // cc = 221
-    launch_conv<32, 32, 3, 1, 16, true, false, false>(c[13], cc, s32, 0, nullptr, b, ni, st);
-    launch_conv<32, 32, 3, 1, 16, true, true, false>(c[14], b, s32, 0, cc, a, ni, st);             // a = 228
-    // layer4 @30x40, 32 ch
-    const long long s40 = 32LL * 30 * 40;
-    launch_conv<32, 32, 3, 2, 16, true, false, false, 1, true>(c[15], a, s32, 0, nullptr, b, ni, st, &c[17], d);
-    launch_conv<32, 32, 3, 1, 16, true, true, false>(c[16], b, s40, 0, d, cc, ni, st);             // cc = 237
-    launch_conv<32, 32, 3, 1, 16, true, false, false>(c[18], cc, s40, 0, nullptr, b, ni, st);
-    launch_conv<32, 32, 3, 1, 16, true, true, false>(c[19], b, s40, 0, cc, a, ni, st);             // a = 244
-    launch_conv<32, 32, 1, 1, 16, false, false, false>(c[20], a, s40, 0, nullptr, b, ni, st);      // b = 245
-    // tokens: images [0,n) -> tok[0] (feat0), [n,2n) -> tok[1] (feat1), at this chunk's pair offset
-    hipLaunchKernelGGL(k_tokens, dim3((n * NTOK * DM + 255) / 256), dim3(256), 0, st, b, P.d_pe, P.tok[0] + p0 * ts, n);
-    hipLaunchKernelGGL(k_tokens, dim3((n * NTOK * DM + 255) / 256), dim3(256), 0, st, b + (long long)n * s40, P.d_pe, P.tok[1] + p0 * ts, n);
+    run_backbone(P, d_a + (long long)p0 * frame_stride, n, P.tok[0] + p0 * ts, d_b + (long long)p0 * frame_stride, n,
+                 P.tok[1] + p0 * ts, frame_stride, row_stride, st);
   }
   if (ev) hipEventRecord(ev[1], st);
+  return transformer_and_head(n_pairs, threshold, d_out, cap, d_n_out, st);
+}
+
+// "next" row 1 of SURVEY.md 8f for LoFTR: the backbone runs once per frame, its tokens stay in a slot.
+hipError_t LoftrPipeline::extract(int n_frames, const uint8_t* d_frames, long long frame_stride, int row_stride,
+                                  int first_slot, hipStream_t st) {
+  if (!p_) return hipErrorNotInitialized;
+  Impl& P = *p_;
+  if (n_frames < 0 || first_slot < 0 || first_slot + n_frames > 2 * P.max_pairs) return hipErrorInvalidValue;
+  const long long ts = (long long)NTOK * DM;
+  for (int f0 = 0; f0 < n_frames; f0 += 2 * P.chunk) {
+    const int n = std::min(2 * P.chunk, n_frames - f0);
+    run_backbone(P, d_frames + (long long)f0 * frame_stride, n, P.tok_cache + (long long)(first_slot + f0) * ts, nullptr,
+                 0, nullptr, frame_stride, row_stride, st);
+  }
+  return hipGetLastError();
+}
+
+hipError_t LoftrPipeline::match_slots(int n_pairs, const int32_t* d_slot_a, const int32_t* d_slot_b, float threshold,
+                                      msf_match* d_out, int cap, int32_t* d_n_out, hipStream_t st) {
+  if (!p_) return hipErrorNotInitialized;
+  Impl& P = *p_;
+  if (n_pairs > P.max_pairs) return hipErrorInvalidValue;
+  if (n_pairs <= 0) return hipSuccess;
+  hipEvent_t* ev = P.ev_ok ? P.ev.data() : nullptr;
+  if (ev) hipEventRecord(ev[0], st);
+  hipLaunchKernelGGL(k_gather_tokens, dim3(NTOK * DM / 4 / 256 + 1, n_pairs, 2), dim3(256), 0, st, P.tok_cache,
+                     d_slot_a, d_slot_b, 2 * P.max_pairs, P.tok[0], P.tok[1]);
+  if (ev) hipEventRecord(ev[1], st);
+  return transformer_and_head(n_pairs, threshold, d_out, cap, d_n_out, st);
+}
+
+int LoftrPipeline::max_slots() const { return p_ ? 2 * p_->max_pairs : 0; }
+
+namespace {
+
+void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* tokA, const uint8_t* srcB, int nB,
+                  float* tokB, long long frame_stride, int row_stride, hipStream_t st) {
+  const int ni = nA + nB;
+  const ConvDesc* c = P.conv;
+  float *a = P.bufA, *b = P.bufB, *cc = P.bufC, *d = P.bufD;
+  const long long s8 = 8LL * 240 * 320;
+  // the stem reads u8 frames from up to two arrays: launch it per array
+  if (nA) launch_conv<1, 8, 7, 2, 64, true, false, true>(c[0], srcA, frame_stride, row_stride, nullptr, a, nA, st);
+  if (nB) launch_conv<1, 8, 7, 2, 64, true, false, true>(c[0], srcB, frame_stride, row_stride, nullptr, a + (long long)nA * s8, nB, st);
+  // layer1 @240x320, 8 ch
+  launch_conv<8, 8, 3, 1, 64, true, false, false, 2>(c[1], a, s8, 0, nullptr, b, ni, st);
+  launch_conv<8, 8, 3, 1, 64, true, true, false, 2>(c[2], b, s8, 0, a, cc, ni, st);
+  launch_conv<8, 8, 3, 1, 64, true, false, false, 2>(c[3], cc, s8, 0, nullptr, b, ni, st);
+  launch_conv<8, 8, 3, 1, 64, true, true, false, 2>(c[4], b, s8, 0, cc, a, ni, st);                 // a = 196
+  // layer2 @120x160, 16 ch
+  const long long s16 = 16LL * 120 * 160;
+  launch_conv<8, 16, 3, 2, 32, true, false, false, 1, true>(c[5], a, s8, 0, nullptr, b, ni, st, &c[7], d);   // + shortcut -> d
+  launch_conv<16, 16, 3, 1, 32, true, true, false>(c[6], b, s16, 0, d, cc, ni, st);              // cc = 205
+  launch_conv<16, 16, 3, 1, 32, true, false, false>(c[8], cc, s16, 0, nullptr, b, ni, st);
+  launch_conv<16, 16, 3, 1, 32, true, true, false>(c[9], b, s16, 0, cc, a, ni, st);              // a = 212
+  // layer3 @60x80, 32 ch
+  const long long s32 = 32LL * 60 * 80;
+  launch_conv<16, 32, 3, 2, 16, true, false, false, 1, true>(c[10], a, s16, 0, nullptr, b, ni, st, &c[12], d);
+  launch_conv<32, 32, 3, 1, 16, true, true, false>(c[11], b, s32, 0, d, cc, ni, st);             // cc = 221
+  launch_conv<32, 32, 3, 1, 16, true, false, false>(c[13], cc, s32, 0, nullptr, b, ni, st);
+  launch_conv<32, 32, 3, 1, 16, true, true, false>(c[14], b, s32, 0, cc, a, ni, st);             // a = 228
+  // layer4 @30x40, 32 ch
+  const long long s40 = 32LL * 30 * 40;
+  launch_conv<32, 32, 3, 2, 16, true, false, false, 1, true>(c[15], a, s32, 0, nullptr, b, ni, st, &c[17], d);
+  launch_conv<32, 32, 3, 1, 16, true, true, false>(c[16], b, s40, 0, d, cc, ni, st);             // cc = 237
+  launch_conv<32, 32, 3, 1, 16, true, false, false>(c[18], cc, s40, 0, nullptr, b, ni, st);
+  launch_conv<32, 32, 3, 1, 16, true, true, false>(c[19], b, s40, 0, cc, a, ni, st);             // a = 244
+  launch_conv<32, 32, 1, 1, 16, false, false, false>(c[20], a, s40, 0, nullptr, b, ni, st);      // b = 245
+  if (nA) hipLaunchKernelGGL(k_tokens, dim3((nA * NTOK * DM + 255) / 256), dim3(256), 0, st, b, P.d_pe, tokA, nA);
+  if (nB) hipLaunchKernelGGL(k_tokens, dim3((nB * NTOK * DM + 255) / 256), dim3(256), 0, st, b + (long long)nA * 32LL * 30 * 40, P.d_pe, tokB, nB);
+}
+
+}  // namespace
+
+hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf_match* d_out, int cap,
+                                               int32_t* d_n_out, hipStream_t st) {
+  Impl& P = *p_;
+  const long long ts = (long long)NTOK * DM;
+  hipEvent_t* ev = P.ev_ok ? P.ev.data() : nullptr;
   // ---- 8 encoder blocks over all pairs: (x, source) -> dst   [self, self, cross, cross(updated feat0)] x 2
   const int n = n_pairs;
   float *f0 = P.tok[0], *f1 = P.tok[1], *t0 = P.tok[2], *t1 = P.tok[3];

@@ -21,11 +21,20 @@ class LoftrPipeline {
   void destroy();
   hipError_t match(int n_pairs, const uint8_t* d_a, const uint8_t* d_b, long long frame_stride, int row_stride,
                    float threshold, msf_match* d_out, int cap_per_pair, int32_t* d_n_out, hipStream_t st);
+  // per-frame token cache: frame -> slot [0, 2*max_pairs), then pairs of slots
+  hipError_t extract(int n_frames, const uint8_t* d_frames, long long frame_stride, int row_stride, int first_slot,
+                     hipStream_t st);
+  hipError_t match_slots(int n_pairs, const int32_t* d_slot_a, const int32_t* d_slot_b, float threshold,
+                         msf_match* d_out, int cap_per_pair, int32_t* d_n_out, hipStream_t st);
+  int max_slots() const;
   int debug_get(int what, int slot, int level, void* host_out, size_t cap, size_t* n_bytes, std::string* err);
   int stage_times(const char** names, float* ms, int cap);
 
- private:
   struct Impl;
+
+ private:
+  hipError_t transformer_and_head(int n_pairs, float threshold, msf_match* d_out, int cap_per_pair, int32_t* d_n_out,
+                                  hipStream_t st);
   Impl* p_ = nullptr;
 };
 

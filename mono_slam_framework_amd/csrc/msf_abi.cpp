@@ -268,16 +268,23 @@ int msf_extract_device(msf_handle* h, int32_t n_frames, const uint8_t* d_frames,
                        int64_t row_stride, int32_t first_slot, void* stream) {
   if (!h) return MSF_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> lk(h->mu);
-  if (h->cfg.kind != MSF_KIND_ORB) return fail(h, MSF_ERR_UNSUPPORTED, "msf_extract_device: ORB handles only");
-  if (n_frames < 0 || !d_frames || first_slot < 0 || first_slot + n_frames > h->orb.max_slots())
+  const bool is_orb = h->cfg.kind == MSF_KIND_ORB;
+  if (n_frames < 0 || !d_frames || first_slot < 0 ||
+      first_slot + n_frames > (is_orb ? h->orb.max_slots() : h->loftr.max_slots()))
     return fail(h, MSF_ERR_INVALID_ARG, "msf_extract_device: slot range outside [0, 2*max_batch_pairs)");
   if (((uintptr_t)d_frames | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 15)
     return fail(h, MSF_ERR_INVALID_ARG, "device frames must be 16-byte aligned with strides multiple of 16");
   hipError_t e = hipSetDevice(h->cfg.device);
   if (e != hipSuccess) return hip_fail(h, "hipSetDevice", e);
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-  msf::FrameSrc src{d_frames, d_frames, n_frames, first_slot, frame_stride, (int)row_stride};
-  if ((e = h->orb.extract(src, n_frames, st)) != hipSuccess) return hip_fail(h, "orb extract", e);
+  if (row_stride < h->cfg.image_width || frame_stride < row_stride * (long long)h->cfg.image_height)
+    return fail(h, MSF_ERR_INVALID_ARG, "msf_extract_device: strides smaller than the frame");
+  if (is_orb) {
+    msf::FrameSrc src{d_frames, d_frames, n_frames, first_slot, frame_stride, (int)row_stride};
+    if ((e = h->orb.extract(src, n_frames, st)) != hipSuccess) return hip_fail(h, "orb extract", e);
+  } else if ((e = h->loftr.extract(n_frames, d_frames, frame_stride, (int)row_stride, first_slot, st)) != hipSuccess) {
+    return hip_fail(h, "loftr extract", e);
+  }
   if (!stream && (e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(h, "hipStreamSynchronize", e);
   return MSF_OK;
 }
@@ -286,14 +293,16 @@ int msf_match_slots_device(msf_handle* h, int32_t n_pairs, const int32_t* d_slot
                            msf_match* d_out, int32_t cap_per_pair, int32_t* d_n_out, void* stream) {
   if (!h) return MSF_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> lk(h->mu);
-  if (h->cfg.kind != MSF_KIND_ORB) return fail(h, MSF_ERR_UNSUPPORTED, "msf_match_slots_device: ORB handles only");
   if (n_pairs < 0 || !d_slot_a || !d_slot_b || !d_out || !d_n_out || cap_per_pair < 1)
     return fail(h, MSF_ERR_INVALID_ARG, "msf_match_slots_device: bad argument");
   hipError_t e = hipSetDevice(h->cfg.device);
   if (e != hipSuccess) return hip_fail(h, "hipSetDevice", e);
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-  if ((e = h->orb.match(n_pairs, d_slot_a, d_slot_b, h->cfg.threshold, d_out, cap_per_pair, d_n_out, st)) != hipSuccess)
-    return hip_fail(h, "orb match", e);
+  if (n_pairs > h->cfg.max_batch_pairs) return fail(h, MSF_ERR_INVALID_ARG, "n_pairs exceeds max_batch_pairs");
+  e = h->cfg.kind == MSF_KIND_ORB
+          ? h->orb.match(n_pairs, d_slot_a, d_slot_b, h->cfg.threshold, d_out, cap_per_pair, d_n_out, st)
+          : h->loftr.match_slots(n_pairs, d_slot_a, d_slot_b, h->cfg.threshold, d_out, cap_per_pair, d_n_out, st);
+  if (e != hipSuccess) return hip_fail(h, "match slots", e);
   if (!stream && (e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(h, "hipStreamSynchronize", e);
   return MSF_OK;
 }
@@ -374,6 +383,8 @@ int msf_store_frame(msf_handle* h, int32_t slot, const msf_image* img) {
   if (h->cfg.kind == MSF_KIND_ORB) {   // features are extracted once, here
     msf::FrameSrc src{dst, dst, 1, slot, h->stage_frame, h->stage_pitch};
     if ((e = h->orb.extract(src, 1, st)) != hipSuccess) return hip_fail(h, "orb extract", e);
+  } else if ((e = h->loftr.extract(1, dst, h->stage_frame, h->stage_pitch, slot, st)) != hipSuccess) {
+    return hip_fail(h, "loftr extract", e);   // backbone tokens of the frame, once
   }
   if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(h, "hipStreamSynchronize", e);
   return MSF_OK;
@@ -400,22 +411,10 @@ int msf_match_one_to_many(msf_handle* h, int32_t query_slot, int32_t n, const in
   for (int i = 0; i < n; i++) { h->idx_stage[i] = query_slot; h->idx_stage[maxp + i] = slots[i]; }
   if ((e = hipMemcpyAsync(h->d_idx, h->idx_stage.data(), (size_t)2 * maxp * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess)
     return hip_fail(h, "hipMemcpyAsync(idx)", e);
-  if (h->cfg.kind == MSF_KIND_ORB) {
-    if ((e = h->orb.match(n, h->d_idx, h->d_idx + maxp, h->cfg.threshold, h->d_out, h->stage_cap, h->d_n, st)) != hipSuccess)
-      return hip_fail(h, "orb match", e);
-  } else {
-    // the graph takes the two frames of a pair together: gather (query, keyframe_i) pairs from the store
-    uint8_t* dA = h->d_stage;
-    uint8_t* dB = h->d_stage + (size_t)maxp * h->stage_frame;
-    for (int i = 0; i < n; i++) {
-      if ((e = hipMemcpyAsync(dA + (size_t)i * h->stage_frame, h->d_store + (size_t)query_slot * h->stage_frame,
-                              (size_t)h->stage_frame, hipMemcpyDeviceToDevice, st)) != hipSuccess) return hip_fail(h, "hipMemcpyAsync", e);
-      if ((e = hipMemcpyAsync(dB + (size_t)i * h->stage_frame, h->d_store + (size_t)slots[i] * h->stage_frame,
-                              (size_t)h->stage_frame, hipMemcpyDeviceToDevice, st)) != hipSuccess) return hip_fail(h, "hipMemcpyAsync", e);
-    }
-    int rc = run_device(h, n, dA, dB, h->stage_frame, h->stage_pitch, h->d_out, h->stage_cap, h->d_n, st);
-    if (rc != MSF_OK) return rc;
-  }
+  e = h->cfg.kind == MSF_KIND_ORB
+          ? h->orb.match(n, h->d_idx, h->d_idx + maxp, h->cfg.threshold, h->d_out, h->stage_cap, h->d_n, st)
+          : h->loftr.match_slots(n, h->d_idx, h->d_idx + maxp, h->cfg.threshold, h->d_out, h->stage_cap, h->d_n, st);
+  if (e != hipSuccess) return hip_fail(h, "match slots", e);
   if (num_mp) {
     e = msf::count_mappoint_matches(n, h->d_out, h->stage_cap, h->d_n, h->d_idx, h->d_idx + maxp, h->d_maps, h->n_maps,
                                     h->map_words, h->cfg.image_width, h->cfg.image_height, h->d_idx + 2 * maxp, st);

@@ -104,6 +104,17 @@ class _Matcher:
             self._h, n, d_a.data_ptr(), d_b.data_ptr(), d_a.stride(0), d_a.stride(1),
             d_out.data_ptr(), cap, d_n_out.data_ptr(), stream))
 
+    def extract_device(self, d_frames, first_slot=0, stream=None):
+        """Per-frame part once (ORB features / LoFTR backbone tokens) into slots first_slot.. of the handle."""
+        self._check(self._L.msf_extract_device(self._h, d_frames.shape[0], d_frames.data_ptr(), d_frames.stride(0),
+                                               d_frames.stride(1), first_slot, stream))
+
+    def match_slots_device(self, d_slot_a, d_slot_b, d_out, d_n_out, stream=None):
+        """Pairs of slots (int32 CUDA tensors) -> match lists, as match_batch_device."""
+        self._check(self._L.msf_match_slots_device(self._h, d_slot_a.shape[0], d_slot_a.data_ptr(),
+                                                   d_slot_b.data_ptr(), d_out.data_ptr(), d_out.shape[1],
+                                                   d_n_out.data_ptr(), stream))
+
     def pack_matches_device(self, d_out, d_n_out, d_packed, d_offsets, stream=None):
         """[n, cap, 4] + counts -> contiguous [total, 4] prefix of d_packed, offsets int32 [n + 1]."""
         self._check(self._L.msf_pack_matches_device(self._h, d_out.shape[0], d_out.data_ptr(), d_out.shape[1],
@@ -164,15 +175,6 @@ class FeatureMatcher(_Matcher):
 
     def __init__(self, threshold=0.8, image_width=640, image_height=480, **kw):
         super().__init__(threshold, image_width, image_height, **kw)
-
-    def extract_device(self, d_frames, first_slot=0, stream=None):
-        self._check(self._L.msf_extract_device(self._h, d_frames.shape[0], d_frames.data_ptr(), d_frames.stride(0),
-                                               d_frames.stride(1), first_slot, stream))
-
-    def match_slots_device(self, d_slot_a, d_slot_b, d_out, d_n_out, stream=None):
-        self._check(self._L.msf_match_slots_device(self._h, d_slot_a.shape[0], d_slot_a.data_ptr(),
-                                                   d_slot_b.data_ptr(), d_out.data_ptr(), d_out.shape[1],
-                                                   d_n_out.data_ptr(), stream))
 
     def level_sizes(self):
         return self._debug(_lib.DBG_LEVEL_SIZES, 0, 0, np.int32, 8 * 4 * 4).reshape(8, 4)

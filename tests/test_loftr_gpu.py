@@ -112,3 +112,37 @@ def test_device_batch_across_backbone_chunks():
         assert cnt[i] == len(ref)
         np.testing.assert_array_equal(out[i, :cnt[i]], ref)
     np.testing.assert_array_equal(out[66, :cnt[66]], G["matches_ii_015"])
+
+
+def test_token_cache_extract_once_match_many():
+    """SURVEY.md 8f row 1 for LoFTR: backbone tokens cached per frame slot (msf_extract_device) + pairs of slots
+    (msf_match_slots_device) give exactly the lists of the two-frame path, for any pairing (a frame against itself,
+    a slot used on both sides, slots beyond one backbone chunk), and KAT (ii) through the cache is its golden list."""
+    import torch
+    n_frames = 140                                     # > one backbone chunk (128 images)
+    A, B = synth.synth_batch(950, n_frames // 2, 640, 480, mode=1)
+    F = np.concatenate([A, B])
+    F[3], F[137] = G["img0_ii"], G["img1_ii"]
+    dm = _dm(0.15, pairs=80)
+    dF = torch.from_numpy(F).cuda()
+    dm.extract_device(dF[:100], first_slot=0)
+    dm.extract_device(dF[100:], first_slot=100)        # second call, other slots
+    rng = np.random.RandomState(4)
+    sa = rng.randint(0, n_frames, 40).astype(np.int32)
+    sb = rng.randint(0, n_frames, 40).astype(np.int32)
+    sa[:3], sb[:3] = [3, 5, 139], [137, 5, 0]          # KAT pair, a frame against itself, last slot
+    out = torch.zeros((40, 2048, 4), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros((40,), dtype=torch.int32, device="cuda")
+    dm.match_slots_device(torch.from_numpy(sa).cuda(), torch.from_numpy(sb).cuda(), out, cnt)
+    out2 = torch.zeros_like(out)
+    cnt2 = torch.zeros_like(cnt)
+    dm.match_batch_device(dF[torch.from_numpy(sa).long().cuda()].contiguous(),
+                          dF[torch.from_numpy(sb).long().cuda()].contiguous(), out2, cnt2)
+    out, cnt, out2, cnt2 = out.cpu().numpy(), cnt.cpu().numpy(), out2.cpu().numpy(), cnt2.cpu().numpy()
+    np.testing.assert_array_equal(cnt, cnt2)
+    for i in range(40):
+        np.testing.assert_array_equal(out[i, :cnt[i]], out2[i, :cnt2[i]])
+    np.testing.assert_array_equal(out[0, :cnt[0]], G["matches_ii_015"])
+    assert cnt[1] > 100                                # a frame matches itself on (nearly) every cell
+    with pytest.raises(Exception):
+        dm.extract_device(dF[:2], first_slot=159)      # slots are [0, 2*max_batch_pairs)
