@@ -161,6 +161,7 @@ class SlamPipelineMatcher : public SLAM_PIPELINE::FeatureMatcher {
     return out;
   }
   void SetThreshold(float v) { impl_.SetThreshold(v); }
+  Impl& impl() { return impl_; }   // the HipMatcherBase the one-vs-many callers share (hip_keyframe_database.h)
 
  private:
   Impl impl_;
