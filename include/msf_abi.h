@@ -149,6 +149,18 @@ int msf_store_frame(msf_handle* h, int32_t slot, const msf_image* img);
 int msf_match_one_to_many(msf_handle* h, int32_t query_slot, int32_t n, const int32_t* slots, int32_t* num_matches,
                           int32_t* num_mp, msf_match* out, int32_t cap_per_pair);
 
+/* "next" row 4 of SURVEY.md 8f: Initializer::CheckHomography / CheckFundamental (slam_pipeline/src/Initializer.cc:
+ * 322-405, 407-487) for all n_hyp RANSAC hypotheses of FindHomography / FindFundamental (:152-199, :201-245) at once.
+ * m21: [n_hyp][9] row-major H21 (or F21); m12: [n_hyp][9] H12 = H21^-1 (homography only, else NULL); matches: the
+ * MatchFramesResult the Initializer was built from (mvKeys1/2, Initializer.cc:79-86); all HOST pointers.
+ * scores[i] is the reference's f32 score of hypothesis i bit for bit; *best = the hypothesis the reference loop keeps
+ * (first strict maximum above 0, -1 if none) and best_inliers[n_matches] its vbMatchesInliers (all 0 if none). */
+#define MSF_MODEL_HOMOGRAPHY 0
+#define MSF_MODEL_FUNDAMENTAL 1
+int msf_check_hypotheses(msf_handle* h, int32_t model, int32_t n_hyp, const float* m21, const float* m12,
+                         int32_t n_matches, const msf_match* matches, float sigma, float* scores, int32_t* best,
+                         uint8_t* best_inliers);
+
 /* Packs [n_pairs][cap_per_pair] match lists + counts into one contiguous device list:
  * d_offsets[i] = start of pair i, d_offsets[n_pairs] = total; pairs with n_out < 0 contribute nothing.
  * This is the payload of the multi-GPU gather of match lists (and of MatchFramesResult's vectors). */

@@ -17,6 +17,9 @@ hipError_t pack_matches(int n, const msf_match* d_in, int cap, const int32_t* d_
 hipError_t count_mappoint_matches(int n, const msf_match* d_matches, int cap, const int32_t* d_cnt,
                                   const int32_t* d_map_a, const int32_t* d_map_b, const uint32_t* d_maps, int n_maps,
                                   int map_words, int width, int height, int32_t* d_num_mp, hipStream_t st);
+hipError_t check_hypotheses(int model, int n_hyp, const float* d_m21, const float* d_m12, int n,
+                            const msf_match* d_matches, float sigma, float* d_scores, uint8_t* d_inliers,
+                            hipStream_t st);
 }
 
 namespace {
@@ -45,6 +48,11 @@ struct msf_handle {
   uint8_t* d_store = nullptr;
   int32_t* d_idx = nullptr;     // [3][max_pairs]: query slot per pair, train slot per pair, map-point counts
   std::vector<int32_t> idx_stage;
+  // msf_check_hypotheses workspace, grown on demand
+  float* d_hyp = nullptr;        // [2][hyp_cap][9] + [hyp_cap] scores
+  uint8_t* d_hyp_inl = nullptr;  // [hyp_cap * hyp_match_cap]
+  msf_match* d_hyp_m = nullptr;  // [hyp_match_cap]
+  int hyp_cap = 0, hyp_match_cap = 0;
 };
 
 namespace {
@@ -181,6 +189,9 @@ void msf_destroy(msf_handle* h) {
   hipFree(h->d_maps);
   hipFree(h->d_store);
   hipFree(h->d_idx);
+  hipFree(h->d_hyp);
+  hipFree(h->d_hyp_inl);
+  hipFree(h->d_hyp_m);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
@@ -436,6 +447,53 @@ int msf_match_one_to_many(msf_handle* h, int32_t query_slot, int32_t n, const in
     }
   }
   if (capacity) return fail(h, MSF_ERR_CAPACITY, "a fixed-capacity device list overflowed for at least one pair");
+  return MSF_OK;
+}
+
+int msf_check_hypotheses(msf_handle* h, int32_t model, int32_t n_hyp, const float* m21, const float* m12,
+                         int32_t n_matches, const msf_match* matches, float sigma, float* scores, int32_t* best,
+                         uint8_t* best_inliers) {
+  if (!h) return MSF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  const bool homography = model == MSF_MODEL_HOMOGRAPHY;
+  if ((!homography && model != MSF_MODEL_FUNDAMENTAL) || n_hyp < 0 || n_matches < 0 || n_matches > 8192 ||
+      (n_hyp > 0 && (!m21 || !scores || (homography && !m12))) || (n_matches > 0 && !matches) || !best ||
+      (n_matches > 0 && !best_inliers))
+    return fail(h, MSF_ERR_INVALID_ARG, "msf_check_hypotheses: bad argument (models 0/1, at most 8192 matches)");
+  *best = -1;
+  for (int i = 0; i < n_matches; i++) best_inliers[i] = 0;   // FindHomography: vbMatchesInliers(N, false) (Initializer.cc:167)
+  if (n_hyp == 0) return MSF_OK;
+  hipError_t e = hipSetDevice(h->cfg.device);
+  if (e != hipSuccess) return hip_fail(h, "hipSetDevice", e);
+  if (n_hyp > h->hyp_cap || n_matches > h->hyp_match_cap) {
+    hipFree(h->d_hyp); hipFree(h->d_hyp_inl); hipFree(h->d_hyp_m);
+    h->d_hyp = nullptr; h->d_hyp_inl = nullptr; h->d_hyp_m = nullptr;
+    h->hyp_cap = h->hyp_match_cap = 0;
+    const int hc = n_hyp > 256 ? n_hyp : 256, mc = n_matches > 2048 ? n_matches : 2048;
+    if ((e = hipMalloc(&h->d_hyp, (size_t)hc * 19 * sizeof(float))) != hipSuccess) return hip_fail(h, "hipMalloc", e);
+    if ((e = hipMalloc(&h->d_hyp_inl, (size_t)hc * mc)) != hipSuccess) return hip_fail(h, "hipMalloc", e);
+    if ((e = hipMalloc(&h->d_hyp_m, (size_t)mc * sizeof(msf_match))) != hipSuccess) return hip_fail(h, "hipMalloc", e);
+    h->hyp_cap = hc;
+    h->hyp_match_cap = mc;
+  }
+  hipStream_t st = h->stream;
+  float* d21 = h->d_hyp;
+  float* d12 = h->d_hyp + (size_t)9 * h->hyp_cap;
+  float* dsc = h->d_hyp + (size_t)18 * h->hyp_cap;
+  if ((e = hipMemcpyAsync(d21, m21, (size_t)n_hyp * 9 * sizeof(float), hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(h, "hipMemcpyAsync", e);
+  if (homography && (e = hipMemcpyAsync(d12, m12, (size_t)n_hyp * 9 * sizeof(float), hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(h, "hipMemcpyAsync", e);
+  if (n_matches && (e = hipMemcpyAsync(h->d_hyp_m, matches, (size_t)n_matches * sizeof(msf_match), hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(h, "hipMemcpyAsync", e);
+  if ((e = msf::check_hypotheses(model, n_hyp, d21, d12, n_matches, h->d_hyp_m, sigma, dsc, h->d_hyp_inl, st)) != hipSuccess)
+    return hip_fail(h, "check_hypotheses", e);
+  if ((e = hipMemcpyAsync(scores, dsc, (size_t)n_hyp * sizeof(float), hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(h, "hipMemcpyAsync", e);
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(h, "hipStreamSynchronize", e);
+  // FindHomography / FindFundamental keep the first hypothesis whose score beats every earlier one (:190-194, :236-240)
+  float score = 0.0f;
+  for (int i = 0; i < n_hyp; i++)
+    if (scores[i] > score) { score = scores[i]; *best = i; }
+  if (*best >= 0 && n_matches &&
+      (e = hipMemcpy(best_inliers, h->d_hyp_inl + (size_t)*best * n_matches, (size_t)n_matches, hipMemcpyDeviceToHost)) != hipSuccess)
+    return hip_fail(h, "hipMemcpy", e);
   return MSF_OK;
 }
 

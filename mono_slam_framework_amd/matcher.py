@@ -132,6 +132,21 @@ class _Matcher:
             self._h, d_out.shape[0], d_out.data_ptr(), d_out.shape[1], d_n_out.data_ptr(), d_map_a.data_ptr(),
             d_map_b.data_ptr(), d_num_mp.data_ptr(), stream))
 
+    def check_hypotheses(self, model, m21, m12, matches, sigma=1.0):
+        """Initializer::CheckHomography (model 0: m21 = H21, m12 = H12) / CheckFundamental (model 1: m21 = F21) for
+        all RANSAC hypotheses [n_hyp, 3, 3] on the match list [n, 4] (Initializer.cc:152-245, 322-487).
+        -> (best index or -1, scores f32 [n_hyp], vbMatchesInliers of the best [n])"""
+        m21 = np.ascontiguousarray(m21, np.float32).reshape(-1, 9)
+        m12 = None if m12 is None else np.ascontiguousarray(m12, np.float32).reshape(-1, 9)
+        m = np.ascontiguousarray(matches, np.int32).reshape(-1, 4)
+        scores = np.zeros(len(m21), np.float32)
+        inl = np.zeros(max(len(m), 1), np.uint8)
+        best = C.c_int32(-1)
+        self._check(self._L.msf_check_hypotheses(self._h, model, len(m21), m21.ctypes.data,
+                                                 None if m12 is None else m12.ctypes.data, len(m), m.ctypes.data,
+                                                 float(sigma), scores.ctypes.data, C.byref(best), inl.ctypes.data))
+        return best.value, scores, inl[:len(m)].astype(bool)
+
     def store_frame(self, slot, frame):
         """Uploads a host frame into resident frame slot `slot` (ORB: and extracts its features once)."""
         img = self._image(frame)
