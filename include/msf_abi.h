@@ -121,7 +121,7 @@ int msf_match_batch_device(msf_handle* h, int32_t n_pairs, const uint8_t* d_a, c
 /* "next" row 1 of SURVEY.md 8f: extract once per frame, match many.  The per-frame part -- ORB key points and
  * descriptors, or the LoFTR backbone tokens ([1200][32] f32; the backbone sees one image at a time, only the attention
  * blocks and the correlation see the pair) -- stays in the handle's device slots [0, 2*max_batch_pairs).
- * msf_match_slots_device pairs slots (DEVICE index arrays), n_pairs <= max_batch_pairs. */
+ * msf_match_slots_device pairs slots (DEVICE index arrays); LoFTR: n_pairs <= max_batch_pairs. */
 int msf_extract_device(msf_handle* h, int32_t n_frames, const uint8_t* d_frames, int64_t frame_stride,
                        int64_t row_stride, int32_t first_slot, void* stream);
 int msf_match_slots_device(msf_handle* h, int32_t n_pairs, const int32_t* d_slot_a, const int32_t* d_slot_b,

@@ -309,7 +309,8 @@ int msf_match_slots_device(msf_handle* h, int32_t n_pairs, const int32_t* d_slot
   hipError_t e = hipSetDevice(h->cfg.device);
   if (e != hipSuccess) return hip_fail(h, "hipSetDevice", e);
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-  if (n_pairs > h->cfg.max_batch_pairs) return fail(h, MSF_ERR_INVALID_ARG, "n_pairs exceeds max_batch_pairs");
+  if (h->cfg.kind != MSF_KIND_ORB && n_pairs > h->cfg.max_batch_pairs)   // LoFTR works on per-pair token buffers
+    return fail(h, MSF_ERR_INVALID_ARG, "n_pairs exceeds max_batch_pairs");
   e = h->cfg.kind == MSF_KIND_ORB
           ? h->orb.match(n_pairs, d_slot_a, d_slot_b, h->cfg.threshold, d_out, cap_per_pair, d_n_out, st)
           : h->loftr.match_slots(n_pairs, d_slot_a, d_slot_b, h->cfg.threshold, d_out, cap_per_pair, d_n_out, st);

@@ -58,9 +58,16 @@ __device__ __forceinline__ uint32_t udot2_u16(uint32_t a, uint32_t b, uint32_t c
 // LDS is read as ALIGNED dwords and the two taps are cut out with v_alignbyte: adjacent byte reads get fused by
 // the compiler into misaligned ds_read_u16, which the LDS replays (measured: 5x slower kernel).
 // Taps with weight 0 may read one byte past the image: staged as 0 (or padding), times 0.
-__global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uint8_t* pyr,
-                                                const uint32_t* __restrict__ tab, int l, int rth, int lds_rows) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t rt[];
+// The kernel is VALU-bound, not HBM-bound, so the per-column work (tap offset, alignbyte shift, weight pair) is done
+// once per task of 4 px x 4 rows instead of once per output dword, the per-row work comes from a small LDS table, and
+// task / row decoding uses host-computed reciprocals instead of integer division (25 -> 12 VALU instructions per px).
+constexpr int kResizeMaxRows = 16;     // output rows per band (rth) upper bound
+__global__ __launch_bounds__(512) void k_resize(OrbGeometry g, FrameSrc src, uint8_t* pyr,
+                                                const uint32_t* __restrict__ tab, int l, int rth, int lds_rows,
+                                                uint32_t magic_n16, uint32_t magic_groups) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t* ysh = reinterpret_cast<uint32_t*>(smem);   // [kResizeMaxRows] per output row: LDS word base | wyp-source
+  uint8_t* rt = smem + 4 * kResizeMaxRows * 2;
   const int fi = blockIdx.y;
   const OrbLevelInfo L = g.lv[l];
   const int sh = g.lv[l - 1].h, sw16 = (g.lv[l - 1].w + 16 + 15) & ~15;   // staged row: source width + 16 zero/pad bytes
@@ -69,13 +76,19 @@ __global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uin
   uint8_t* d = pyr + (long long)(src.slot0 + fi) * g.pyr_bytes + L.pix_off;
   const uint32_t* xtab = tab + L.tab_off;      // per x: xofs | w1 << 16
   const uint32_t* ytab = xtab + ((L.w + 3) & ~3);
-  const int Y0 = blockIdx.x * rth, tid = threadIdx.x;
+  const int Y0 = blockIdx.x * rth, tid = threadIdx.x, nthr = blockDim.x;
   const int ylast = min(Y0 + rth, L.h) - 1;
   const int sy0 = ytab[Y0] & 0xFFFF;
   const int nrow = min((int)(ytab[ylast] & 0xFFFF) + 2 - sy0, lds_rows);
-  const int n16 = sw16 >> 4;
-  for (int i = tid; i < nrow * n16; i += 256) {
-    const int r = i / n16, c = i - r * n16;
+  const int n16 = sw16 >> 4, n4 = sw16 >> 2, rows = ylast - Y0 + 1;
+  if (tid < rows) {
+    const uint32_t yt = ytab[Y0 + tid];
+    const uint32_t wy1 = yt >> 16;
+    ysh[2 * tid] = (uint32_t)(((int)(yt & 0xFFFF) - sy0) * n4);       // LDS word index of the upper source row
+    ysh[2 * tid + 1] = (256u - wy1) | (wy1 << 16);                     // (w0, w1) as a u16 pair for v_dot2_u32_u16
+  }
+  for (int i = tid; i < nrow * n16; i += nthr) {
+    const int r = (int)__umulhi((uint32_t)i, magic_n16), c = i - r * n16;   // i / n16 (exact for i < 2^16)
     const int gx = 16 * c, gy = sy0 + r;
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     if (gy < sh && gx + 16 <= spitch) v = *reinterpret_cast<const uint4*>(s + (long long)gy * spitch + gx);
@@ -83,33 +96,41 @@ __global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uin
   }
   __syncthreads();
   const uint32_t* T = reinterpret_cast<const uint32_t*>(rt);
-  const int n4 = sw16 >> 2, groups = (L.w + 3) >> 2, rows = ylast - Y0 + 1;
-  for (int i = tid; i < rows * groups; i += 256) {
-    const int ry = i / groups, gq = i - ry * groups;
-    const int y = Y0 + ry, x4 = 4 * gq;
-    const uint32_t yt = ytab[y];
-    const uint32_t wy1 = yt >> 16;
-    const uint32_t wyp = (256u - wy1) | (wy1 << 16);                // (w0, w1) as a u16 pair for v_dot2_u32_u16
-    const int rbase = ((int)(yt & 0xFFFF) - sy0) * n4;
+  const int groups = (L.w + 3) >> 2, rgs = (rows + 3) >> 2;
+  for (int i = tid; i < rgs * groups; i += nthr) {
+    const int rg = magic_groups ? (int)__umulhi((uint32_t)i, magic_groups) : i, gq = i - rg * groups;   // i / groups
+    const int x4 = 4 * gq;
     const uint4 xt = *reinterpret_cast<const uint4*>(xtab + x4);   // table is padded to a multiple of 4 entries
     const uint32_t xe[4] = {xt.x, xt.y, xt.z, xt.w};
-    uint32_t packed = 0;
+    int w0[4];
+    uint32_t shf[4], wxp[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const int cx = xe[k] & 0xFFFF;
-      const uint32_t wx1 = xe[k] >> 16;
-      const uint32_t wxp = (256u - wx1) | (wx1 << 16);
-      const int w0i = rbase + (cx >> 2);
-      const uint32_t a = __builtin_amdgcn_alignbyte(T[w0i + 1], T[w0i], cx & 3);            // row sy:   p[cx], p[cx+1]
-      const uint32_t c = __builtin_amdgcn_alignbyte(T[w0i + n4 + 1], T[w0i + n4], cx & 3);  // row sy+1
-      // bytes (p0, p1) -> u16 pair, then w0*p0 + w1*p1 in one v_dot2_u32_u16 (<= 255 * 256: fits 16 bits)
-      const uint32_t h0 = udot2_u16(__builtin_amdgcn_perm(0u, a, 0x0c010c00u), wxp, 0u);
-      const uint32_t h1 = udot2_u16(__builtin_amdgcn_perm(0u, c, 0x0c010c00u), wxp, 0u);
-      uint32_t v = udot2_u16(h0 | (h1 << 16), wyp, 32768u) >> 16;
-      v = v > 255u ? 255u : v;
-      packed |= v << (8 * k);
+      const uint32_t cx = xe[k] & 0xFFFFu, wx1 = xe[k] >> 16;
+      w0[k] = (int)(cx >> 2);
+      shf[k] = cx & 3u;
+      wxp[k] = (256u - wx1) | (wx1 << 16);
     }
-    *reinterpret_cast<uint32_t*>(d + (long long)y * L.pitch + x4) = packed;  // pitch % 16 == 0, pad bytes are never read as pixels
+    const int ry0 = 4 * rg, ry1 = min(ry0 + 4, rows);
+    for (int ry = ry0; ry < ry1; ry++) {
+      const int rbase = (int)ysh[2 * ry];
+      const uint32_t wyp = ysh[2 * ry + 1];
+      uint32_t packed = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int w0i = rbase + w0[k];
+        const uint32_t a = __builtin_amdgcn_alignbyte(T[w0i + 1], T[w0i], shf[k]);            // row sy:   p[cx], p[cx+1]
+        const uint32_t c = __builtin_amdgcn_alignbyte(T[w0i + n4 + 1], T[w0i + n4], shf[k]);  // row sy+1
+        // bytes (p0, p1) -> u16 pair, then w0*p0 + w1*p1 in one v_dot2_u32_u16 (<= 255 * 256: fits 16 bits)
+        const uint32_t h0 = udot2_u16(__builtin_amdgcn_perm(0u, a, 0x0c010c00u), wxp[k], 0u);
+        const uint32_t h1 = udot2_u16(__builtin_amdgcn_perm(0u, c, 0x0c010c00u), wxp[k], 0u);
+        // weights sum to 256 * 256, so the result is <= 255 without a clamp
+        const uint32_t v = udot2_u16(h0 | (h1 << 16), wyp, 32768u) >> 16;
+        packed |= v << (8 * k);
+      }
+      // pitch % 16 == 0, pad bytes are never read as pixels
+      *reinterpret_cast<uint32_t*>(d + (long long)(Y0 + ry) * L.pitch + x4) = packed;
+    }
   }
 }
 
@@ -930,13 +951,26 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
   if (ev_ok_) hipEventRecord(ev_[0], st);
   for (int l = 1; l < g.nlevels; l++) {
     const OrbLevelInfo& L = g.lv[l];
-    // band height: as many output rows as keep the staged source rows within 60 KB of LDS
+    // band height and workgroup size: the tasks (4 px x 4 rows each) of a band should fill whole passes of the
+    // workgroup; staged source rows stay within 60 KB of LDS
     const int sw16 = (g.lv[l - 1].w + 16 + 15) & ~15;
-    int rth = 8;   // 8 measured best on 720p (4: 3.86 ms, 8: 3.53, 16: 3.66, 32: 5.10 per 2048 frames)
-    while (rth > 1 && ((rth * 5 + 3) / 4 + 3) * sw16 > 60000) rth >>= 1;
+    const int groups = (L.w + 3) >> 2;
+    int rth = 8, threads = 256;
+    double best = 0.0;
+    for (int r : {8, 12, 16}) {
+      if (((r * 5 + 3) / 4 + 3) * sw16 > 60000) continue;
+      for (int t = 256; t <= 512; t += 64) {
+        const int tasks = groups * (r / 4);
+        const double eff = (double)tasks / ((double)t * ((tasks + t - 1) / t)) - (r == 8 ? 0.0 : 0.02);
+        if (eff > best) { best = eff; rth = r; threads = t; }
+      }
+    }
+    while (rth > 4 && ((rth * 5 + 3) / 4 + 3) * sw16 > 60000) rth -= 4;
     const int lds_rows = (rth * 5 + 3) / 4 + 3;
-    hipLaunchKernelGGL(k_resize, dim3((L.h + rth - 1) / rth, n), dim3(256), (size_t)lds_rows * sw16, st, g, src, d_pyr_,
-                       d_tab_, l, rth, lds_rows);
+    const uint32_t magic_n16 = (uint32_t)(0x100000000ull / (uint32_t)(sw16 >> 4)) + 1u;
+    const uint32_t magic_groups = groups > 1 ? (uint32_t)(0x100000000ull / (uint32_t)groups) + 1u : 0u;
+    hipLaunchKernelGGL(k_resize, dim3((L.h + rth - 1) / rth, n), dim3(threads), (size_t)lds_rows * sw16 + 8 * kResizeMaxRows,
+                       st, g, src, d_pyr_, d_tab_, l, rth, lds_rows, magic_n16, magic_groups);
   }
   if (ev_ok_) hipEventRecord(ev_[1], st);
   if (g.total_tiles > 0)
