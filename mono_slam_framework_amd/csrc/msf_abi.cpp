@@ -288,7 +288,8 @@ int msf_extract_device(msf_handle* h, int32_t n_frames, const uint8_t* d_frames,
   hipError_t e = hipSetDevice(h->cfg.device);
   if (e != hipSuccess) return hip_fail(h, "hipSetDevice", e);
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-  if (row_stride < h->cfg.image_width || frame_stride < row_stride * (long long)h->cfg.image_height)
+  if (row_stride < h->cfg.image_width ||
+      (n_frames > 1 && frame_stride < row_stride * (long long)h->cfg.image_height))   // one frame: its stride is unused
     return fail(h, MSF_ERR_INVALID_ARG, "msf_extract_device: strides smaller than the frame");
   if (is_orb) {
     msf::FrameSrc src{d_frames, d_frames, n_frames, first_slot, frame_stride, (int)row_stride};

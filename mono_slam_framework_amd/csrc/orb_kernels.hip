@@ -62,7 +62,7 @@ __device__ __forceinline__ uint32_t udot2_u16(uint32_t a, uint32_t b, uint32_t c
 // once per task of 4 px x 4 rows instead of once per output dword, the per-row work comes from a small LDS table, and
 // task / row decoding uses host-computed reciprocals instead of integer division (25 -> 12 VALU instructions per px).
 constexpr int kResizeMaxRows = 16;     // output rows per band (rth) upper bound
-__global__ __launch_bounds__(512) void k_resize(OrbGeometry g, FrameSrc src, uint8_t* pyr,
+__global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uint8_t* pyr,
                                                 const uint32_t* __restrict__ tab, int l, int rth, int lds_rows,
                                                 uint32_t magic_n16, uint32_t magic_groups) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -951,20 +951,13 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
   if (ev_ok_) hipEventRecord(ev_[0], st);
   for (int l = 1; l < g.nlevels; l++) {
     const OrbLevelInfo& L = g.lv[l];
-    // band height and workgroup size: the tasks (4 px x 4 rows each) of a band should fill whole passes of the
-    // workgroup; staged source rows stay within 60 KB of LDS
+    // band height: 8 output rows x 256 threads measured best (rth 4: 3.26 ms, 8: 2.71, 12: 2.77, 16: 2.74 per 2048
+    // 720p frames; workgroup sizes chosen to fill whole passes of 4 px x 4 row tasks -- 320..512 threads -- were
+    // slower, 2.99: more, smaller workgroups hide the stage-then-compute latency better than full lanes do)
     const int sw16 = (g.lv[l - 1].w + 16 + 15) & ~15;
     const int groups = (L.w + 3) >> 2;
-    int rth = 8, threads = 256;
-    double best = 0.0;
-    for (int r : {8, 12, 16}) {
-      if (((r * 5 + 3) / 4 + 3) * sw16 > 60000) continue;
-      for (int t = 256; t <= 512; t += 64) {
-        const int tasks = groups * (r / 4);
-        const double eff = (double)tasks / ((double)t * ((tasks + t - 1) / t)) - (r == 8 ? 0.0 : 0.02);
-        if (eff > best) { best = eff; rth = r; threads = t; }
-      }
-    }
+    int rth = 8;
+    const int threads = 256;
     while (rth > 4 && ((rth * 5 + 3) / 4 + 3) * sw16 > 60000) rth -= 4;
     const int lds_rows = (rth * 5 + 3) / 4 + 3;
     const uint32_t magic_n16 = (uint32_t)(0x100000000ull / (uint32_t)(sw16 >> 4)) + 1u;
