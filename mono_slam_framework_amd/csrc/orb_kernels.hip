@@ -213,7 +213,7 @@ __device__ __forceinline__ uint32_t reserve_packed(uint32_t mine, uint32_t* coun
 
 constexpr int kFastThreads = 256;   // 320 (two full prefilter passes) measured slower: 5 waves sit unevenly on 4 SIMDs
 __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
-                                                       uint32_t* cand_cnt, uint2* cand) {
+                                                       uint32_t* cand_cnt, uint32_t* cand_key, uint8_t* cand_sc) {
   __shared__ __attribute__((aligned(16))) uint8_t px[PW2 * PH2];
   __shared__ __attribute__((aligned(16))) uint8_t sc[PW2 * PH2 + 2 * SCO];   // one dword of slack either side
   __shared__ uint16_t list1[kList1Cap];
@@ -369,28 +369,61 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
   if (tid == 0) gbase = atomicAdd(&cand_cnt[slot * kOrbLevels + l], n);
   __syncthreads();
   const uint32_t base = gbase;
-  uint2* out = cand + (long long)slot * g.cand_total + L.cand_off;
+  // structure of arrays: the retainBest threshold pass reads every score (1 byte) but only a few hundred keys
+  uint32_t* outk = cand_key + (long long)slot * g.cand_total + L.cand_off;
+  uint8_t* outs = cand_sc + (long long)slot * g.cand_total + L.cand_off;
   for (uint32_t i = tid; i < n; i += kFastThreads)
-    if (base + i < (uint32_t)L.cand_cap) out[base + i] = llist[i];
+    if (base + i < (uint32_t)L.cand_cap) {
+      const uint2 e = llist[i];
+      outk[base + i] = e.x;
+      outs[base + i] = (uint8_t)e.y;
+    }
 }
 
 // ------------------------------------------------------------------ K5+K6: retainBest(2N) by FAST score, Harris response
 // HarrisResponses (orb.cpp), blockSize 7, k = 0.04, on the unblurred level.
+// One lane per candidate.  The 9 x 9 neighbourhood comes in as 27 aligned dwords (3 per row; scattered byte loads --
+// ~190 per candidate -- made the texture addresser the bottleneck: 0.67 ms of this stage per 2048 frames), and the
+// Sobel sums are separable dot products on bytes biased by 128 (differences and the 1-2-1 sums of differences are
+// unaffected by the bias):  G[row][j] = p[j+1] - p[j-1],  H[row][j] = p[j-1] + 2 p[j] + p[j+1] - 512,
+//   Ix[r][j] = G[r-1][j] + 2 G[r][j] + G[r+1][j],   Iy[r][j] = H[r+1][j] - H[r-1][j]   (all int32, exact).
 __device__ __forceinline__ float harris_at(const uint8_t* img, int step, int x0, int y0) {
+  const int xb = (x0 - 4) & ~3;
+  const uint32_t o = (uint32_t)(x0 - 4) & 3u;
+  const uint8_t* base = img + (long long)(y0 - 4) * step + xb;
+  constexpr int kWG = 0x000100FF;                                 // weights (-1, 0, +1, 0) on bytes 0..3
+  constexpr int kWH = 0x00010201;                                 // weights ( 1, 2,  1, 0)
+  int Gm2[7], Gm1[7], Hm2[7], Hm1[7];
   int a = 0, b = 0, c = 0;
-  for (int i = -3; i <= 3; i++) {
-    const uint8_t* r0 = img + (long long)(y0 + i - 1) * step + x0;
-    const uint8_t* r1 = r0 + step;
-    const uint8_t* r2 = r1 + step;
-    for (int j = -3; j <= 3; j++) {
-      const int Ix = ((int)r1[j + 1] - (int)r1[j - 1]) * 2 + ((int)r0[j + 1] - (int)r0[j - 1]) +
-                     ((int)r2[j + 1] - (int)r2[j - 1]);
-      const int Iy = ((int)r2[j] - (int)r0[j]) * 2 + ((int)r2[j - 1] - (int)r0[j - 1]) +
-                     ((int)r2[j + 1] - (int)r0[j + 1]);
-      a += Ix * Ix;
-      b += Iy * Iy;
-      c += Ix * Iy;
+#pragma unroll
+  for (int t = 0; t < 9; t++) {
+    const uint32_t* rp = reinterpret_cast<const uint32_t*>(base + (long long)t * step);
+    const uint32_t d0 = rp[0] ^ 0x80808080u, d1 = rp[1] ^ 0x80808080u, d2 = rp[2] ^ 0x80808080u;
+    const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, o);   // px -4 .. -1 (relative to x0)
+    const uint32_t w1 = __builtin_amdgcn_alignbyte(d2, d1, o);   // px  0 ..  3
+    const uint32_t w2 = d2 >> (8u * o);                          // px  4 in byte 0
+    // windows starting at px j-1 for j = -3 .. 3 (the 4th byte has weight 0)
+    const uint32_t win[7] = {w0, __builtin_amdgcn_alignbyte(w1, w0, 1), __builtin_amdgcn_alignbyte(w1, w0, 2),
+                             __builtin_amdgcn_alignbyte(w1, w0, 3), w1, __builtin_amdgcn_alignbyte(w2, w1, 1),
+                             __builtin_amdgcn_alignbyte(w2, w1, 2)};
+    int G[7], H[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+      G[j] = __builtin_amdgcn_sdot4((int)win[j], kWG, 0, false);
+      H[j] = __builtin_amdgcn_sdot4((int)win[j], kWH, 0, false);
     }
+    if (t >= 2) {
+#pragma unroll
+      for (int j = 0; j < 7; j++) {
+        const int Ix = Gm2[j] + 2 * Gm1[j] + G[j];
+        const int Iy = H[j] - Hm2[j];
+        a += Ix * Ix;
+        b += Iy * Iy;
+        c += Ix * Iy;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 7; j++) { Gm2[j] = Gm1[j]; Gm1[j] = G[j]; Hm2[j] = Hm1[j]; Hm1[j] = H[j]; }
   }
   const float scale = 1.f / ((1 << 2) * 7 * 255.f);
   const float scale_sq_sq = scale * scale * scale * scale;
@@ -399,7 +432,8 @@ __device__ __forceinline__ float harris_at(const uint8_t* img, int step, int x0,
 }
 
 __global__ __launch_bounds__(256) void k_thr_harris(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
-                                                    const uint32_t* cand_cnt, const uint2* cand,
+                                                    const uint32_t* cand_cnt, const uint32_t* cand_key,
+                                                    const uint8_t* cand_sc,
                                                     uint32_t* s1_cnt, uint4* s1, uint32_t* status) {
   __shared__ uint32_t hist[256];
   __shared__ uint32_t thr_s, lcount;
@@ -411,12 +445,20 @@ __global__ __launch_bounds__(256) void k_thr_harris(OrbGeometry g, FrameSrc src,
     if (tid == 0) atomicOr(&status[slot], kStatusOverflow);
     n = L.cand_cap;
   }
-  const uint2* in = cand + (long long)slot * g.cand_total + L.cand_off;
+  const uint32_t* keys = cand_key + (long long)slot * g.cand_total + L.cand_off;
+  const uint8_t* scs = cand_sc + (long long)slot * g.cand_total + L.cand_off;   // 16-byte aligned (cand_off % 16 == 0)
   uint4* out = s1 + (long long)slot * g.s1_total + L.s1_off;
   hist[tid] = 0;
   if (tid == 0) lcount = 0;
   __syncthreads();
-  for (uint32_t i = tid; i < n; i += 256) atomicAdd(&hist[in[i].y & 255u], 1u);
+  // 16 scores per lane and load; bytes past n inside the last group are stale and masked by index
+  for (uint32_t i = 16u * tid; i < n; i += 16u * 256u) {
+    const uint4 v = *reinterpret_cast<const uint4*>(scs + i);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int b = 0; b < 16; b++)
+      if (i + b < n) atomicAdd(&hist[(w[b >> 2] >> (8 * (b & 3))) & 255u], 1u);
+  }
   __syncthreads();
   if (tid == 0) {
     // KeyPointsFilter::retainBest(keypoints, 2 * featuresNum): keep all >= the (2N)-th largest score
@@ -436,19 +478,27 @@ __global__ __launch_bounds__(256) void k_thr_harris(OrbGeometry g, FrameSrc src,
   const uint32_t thr = thr_s;
   int pitch;
   const uint8_t* img = level_ptr(g, src, pyr, fi, l, &pitch);
-  // pass 1: compact the kept candidates (score >= thr) into the stage-1 list, response pending
-  for (uint32_t i0 = 0; i0 < n; i0 += 256) {
-    const uint32_t i = i0 + tid;
-    uint2 c = make_uint2(0u, 0u);
-    bool keep = false;
-    if (i < n) { c = in[i]; keep = c.y >= thr; }
-    const unsigned long long q = __ballot(keep);
-    if (q) {
-      uint32_t base = 0;
-      if ((tid & 63) == 0) base = atomicAdd(&lcount, (uint32_t)__popcll(q));
-      base = __shfl(base, 0);
-      const uint32_t k = base + mbcnt64(q);
-      if (keep && k < (uint32_t)kS1Cap) out[k] = make_uint4(c.x, 0u, c.y, 0u);
+  // pass 1: compact the kept candidates (score >= thr) into the stage-1 list, response pending.  Kept candidates are
+  // a few hundred out of tens of thousands: most waves see none and move on.
+  for (uint32_t i0 = 0; i0 < n; i0 += 16u * 256u) {
+    const uint32_t i = i0 + 16u * tid;
+    uint32_t mask = 0;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (i < n) {
+      v = *reinterpret_cast<const uint4*>(scs + i);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int b = 0; b < 16; b++)
+        if (i + b < n && ((w[b >> 2] >> (8 * (b & 3))) & 255u) >= thr) mask |= 1u << b;
+    }
+    if (__ballot(mask != 0u) == 0ull) continue;
+    uint32_t k = reserve_packed(__popc(mask), &lcount, tid & 63);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    while (mask) {
+      const int b = __ffs(mask) - 1;
+      mask &= mask - 1;
+      if (k < (uint32_t)kS1Cap) out[k] = make_uint4(keys[i + b], 0u, (w[b >> 2] >> (8 * (b & 3))) & 255u, 0u);
+      k++;
     }
   }
   __syncthreads();
@@ -810,9 +860,9 @@ static void make_table(int src, int dst, uint32_t* tab) {
 OrbPipeline::~OrbPipeline() { destroy(); }
 
 void OrbPipeline::destroy() {
-  hipFree(d_pyr_); hipFree(d_tab_); hipFree(d_cand_cnt_); hipFree(d_cand_); hipFree(d_s1_cnt_); hipFree(d_s1_);
+  hipFree(d_pyr_); hipFree(d_tab_); hipFree(d_cand_cnt_); hipFree(d_cand_); hipFree(d_cand_sc_); hipFree(d_s1_cnt_); hipFree(d_s1_);
   hipFree(d_kp_); hipFree(d_desc_); hipFree(d_kp_cnt_); hipFree(d_status_);
-  d_pyr_ = nullptr; d_tab_ = nullptr; d_cand_cnt_ = nullptr; d_cand_ = nullptr; d_s1_cnt_ = nullptr;
+  d_pyr_ = nullptr; d_tab_ = nullptr; d_cand_cnt_ = nullptr; d_cand_ = nullptr; d_cand_sc_ = nullptr; d_s1_cnt_ = nullptr;
   d_s1_ = nullptr; d_kp_ = nullptr; d_desc_ = nullptr; d_kp_cnt_ = nullptr; d_status_ = nullptr;
   if (ev_ok_) for (auto& e : ev_) hipEventDestroy(e);
   ev_ok_ = false;
@@ -877,6 +927,7 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     // strict 3x3 maxima are at most w*h/4; w*h/8 covers white noise with margin (overflow is flagged, never silent)
     int cap = (int)((long long)L.w * L.h / 8);
     if (cap < 4096) cap = 4096;
+    cap = (cap + 15) & ~15;   // score bytes of a level start 16-byte aligned
     L.cand_cap = cap;
     L.cand_off = cand;
     cand += cap;
@@ -910,7 +961,8 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   MSF_HIP_TRY(hipMalloc(&d_tab_, htab.size() * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMemcpy(d_tab_, htab.data(), htab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   MSF_HIP_TRY(hipMalloc(&d_cand_cnt_, S * kOrbLevels * sizeof(uint32_t)));
-  MSF_HIP_TRY(hipMalloc(&d_cand_, S * g.cand_total * sizeof(uint2)));
+  MSF_HIP_TRY(hipMalloc(&d_cand_, S * g.cand_total * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMalloc(&d_cand_sc_, S * g.cand_total));
   MSF_HIP_TRY(hipMalloc(&d_s1_cnt_, S * kOrbLevels * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMalloc(&d_s1_, S * g.s1_total * sizeof(uint4)));
   MSF_HIP_TRY(hipMalloc(&d_kp_, S * kKpCap * sizeof(msf_keypoint)));
@@ -968,9 +1020,9 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
   if (ev_ok_) hipEventRecord(ev_[1], st);
   if (g.total_tiles > 0)
     hipLaunchKernelGGL(k_fast, dim3((unsigned)g.total_tiles * (unsigned)n), dim3(kFastThreads), 0, st, g, src, d_pyr_, d_cand_cnt_,
-                       d_cand_);
+                       d_cand_, d_cand_sc_);
   if (ev_ok_) hipEventRecord(ev_[2], st);
-  hipLaunchKernelGGL(k_thr_harris, dim3(g.nlevels, n), dim3(256), 0, st, g, src, d_pyr_, d_cand_cnt_, d_cand_,
+  hipLaunchKernelGGL(k_thr_harris, dim3(g.nlevels, n), dim3(256), 0, st, g, src, d_pyr_, d_cand_cnt_, d_cand_, d_cand_sc_,
                      d_s1_cnt_, d_s1_, d_status_);
   hipLaunchKernelGGL(k_select, dim3(n), dim3(256), 0, st, g, src.slot0, d_s1_cnt_, d_s1_, d_kp_, d_kp_cnt_,
                      d_status_);
@@ -1044,10 +1096,14 @@ int OrbPipeline::debug_get(int what, int slot, int level, void* host_out, size_t
       uint32_t n = 0;
       hipMemcpy(&n, d_cand_cnt_ + (size_t)slot * kOrbLevels + level, 4, hipMemcpyDeviceToHost);
       if (n > (uint32_t)g.lv[level].cand_cap) n = g.lv[level].cand_cap;
-      std::vector<uint2> tmp(n);
-      if (n) hipMemcpy(tmp.data(), d_cand_ + (size_t)slot * g.cand_total + g.lv[level].cand_off, n * sizeof(uint2), hipMemcpyDeviceToHost);
+      std::vector<uint32_t> tk(n);
+      std::vector<uint8_t> ts(n);
+      if (n) {
+        hipMemcpy(tk.data(), d_cand_ + (size_t)slot * g.cand_total + g.lv[level].cand_off, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        hipMemcpy(ts.data(), d_cand_sc_ + (size_t)slot * g.cand_total + g.lv[level].cand_off, n, hipMemcpyDeviceToHost);
+      }
       std::vector<int32_t> o(n * 3);
-      for (uint32_t i = 0; i < n; i++) { o[i * 3] = tmp[i].x & 0xFFFF; o[i * 3 + 1] = tmp[i].x >> 16; o[i * 3 + 2] = tmp[i].y; }
+      for (uint32_t i = 0; i < n; i++) { o[i * 3] = tk[i] & 0xFFFF; o[i * 3 + 1] = tk[i] >> 16; o[i * 3 + 2] = ts[i]; }
       *n_bytes = o.size() * 4;
       memcpy(host_out, o.data(), *n_bytes < cap ? *n_bytes : cap);
       return 0;

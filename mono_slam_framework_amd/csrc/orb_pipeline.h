@@ -80,7 +80,8 @@ class OrbPipeline {
   uint8_t* d_pyr_ = nullptr;
   uint32_t* d_tab_ = nullptr;      // resize tables: per output x / y, source offset | w1 << 16
   uint32_t* d_cand_cnt_ = nullptr; // [slots][8]
-  uint2* d_cand_ = nullptr;        // [slots][cand_total] (key, score)
+  uint32_t* d_cand_ = nullptr;     // [slots][cand_total] key = y << 16 | x
+  uint8_t* d_cand_sc_ = nullptr;   // [slots][cand_total] FAST score
   uint32_t* d_s1_cnt_ = nullptr;   // [slots][8]
   uint4* d_s1_ = nullptr;          // [slots][s1_total] (key, response bits, score, 0)
   msf_keypoint* d_kp_ = nullptr;   // [slots][kKpCap]
