@@ -653,9 +653,16 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
   uint8_t* raw = raw_s[wave];
   uint16_t* hb = hb_s[wave];
   uint32_t* raw32 = reinterpret_cast<uint32_t*>(raw);
-  for (uint32_t k0 = blockIdx.x * 4; k0 < count; k0 += gridDim.x * 4) {
-    const uint32_t k = k0 + wave;
-    const bool active = k < count;
+  // Each wave owns its LDS patch and walks its own key points: waves never wait for each other.  LDS operations of
+  // one wave are executed in issue order, so a wavefront-scope fence (compiler ordering) is all the staging needs.
+#define MSF_WAVE_SYNC()                                        \
+  do {                                                         \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     \
+    __builtin_amdgcn_wave_barrier();                           \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
+  } while (0)
+  for (uint32_t k = blockIdx.x * 4 + wave; k < count; k += gridDim.x * 4) {
+    const bool active = true;
     msf_keypoint* K = kp + (long long)slot * kKpCap + k;
     int l = 0, cx = 0, cy = 0, pitch = 0, xo = 0;
     const uint8_t* img = nullptr;
@@ -672,7 +679,7 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
         raw32[i] = *reinterpret_cast<const uint32_t*>(base + (long long)r * pitch + 4 * c);
       }
     }
-    __syncthreads();
+    MSF_WAVE_SYNC();
     float angle = 0.f;
     if (active) {
       // ICAngles (orb.cpp): the 749 pixels of the 31-px disc are spread over all 64 lanes through a table of
@@ -716,7 +723,7 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
         hb32[r * (HP / 2) + 2 * gq + 1] = sres[2] | (sres[3] << 16);
       }
     }
-    __syncthreads();
+    MSF_WAVE_SYNC();
     if (active) {
       float a, b;
       float rad = angle;
@@ -755,9 +762,10 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
       if ((lane & 1) == 0) desc[((long long)slot * kKpCap + k) * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
       if (lane == 0) K->angle = angle;
     }
-    __syncthreads();
+    MSF_WAVE_SYNC();
   }
 }
+#undef MSF_WAVE_SYNC
 
 // ------------------------------------------------------------------ K11: brute-force Hamming 2-NN + ratio + ordered compaction
 constexpr int kTrainChunk = 1024;  // train descriptors staged per LDS pass (32 KB)
