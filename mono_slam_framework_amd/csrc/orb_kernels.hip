@@ -262,8 +262,10 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
   // [31, dim-31), so only those pixels and their NMS neighbours ([30, dim-30)) can matter; the rest keeps score 0.
   constexpr int kLo = kEdge - 1;
   const int txlo = max(-1, kLo - x0), txhi = min(TW, L.w - kLo - 1 - x0);   // scored tile-x range
+  const bool inner1 = txlo == -1 && txhi == TW && y0 - 1 >= kLo && y0 + TH < L.h - kLo;
   for (int i0 = 0; i0 < GPR * SH; i0 += kFastThreads) {
     const int i = i0 + tid;
+    if (i0 + (tid & ~63) >= GPR * SH) continue;       // wave-uniform: the last pass has work for two waves only
     const int ic = i < GPR * SH ? i : GPR * SH - 1;   // idle lanes recompute the last task, masked below
     const int sr = ic / GPR, gq = ic % GPR;        // score row, 4-px group
     const int ty = sr - 1, tx0 = 4 * gq - 4;
@@ -279,9 +281,12 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
     const uint32_t b8 = __builtin_amdgcn_lerp(l8, kLerpBright, 0), b12 = __builtin_amdgcn_lerp(l12, kLerpBright, 0);
     const uint32_t n0 = __builtin_amdgcn_lerp(l0, kLerpNotDark, 0), n4 = __builtin_amdgcn_lerp(l4, kLerpNotDark, 0);
     const uint32_t n8 = __builtin_amdgcn_lerp(l8, kLerpNotDark, 0), n12 = __builtin_amdgcn_lerp(l12, kLerpNotDark, 0);
-    // the score tile spans tile +- 1
+    // the score tile spans tile +- 1 (group 0 holds only x = -1, group 17 only x = TW)
     uint32_t vm = 0;
-    {
+    if (inner1) {   // uniform: the whole score tile lies inside the scored domain
+      vm = gq == 0 ? 0x80000000u : gq == GPR - 1 ? 0x00000080u : 0x80808080u;
+      vm = i < GPR * SH ? vm : 0u;
+    } else {
       const int gy = y0 + ty;
       int first = txlo - tx0, last = txhi - tx0;         // valid bytes: first .. last
       first = first < 0 ? 0 : first;
@@ -329,6 +334,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
     const uint32_t* S = reinterpret_cast<const uint32_t*>(sc) + SCO / 4;
     constexpr int SPD = PW2 / 4;                                    // score-tile pitch in dwords
     const int txlo3 = max(0, kEdge - x0), txhi3 = min(TW - 1, L.w - kEdge - 1 - x0);   // 31-px border
+    const bool inner3 = txlo3 == 0 && txhi3 == TW - 1;
     for (int i = tid; i < (TW / 4) * TH; i += kFastThreads) {
       const int ty = i / (TW / 4), j = i % (TW / 4);
       const int w = (ty + HY) * SPD + HX / 4 + j;
@@ -349,10 +355,14 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
         keep &= __builtin_amdgcn_lerp(C, ~D, 0);
         keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(D, Dl, 3), 0);
         keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(Dr, D, 1), 0);
-        int first = txlo3 - 4 * j, last = txhi3 - 4 * j;
-        first = first < 0 ? 0 : first;
-        last = last > 3 ? 3 : last;
-        keep &= first <= last ? (0x80808080u << (8 * first)) & (0x80808080u >> (8 * (3 - last))) : 0u;
+        if (!inner3) {   // uniform: only tiles that touch the 31-px border mask columns
+          int first = txlo3 - 4 * j, last = txhi3 - 4 * j;
+          first = first < 0 ? 0 : first;
+          last = last > 3 ? 3 : last;
+          keep &= first <= last ? (0x80808080u << (8 * first)) & (0x80808080u >> (8 * (3 - last))) : 0u;
+        } else {
+          keep &= 0x80808080u;
+        }
       }
       const uint32_t mine = __popc(keep);
       uint32_t k = reserve_packed(mine, &lcount, lane);
