@@ -30,16 +30,17 @@ constexpr int MASK_WORDS = 38;  // ceil(1200 / 32)
 // D[16 px][16 cout] += A[16 px][4 k] * B[4 k][16 cout]; k enumerates (ky, kx, cin) with cin fastest.
 // Block = 4 waves; wave w computes output row oy0 + w, OTW pixels wide, all output channels.
 // RP = 2 ("row packing", for COUT = 8): the 16 MFMA columns carry 8 output channels of TWO adjacent output rows; k then
-// spans KS + 1 input rows, with zero weights where a row does not contribute (75 % useful MFMA work instead of 50 %).
+// spans KS + S input rows, with zero weights where a row does not contribute (3x3 stride 1: 75 % useful MFMA work
+// instead of 50 %; the 7x7 stride-2 stem: 16 k steps per row pair instead of 2 x 13).
 template <int CIN, int COUT, int KS, int S, int OTW, bool RELU, bool RES, bool U8IN, int RP = 1>
 struct ConvCfg {
-  static_assert(RP == 1 || (RP == 2 && S == 1 && COUT * RP <= 16), "row packing: stride 1, 2 * COUT <= 16");
+  static_assert(RP == 1 || (RP == 2 && COUT * RP <= 16), "row packing: 2 * COUT <= 16");
   static constexpr int OTH = 4 * RP;
   static constexpr int MT = OTW / 16;
   static constexpr int NT = (COUT * RP + 15) / 16;
   static constexpr int NPAD = NT * 16;
   static constexpr int PAD = KS / 2;
-  static constexpr int KY = KS + RP - 1;            // input rows spanned by one MFMA column group
+  static constexpr int KY = KS + S * (RP - 1);      // input rows spanned by one MFMA column group
   static constexpr int IN_H = (OTH - 1) * S + KS;
   static constexpr int IN_W = (OTW - 1) * S + KS;
   // the tile is staged with 16-byte global loads: its first column is the 4-float-aligned x just left of the
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void k_conv(const void* __restrict__ in_, long
           int k = step * 4 + kq;
           k = k < C::KTOT ? k : C::KTOT - 1;
           const int ky = k / KS, kx = k - ky * KS;
-          a_off = (wave * S + ky) * C::PITCH + kx + C::XO;
+          a_off = (wave * RP * S + ky) * C::PITCH + kx + C::XO;
         }
         float av[C::MT];
 #pragma unroll
@@ -791,17 +792,19 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
             wb[(size_t)k * npad + co] = (*w)[(((size_t)co * c.cin + ci) * c.ks + ky) * c.ks + kx];
           }
     LF_TRY(upload(wb, &c.d_w));
-    if (c.cin == 8 && c.cout == 8 && c.ks == 3 && c.stride == 1) {
-      // row-packed weights: k = ((ky4 * 3 + kx) * 8 + ci) over 4 input rows, column = row_sel * 8 + co
-      const int kt2 = 4 * 3 * 8, ks2 = kt2 / 4;   // 24 steps = 6 groups of 4
-      std::vector<float> w2((size_t)ks2 * 4 * 16, 0.f);
+    if (c.cout == 8 && (c.stride == 1 || c.cin == 1)) {
+      // row-packed weights (RP = 2): k = ((kyy * ks + kx) * cin + ci) over ks + stride input rows,
+      // column = row_sel * 8 + co; output row rs sees input rows stride * rs .. stride * rs + ks - 1
+      const int kyy = c.ks + c.stride, kt2 = kyy * c.ks * c.cin, ks2 = (kt2 + 3) / 4;
+      const int g2 = ks2 >= 4 ? 4 : ks2, ks2_pad = ((ks2 + g2 - 1) / g2) * g2;   // = ConvCfg::NG * G
+      std::vector<float> w2((size_t)ks2_pad * 4 * 16, 0.f);
       for (int rs = 0; rs < 2; rs++)
         for (int co = 0; co < 8; co++)
-          for (int ci = 0; ci < 8; ci++)
-            for (int ky = 0; ky < 3; ky++)
-              for (int kx = 0; kx < 3; kx++) {
-                const int k = ((ky + rs) * 3 + kx) * 8 + ci;   // output row rs sees input rows rs .. rs+2
-                w2[(size_t)k * 16 + rs * 8 + co] = (*w)[(((size_t)co * 8 + ci) * 3 + ky) * 3 + kx];
+          for (int ci = 0; ci < c.cin; ci++)
+            for (int ky = 0; ky < c.ks; ky++)
+              for (int kx = 0; kx < c.ks; kx++) {
+                const int k = ((ky + c.stride * rs) * c.ks + kx) * c.cin + ci;
+                w2[(size_t)k * 16 + rs * 8 + co] = (*w)[(((size_t)co * c.cin + ci) * c.ks + ky) * c.ks + kx];
               }
       LF_TRY(upload(w2, &c.d_w2));
     }
@@ -981,8 +984,8 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
   float *a = P.bufA, *b = P.bufB, *cc = P.bufC, *d = P.bufD;
   const long long s8 = 8LL * 240 * 320;
   // the stem reads u8 frames from up to two arrays: launch it per array
-  if (nA) launch_conv<1, 8, 7, 2, 64, true, false, true>(c[0], srcA, frame_stride, row_stride, nullptr, a, nA, st);
-  if (nB) launch_conv<1, 8, 7, 2, 64, true, false, true>(c[0], srcB, frame_stride, row_stride, nullptr, a + (long long)nA * s8, nB, st);
+  if (nA) launch_conv<1, 8, 7, 2, 64, true, false, true, 2>(c[0], srcA, frame_stride, row_stride, nullptr, a, nA, st);
+  if (nB) launch_conv<1, 8, 7, 2, 64, true, false, true, 2>(c[0], srcB, frame_stride, row_stride, nullptr, a + (long long)nA * s8, nB, st);
   // layer1 @240x320, 8 ch
   launch_conv<8, 8, 3, 1, 64, true, false, false, 2>(c[1], a, s8, 0, nullptr, b, ni, st);
   launch_conv<8, 8, 3, 1, 64, true, true, false, 2>(c[2], b, s8, 0, a, cc, ni, st);
