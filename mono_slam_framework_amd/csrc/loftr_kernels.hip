@@ -485,9 +485,29 @@ __device__ __forceinline__ void load8(const float* p, float* v) {
 // exp is the hardware v_exp_f32 path (__expf, ~2 ulp): confidences move by < 1e-6, far inside the 1e-3 bar.
 // Row statistics (max, sum of exp) of S = A B^T / 0.1; called with (f0s, f1s) for the rows and with (f1s, f0s) for
 // the columns: the products commute and are summed in the same order, so both calls see bit-identical s_ij.
+// EMIT (the column call, when row statistics exist): conf_ij <= softmax_j(s)_ij = exp(s - rm_i) / rsum_i, so only
+// entries with s >= lim_i = rm_i + log(threshold * rsum_i) - margin can pass the threshold -- at most 1 / (0.99 thr)
+// per row.  They are appended to a per-pair candidate list (i, j, s) and evaluated exactly by k_conf_cand once the
+// column statistics are complete; the similarity GEMM is not recomputed a third time.
+constexpr int kCandPerRow = 21;                       // >= 1 / (0.99 * kCandMinThreshold)
+constexpr float kCandMinThreshold = 0.05f;            // below this the dense k_conf_mask pass is used
+constexpr int kCandCap = NTOK * kCandPerRow;          // per pair; cannot overflow for thresholds >= kCandMinThreshold
+struct SimCand { uint32_t ij; float s; };
+
+__global__ __launch_bounds__(256) void k_row_limits(const float* __restrict__ rstats, long long stats_stride,
+                                                    float threshold, float* __restrict__ lim, int n_pairs) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n_pairs * NTOK) return;
+  const int pair = idx / NTOK, i = idx - pair * NTOK;
+  const float* rs = rstats + (long long)pair * stats_stride;
+  lim[idx] = rs[i] + __logf(threshold * rs[NTOK + i]) - 1e-2f;
+}
+
+template <bool EMIT>
 __global__ __launch_bounds__(256) void k_sim_stats(const float* __restrict__ fa, const float* __restrict__ fb,
                                                    long long pair_stride, float* __restrict__ stats /*[pair][2][1200]*/,
-                                                   long long stats_stride) {
+                                                   long long stats_stride, const float* __restrict__ lim,
+                                                   SimCand* __restrict__ cand, uint32_t* __restrict__ cand_cnt) {
   const int pair = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tl = lane & 15, g = lane >> 4;
   const int it = blockIdx.x * 4 + wave;
   if (it >= NTOK / 16) return;
@@ -502,11 +522,33 @@ __global__ __launch_bounds__(256) void k_sim_stats(const float* __restrict__ fa,
     f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int sI = 0; sI < 8; sI++) d = mfma4(a[sI], b[sI], d);
+    float sv[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const float s = d[r] / 0.1f;
+      sv[r] = s;
       if (s > mx[r]) { sm[r] = sm[r] * __expf(mx[r] - s) + 1.f; mx[r] = s; }
       else sm[r] += __expf(s - mx[r]);
+    }
+    if (EMIT) {
+      // here the tile is S^T: this lane holds s_ij for i = jt*16 + tl (the row of S) and j = it*16 + 4g + r
+      const int i = jt * 16 + tl;
+      const float li = lim[(long long)pair * NTOK + i];
+      const bool h0 = sv[0] >= li, h1 = sv[1] >= li, h2 = sv[2] >= li, h3 = sv[3] >= li;
+      if (__any(h0 | h1 | h2 | h3)) {
+        const uint32_t nh = (uint32_t)h0 + h1 + h2 + h3;
+        if (nh) {
+          uint32_t k = atomicAdd(&cand_cnt[pair], nh);
+          SimCand* c = cand + (long long)pair * kCandCap;
+          const bool hs[4] = {h0, h1, h2, h3};
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            if (hs[r]) {
+              if (k < (uint32_t)kCandCap) c[k] = SimCand{(uint32_t)i | ((uint32_t)(it * 16 + 4 * g + r) << 16), sv[r]};
+              k++;
+            }
+        }
+      }
     }
   }
   // combine the 16 lanes (columns) that share each row
@@ -594,6 +636,26 @@ __global__ __launch_bounds__(256) void k_conf_mask(const float* __restrict__ f0s
   }
 }
 
+// Exact confidence of the candidates (same expression and operand values as k_conf_mask, so the same bits) and the
+// '> threshold' bit of each into the (zeroed) mask.
+__global__ __launch_bounds__(256) void k_conf_cand(const SimCand* __restrict__ cand, const uint32_t* __restrict__ cand_cnt,
+                                                   const float* __restrict__ rstats, const float* __restrict__ cstats,
+                                                   long long stats_stride, float threshold, uint32_t* __restrict__ mask) {
+  const int pair = blockIdx.y;
+  const uint32_t n = min(cand_cnt[pair], (uint32_t)kCandCap);
+  const SimCand* c = cand + (long long)pair * kCandCap;
+  const float* rs = rstats + (long long)pair * stats_stride;
+  const float* cs = cstats + (long long)pair * stats_stride;
+  uint32_t* mk = mask + (long long)pair * NTOK * MASK_WORDS;
+  for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+    const SimCand e = c[k];
+    const int i = e.ij & 0xFFFF, j = e.ij >> 16;
+    const float s = e.s;
+    const float conf = (__expf(s - cs[j]) / cs[NTOK + j]) * (__expf(s - rs[i]) / rs[NTOK + i]);
+    if (conf > threshold) atomicOr(&mk[i * MASK_WORDS + (j >> 5)], 1u << (j & 31));
+  }
+}
+
 // findNonZero row-major + decode (dnnfeaturematcher.cpp:80-99): one workgroup per pair scans the bit mask in order.
 __global__ __launch_bounds__(256) void k_decode(const uint32_t* __restrict__ mask, msf_match* __restrict__ out, int cap,
                                                 int32_t* __restrict__ n_out) {
@@ -668,6 +730,10 @@ struct LoftrPipeline::Impl {
   float* rstats = nullptr;   // [max_pairs][2][1200]
   float* cstats = nullptr;
   uint32_t* mask = nullptr;  // [max_pairs][1200][38]
+  float* lim = nullptr;      // [max_pairs][1200] candidate bound per row of S
+  SimCand* cand = nullptr;   // [max_pairs][kCandCap]
+  uint32_t* cand_cnt = nullptr;
+  bool dense_head = false;
   float* conf_dbg = nullptr; // [1200][1200]
   float* feat_dbg = nullptr; // [2][1200][32]
   int dbg_pair = 0;
@@ -743,6 +809,7 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
   Impl& P = *p_;
   P.max_pairs = max_pairs;
   {
+    if (const char* d = getenv("MSF_LOFTR_DENSE_HEAD")) P.dense_head = atoi(d) != 0;   // tests: force the dense head
     const char* e = getenv("MSF_LOFTR_CHUNK");   // pairs per backbone pass (activation working set)
     const int want = e ? atoi(e) : 64;
     P.chunk = max_pairs < want ? max_pairs : (want > 0 ? want : 64);
@@ -881,6 +948,14 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
     P.mask = reinterpret_cast<uint32_t*>(m);
     // the last 16-bit chunk of every row (bits 1200 .. 1215) is never written: keep it zero
     LF_TRY(hipMemset(P.mask, 0, (size_t)max_pairs * NTOK * MASK_WORDS * sizeof(uint32_t)));
+  }
+  LF_TRY(dalloc(&P.lim, (size_t)max_pairs * NTOK));
+  {
+    float* m = nullptr;
+    LF_TRY(dalloc(&m, (size_t)max_pairs * kCandCap * 2));
+    P.cand = reinterpret_cast<SimCand*>(m);
+    LF_TRY(dalloc(&m, (size_t)max_pairs));
+    P.cand_cnt = reinterpret_cast<uint32_t*>(m);
   }
   LF_TRY(dalloc(&P.conf_dbg, (size_t)NTOK * NTOK));
   LF_TRY(dalloc(&P.feat_dbg, (size_t)2 * NTOK * DM));
@@ -1038,11 +1113,26 @@ hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf
   hipLaunchKernelGGL(k_scale_feats, dim3((unsigned)((n * ts + 255) / 256)), dim3(256), 0, st, f0, f0s, n * ts);
   hipLaunchKernelGGL(k_scale_feats, dim3((unsigned)((n * ts + 255) / 256)), dim3(256), 0, st, f1, f1s, n * ts);
   const int head_blocks = (NTOK / 16 + 3) / 4;
-  hipLaunchKernelGGL(k_sim_stats, dim3(head_blocks, n), dim3(256), 0, st, f0s, f1s, ts, P.rstats, 2LL * NTOK);
-  hipLaunchKernelGGL(k_sim_stats, dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats, 2LL * NTOK);
-  // pair 0's confidence matrix + features are kept for the parity tests
-  hipLaunchKernelGGL(k_conf_mask, dim3(head_blocks, n), dim3(256), 0, st, f0s, f1s, ts, P.rstats, P.cstats, 2LL * NTOK,
-                     threshold, P.mask, P.conf_dbg, 0);
+  hipLaunchKernelGGL(k_sim_stats<false>, dim3(head_blocks, n), dim3(256), 0, st, f0s, f1s, ts, P.rstats, 2LL * NTOK, nullptr,
+                     nullptr, nullptr);
+  if (threshold >= kCandMinThreshold && !P.dense_head) {
+    // sparse path: the column pass lists the few entries per row that can pass, k_conf_cand evaluates them exactly
+    hipMemsetAsync(P.cand_cnt, 0, (size_t)n * sizeof(uint32_t), st);
+    hipMemsetAsync(P.mask, 0, (size_t)n * NTOK * MASK_WORDS * sizeof(uint32_t), st);
+    hipLaunchKernelGGL(k_row_limits, dim3((n * NTOK + 255) / 256), dim3(256), 0, st, P.rstats, 2LL * NTOK, threshold, P.lim, n);
+    hipLaunchKernelGGL(k_sim_stats<true>, dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats, 2LL * NTOK, P.lim,
+                       P.cand, P.cand_cnt);
+    // pair 0's confidence matrix (+ its mask, densely) is kept for the parity tests
+    hipLaunchKernelGGL(k_conf_mask, dim3(head_blocks, 1), dim3(256), 0, st, f0s, f1s, ts, P.rstats, P.cstats, 2LL * NTOK,
+                       threshold, P.mask, P.conf_dbg, 0);
+    hipLaunchKernelGGL(k_conf_cand, dim3(8, n), dim3(256), 0, st, P.cand, P.cand_cnt, P.rstats, P.cstats, 2LL * NTOK, threshold,
+                       P.mask);
+  } else {
+    hipLaunchKernelGGL(k_sim_stats<false>, dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats, 2LL * NTOK, nullptr,
+                       nullptr, nullptr);
+    hipLaunchKernelGGL(k_conf_mask, dim3(head_blocks, n), dim3(256), 0, st, f0s, f1s, ts, P.rstats, P.cstats, 2LL * NTOK,
+                       threshold, P.mask, P.conf_dbg, 0);
+  }
   hipLaunchKernelGGL(k_decode, dim3(n), dim3(256), 0, st, P.mask, d_out, cap, d_n_out);
   hipMemcpyAsync(P.feat_dbg, f0, ts * sizeof(float), hipMemcpyDeviceToDevice, st);
   hipMemcpyAsync(P.feat_dbg + ts, f1, ts * sizeof(float), hipMemcpyDeviceToDevice, st);

@@ -146,3 +146,31 @@ def test_token_cache_extract_once_match_many():
     assert cnt[1] > 100                                # a frame matches itself on (nearly) every cell
     with pytest.raises(Exception):
         dm.extract_device(dF[:2], first_slot=159)      # slots are [0, 2*max_batch_pairs)
+
+
+def test_sparse_head_equals_dense_head(monkeypatch):
+    """The head lists, per row of S, the entries that can reach the threshold (conf <= softmax_j) and evaluates only
+    those; below threshold 0.05 (and with MSF_LOFTR_DENSE_HEAD=1) every entry is evaluated.  Both must give the same
+    match lists: textured pairs, the KATs, a frame against itself (a match on nearly every cell)."""
+    A, B = synth.synth_batch(1200, 6, 640, 480, mode=1)
+    pairs = [(A[i], B[i]) for i in range(6)] + [(G["img0_ii"], G["img1_ii"]), (A[0], A[0]), (B[3], B[3])]
+    sparse = _dm(0.15, pairs=4)
+    monkeypatch.setenv("MSF_LOFTR_DENSE_HEAD", "1")
+    dense = _dm(0.15, pairs=4)
+    monkeypatch.delenv("MSF_LOFTR_DENSE_HEAD")
+    total = 0
+    for thr in (0.05, 0.0501, 0.1, 0.15, 0.3, 0.9):
+        sparse.SetThreshold(thr)
+        dense.SetThreshold(thr)
+        for i in range(0, len(pairs), 4):
+            fa = [p[0] for p in pairs[i:i + 4]]
+            fb = [p[1] for p in pairs[i:i + 4]]
+            ls = sparse.match_batch(fa, fb, cap=8192)
+            ld = dense.match_batch(fa, fb, cap=8192)
+            for a, b in zip(ls, ld):
+                np.testing.assert_array_equal(a, b)
+                total += len(a)
+    assert total > 5000
+    sparse.SetThreshold(0.02)       # below the sparse path's validity: the handle switches to the dense head itself
+    dense.SetThreshold(0.02)
+    np.testing.assert_array_equal(sparse.MatchFrames(*pairs[6], cap=8192), dense.MatchFrames(*pairs[6], cap=8192))
