@@ -717,7 +717,10 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
       constexpr uint32_t kTapLo = 18u | (34u << 8) | (49u << 16) | (55u << 24);
       constexpr uint32_t kTapHi = 49u | (34u << 8) | (18u << 16);
       uint32_t* hb32 = reinterpret_cast<uint32_t*>(hb);
-      for (int i = lane; i < PD * 10; i += 64) {
+      // 45 rows x 10 groups = 450 tasks; the last two (row 44, columns 32..39) would need a sample at x >= 13, y = 19,
+      // outside the pattern's reach (bit_pattern_31 has radius <= 18.4): 448 tasks are exactly 7 passes of the wave
+      static_assert(PD * 10 - 2 == 7 * 64, "row-blur task count");
+      for (int i = lane; i < PD * 10 - 2; i += 64) {
         const int r = i / 10, gq = i % 10;
         const uint32_t* d = raw32 + r * (PP / 4) + gq;
         const uint32_t d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];
