@@ -29,8 +29,10 @@ constexpr int kTileX0 = 16, kTileY0 = kEdge;  // tile grid origin: first output 
 constexpr uint32_t kStatusOverflow = 1u;
 
 __constant__ __attribute__((aligned(16))) signed char c_pattern[1024];
-constexpr int kDiscPad = 768;          // 749 disc pixels of ICAngles, padded with null entries to 12 x 64
-__constant__ uint32_t c_disc[kDiscPad]; // (offset in the 45 x 48 raw patch) | u << 16 | v << 24
+// ICAngles disc as 31 rows x 8 dwords of 4 pixels (u = -16 + 4k .. -13 + 4k): per dword the signed byte weights u
+// (0 outside the disc) and the 0/1 membership bytes, padded to 4 x 64 tasks
+constexpr int kDiscTasks = 256;
+__constant__ uint32_t c_disc[2 * kDiscTasks];
 
 // ------------------------------------------------------------------ helpers
 __device__ __forceinline__ const uint8_t* level_ptr(const OrbGeometry& g, const FrameSrc& src,
@@ -654,10 +656,10 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
                                                   int half_up) {
   __shared__ __attribute__((aligned(16))) uint8_t raw_s[4][PD * PP + 16];
   __shared__ __attribute__((aligned(16))) uint16_t hb_s[4][PD * HP];
-  __shared__ uint32_t disc_s[kDiscPad];
+  __shared__ uint32_t disc_s[2 * kDiscTasks];
   const int fi = blockIdx.y, slot = src.slot0 + fi;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int i = threadIdx.x; i < kDiscPad; i += 256) disc_s[i] = c_disc[i];
+  for (int i = threadIdx.x; i < 2 * kDiscTasks; i += 256) disc_s[i] = c_disc[i];
   __syncthreads();
   const uint32_t count = min(kp_cnt[slot], (uint32_t)kKpCap);
   uint8_t* raw = raw_s[wave];
@@ -692,18 +694,23 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
     MSF_WAVE_SYNC();
     float angle = 0.f;
     if (active) {
-      // ICAngles (orb.cpp): the 749 pixels of the 31-px disc are spread over all 64 lanes through a table of
-      // (offset, u, v); integer moments, so the summation order is free.  volatile: single-byte LDS reads (the
-      // compiler would otherwise fuse neighbours into misaligned wide reads, which the LDS replays)
+      // ICAngles (orb.cpp): m10 = sum u * p, m01 = sum v * p over the 31-px disc, integer, so the summation order is
+      // free.  A task is one dword of 4 pixels of one disc row: m10 += dot4(p - 128, u weights) (the -128 cancels:
+      // the u weights of a whole row sum to 0) and m01 += v * dot4(p, membership).  4 passes of the wave.
       int m10 = 0, m01 = 0;
       {
-        const volatile uint8_t* pc = raw + xo;
+        // pixel (u, v) sits at byte xo + 22 + u of raw row 22 + v; the windows start at u = -16 + 4k
+        const int dw0 = 1 + ((xo + 2) >> 2);
+        const uint32_t shf = (uint32_t)(xo + 2) & 3u;
 #pragma unroll
-        for (int it = 0; it < kDiscPad / 64; it++) {
-          const uint32_t e = disc_s[it * 64 + lane];
-          const int p = pc[e & 0xFFFFu];
-          m10 += (int)(signed char)(e >> 16) * p;
-          m01 += (int)(signed char)(e >> 24) * p;
+        for (int it = 0; it < kDiscTasks / 64; it++) {
+          const int t = it * 64 + lane;
+          const int row = t >> 3, k = t & 7;              // row = v + 15 (rows 31 are padding: zero weights)
+          const uint32_t* d = raw32 + min(row + 7, PD - 1) * (PP / 4) + dw0 + k;
+          const uint32_t pxw = __builtin_amdgcn_alignbyte(d[1], d[0], shf);
+          const uint32_t wu = disc_s[2 * t], w1 = disc_s[2 * t + 1];
+          m10 = __builtin_amdgcn_sdot4((int)(pxw ^ 0x80808080u), (int)wu, m10, false);
+          m01 += (row - 15) * (int)__builtin_amdgcn_udot4(pxw, w1, 0u, false);
         }
       }
 #pragma unroll
@@ -996,15 +1003,23 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   MSF_HIP_TRY(hipMemset(d_s1_cnt_, 0, S * kOrbLevels * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), k_orb_bit_pattern_31, 1024));
   {
-    std::vector<uint32_t> disc(kDiscPad, 0u);   // null entries: offset 0, u = v = 0 contribute nothing
-    int n = 0;
+    std::vector<uint32_t> disc(2 * kDiscTasks, 0u);   // padding tasks: zero weights
     for (int v = -15; v <= 15; v++) {
-      const int d = g.umax[v < 0 ? -v : v];
-      for (int u = -d; u <= d; u++)
-        disc[n++] = (uint32_t)((22 + v) * 48 + 22 + u) | ((uint32_t)(uint8_t)(int8_t)u << 16) | ((uint32_t)(uint8_t)(int8_t)v << 24);
+      const int dmax = g.umax[v < 0 ? -v : v];
+      for (int k = 0; k < 8; k++) {
+        uint32_t wu = 0, w1 = 0;
+        for (int b = 0; b < 4; b++) {
+          const int u = -16 + 4 * k + b;
+          if (u >= -dmax && u <= dmax) {
+            wu |= (uint32_t)(uint8_t)(int8_t)u << (8 * b);
+            w1 |= 1u << (8 * b);
+          }
+        }
+        disc[2 * ((v + 15) * 8 + k)] = wu;
+        disc[2 * ((v + 15) * 8 + k) + 1] = w1;
+      }
     }
-    if (n > kDiscPad) return "ORB: disc table overflow";
-    MSF_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_disc), disc.data(), sizeof(uint32_t) * kDiscPad));
+    MSF_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_disc), disc.data(), sizeof(uint32_t) * 2 * kDiscTasks));
   }
   if (profile_) {
     for (auto& e : ev_) MSF_HIP_TRY(hipEventCreate(&e));
