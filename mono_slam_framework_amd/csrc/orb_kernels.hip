@@ -535,6 +535,11 @@ constexpr int kSelCap = kKpCap;
 __global__ __launch_bounds__(256) void k_select(OrbGeometry g, int slot0, const uint32_t* s1_cnt, const uint4* s1,
                                                 msf_keypoint* kp, uint32_t* kp_cnt, uint32_t* status) {
   __shared__ uint4 kept[kSelCap];
+  // the two counting loops below read every response / key once per element: staged in LDS and read four at a time
+  // (they were global loads: 63 us of the 0.45 ms single-pair call)
+  constexpr int kRespCap = 4096;
+  __shared__ __attribute__((aligned(16))) float resp[kRespCap];
+  __shared__ __attribute__((aligned(16))) uint32_t keys[kSelCap];
   __shared__ uint32_t nkept;
   const int slot = slot0 + blockIdx.x, tid = threadIdx.x;
   msf_keypoint* out = kp + (long long)slot * kKpCap;
@@ -546,6 +551,10 @@ __global__ __launch_bounds__(256) void k_select(OrbGeometry g, int slot0, const 
     const uint4* in = s1 + (long long)slot * g.s1_total + L.s1_off;
     const uint32_t keep = (uint32_t)L.quota;
     if (tid == 0) nkept = 0;
+    const bool staged = n > keep && n <= (uint32_t)kRespCap;
+    const uint32_t n4 = (n + 3) >> 2;
+    if (staged)
+      for (uint32_t i = tid; i < 4 * n4; i += 256) resp[i] = i < n ? __uint_as_float(in[i].y) : -INFINITY;
     __syncthreads();
     // retainBest(N): v is kept iff fewer than N entries are strictly greater than v
     for (uint32_t i = tid; i < n; i += 256) {
@@ -554,7 +563,15 @@ __global__ __launch_bounds__(256) void k_select(OrbGeometry g, int slot0, const 
       if (n > keep) {
         const float v = __uint_as_float(e.y);
         uint32_t greater = 0;
-        for (uint32_t j = 0; j < n; j++) greater += (__uint_as_float(in[j].y) > v) ? 1u : 0u;
+        if (staged) {
+          const float4* r4 = reinterpret_cast<const float4*>(resp);
+          for (uint32_t j = 0; j < n4; j++) {
+            const float4 r = r4[j];
+            greater += (uint32_t)(r.x > v) + (uint32_t)(r.y > v) + (uint32_t)(r.z > v) + (uint32_t)(r.w > v);
+          }
+        } else {
+          for (uint32_t j = 0; j < n; j++) greater += (__uint_as_float(in[j].y) > v) ? 1u : 0u;
+        }
         k = greater < keep;
       }
       if (k) {
@@ -567,10 +584,17 @@ __global__ __launch_bounds__(256) void k_select(OrbGeometry g, int slot0, const 
     if (m > (uint32_t)kSelCap) { overflow = true; m = kSelCap; }
     if (base + m > (uint32_t)kKpCap) { overflow = true; m = kKpCap - base; }
     // canonical order inside the level: rank by (y, x)
+    const uint32_t m4 = (m + 3) >> 2;
+    for (uint32_t i = tid; i < 4 * m4; i += 256) keys[i] = i < m ? kept[i].x : 0xFFFFFFFFu;
+    __syncthreads();
     for (uint32_t i = tid; i < m; i += 256) {
       const uint4 e = kept[i];
       uint32_t rank = 0;
-      for (uint32_t j = 0; j < m; j++) rank += (kept[j].x < e.x) ? 1u : 0u;
+      const uint4* k4 = reinterpret_cast<const uint4*>(keys);
+      for (uint32_t j = 0; j < m4; j++) {
+        const uint4 kk = k4[j];
+        rank += (uint32_t)(kk.x < e.x) + (uint32_t)(kk.y < e.x) + (uint32_t)(kk.z < e.x) + (uint32_t)(kk.w < e.x);
+      }
       msf_keypoint k;
       k.lx = e.x & 0xFFFF;
       k.ly = e.x >> 16;
@@ -862,6 +886,113 @@ __global__ __launch_bounds__(256) void k_match(int n_pairs, const int32_t* slot_
   if (tid == 0) n_out[pair] = (int32_t)running;
 }
 
+// Small batches (the drop-in call is ONE pair): the same matching spread over kSplitBlocks workgroups per pair.  A
+// workgroup takes 64 queries; its four waves scan a quarter of the train descriptors each and the partial 2-NN results
+// are merged by value with ties to the lower train index -- exactly what the sequential insertion above keeps.  The
+// workgroup that finishes last (ticket counter) does the ordered compaction of the per-query results.
+constexpr int kSplitBlocks = kKpCap / 64;
+constexpr int kSplitMaxPairs = 128;
+__global__ __launch_bounds__(256) void k_match_split(int n_pairs, const int32_t* slot_a, const int32_t* slot_b,
+                                                     const msf_keypoint* kp, const uint32_t* kp_cnt,
+                                                     const uint8_t* desc, const uint32_t* status, float ratio,
+                                                     msf_match* out, int cap, int32_t* n_out, int chunk,
+                                                     uint32_t* qres, uint32_t* done) {
+  __shared__ __attribute__((aligned(16))) unsigned long long train[kTrainChunk * 4];
+  __shared__ int part[3][4][64];
+  __shared__ uint32_t wave_cnt[4];
+  __shared__ uint32_t running, last_s;
+  const int pair = blockIdx.y, qb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sa = slot_a ? slot_a[pair] : pair;
+  const int sb = slot_b ? slot_b[pair] : n_pairs + pair;
+  if ((status[sa] | status[sb]) & kStatusOverflow) {   // uniform over the pair's workgroups: nobody takes a ticket
+    if (qb == 0 && tid == 0) n_out[pair] = -1;
+    return;
+  }
+  const uint32_t n1 = min(kp_cnt[sa], (uint32_t)kKpCap), n2 = min(kp_cnt[sb], (uint32_t)kKpCap);
+  const unsigned long long* tsrc = reinterpret_cast<const unsigned long long*>(desc + (long long)sb * kKpCap * 32);
+  uint32_t* qr = qres + (long long)pair * kKpCap;
+  const uint32_t q = (uint32_t)qb * 64u + lane;
+  if ((uint32_t)qb * 64u < n1) {   // uniform
+    const bool have_q = q < n1;
+    unsigned long long q0w = 0, q1w = 0, q2w = 0, q3w = 0;
+    if (have_q) {
+      const unsigned long long* qd = reinterpret_cast<const unsigned long long*>(desc + ((long long)sa * kKpCap + q) * 32);
+      q0w = qd[0]; q1w = qd[1]; q2w = qd[2]; q3w = qd[3];
+    }
+    int d0 = 0x7fffffff, d1 = 0x7fffffff, i0 = 0x7fffffff;
+    for (uint32_t t0 = 0; t0 < n2; t0 += chunk) {
+      const uint32_t tn = min(n2 - t0, (uint32_t)chunk);
+      __syncthreads();
+      for (uint32_t i = tid; i < tn * 4; i += 256) train[i] = tsrc[(size_t)t0 * 4 + i];
+      __syncthreads();
+      const uint32_t ta = (tn * wave) >> 2, tb = (tn * (wave + 1)) >> 2;   // this wave's quarter of the chunk
+      for (uint32_t t = ta; t < tb; t++) {
+        const unsigned long long* tr = &train[t * 4];
+        const int d = __popcll(q0w ^ tr[0]) + __popcll(q1w ^ tr[1]) + __popcll(q2w ^ tr[2]) + __popcll(q3w ^ tr[3]);
+        if (d < d1) {
+          if (d < d0) { d1 = d0; d0 = d; i0 = (int)(t0 + t); }
+          else d1 = d;
+        }
+      }
+    }
+    part[0][wave][lane] = d0;
+    part[1][wave][lane] = i0;
+    part[2][wave][lane] = d1;
+    __syncthreads();
+    if (wave == 0) {
+      // quarters are visited in increasing train order inside a chunk but chunks interleave them: merge by
+      // (distance, index), which is what one sequential pass keeps
+      int b0 = 0x7fffffff, bi = 0x7fffffff, b1 = 0x7fffffff;
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        const int e0 = part[0][w][lane], ei = part[1][w][lane], e1 = part[2][w][lane];
+        if (e0 < b0 || (e0 == b0 && ei < bi)) { b1 = min(b0, e1); b0 = e0; bi = ei; }
+        else b1 = min(b1, e0);
+        b1 = min(b1, e1);
+      }
+      const bool pass = have_q && n2 >= 2 && ((float)b0 < ratio * (float)b1);
+      if (have_q) qr[q] = pass ? (0x80000000u | (uint32_t)bi) : 0u;
+    }
+  }
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) last_s = atomicAdd(&done[pair], 1u) == (uint32_t)gridDim.x - 1u;
+  __syncthreads();
+  if (!last_s) return;
+  __threadfence();
+  // ordered compaction (query order) by the last workgroup of the pair
+  if (tid == 0) { running = 0; done[pair] = 0; }
+  __syncthreads();
+  const msf_keypoint* ka = kp + (long long)sa * kKpCap;
+  const msf_keypoint* kb = kp + (long long)sb * kKpCap;
+  msf_match* o = out + (long long)pair * cap;
+  for (uint32_t q0 = 0; q0 < n1; q0 += 256) {
+    const uint32_t qq = q0 + tid;
+    const uint32_t r = qq < n1 ? __hip_atomic_load(&qr[qq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    const bool pass = (r & 0x80000000u) != 0u;
+    const unsigned long long bal = __ballot(pass);
+    const uint32_t before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    uint32_t off = running;
+    for (int w = 0; w < wave; w++) off += wave_cnt[w];
+    if (pass) {
+      const uint32_t idx = off + before;
+      if (idx < (uint32_t)cap) {
+        const uint32_t t = r & 0x7fffffffu;
+        msf_match m;
+        m.x1 = (int)ka[qq].x; m.y1 = (int)ka[qq].y;      // static_cast<int>(kp.pt.x) (featurematcher.cpp:33-38)
+        m.x2 = (int)kb[t].x; m.y2 = (int)kb[t].y;
+        o[idx] = m;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  if (tid == 0) n_out[pair] = (int32_t)running;
+}
+
 // ================================================================== host side
 static int cv_round_f(float v) { return (int)lrintf(v); }
 static int cv_round_d(double v) { return (int)lrint(v); }
@@ -888,9 +1019,9 @@ static void make_table(int src, int dst, uint32_t* tab) {
 OrbPipeline::~OrbPipeline() { destroy(); }
 
 void OrbPipeline::destroy() {
-  hipFree(d_pyr_); hipFree(d_tab_); hipFree(d_cand_cnt_); hipFree(d_cand_); hipFree(d_cand_sc_); hipFree(d_s1_cnt_); hipFree(d_s1_);
+  hipFree(d_pyr_); hipFree(d_tab_); hipFree(d_cand_cnt_); hipFree(d_cand_); hipFree(d_cand_sc_); hipFree(d_qres_); hipFree(d_done_); hipFree(d_s1_cnt_); hipFree(d_s1_);
   hipFree(d_kp_); hipFree(d_desc_); hipFree(d_kp_cnt_); hipFree(d_status_);
-  d_pyr_ = nullptr; d_tab_ = nullptr; d_cand_cnt_ = nullptr; d_cand_ = nullptr; d_cand_sc_ = nullptr; d_s1_cnt_ = nullptr;
+  d_pyr_ = nullptr; d_tab_ = nullptr; d_cand_cnt_ = nullptr; d_cand_ = nullptr; d_cand_sc_ = nullptr; d_qres_ = nullptr; d_done_ = nullptr; d_s1_cnt_ = nullptr;
   d_s1_ = nullptr; d_kp_ = nullptr; d_desc_ = nullptr; d_kp_cnt_ = nullptr; d_status_ = nullptr;
   if (ev_ok_) for (auto& e : ev_) hipEventDestroy(e);
   ev_ok_ = false;
@@ -997,6 +1128,9 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   MSF_HIP_TRY(hipMalloc(&d_desc_, S * kKpCap * 32));
   MSF_HIP_TRY(hipMalloc(&d_kp_cnt_, S * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMalloc(&d_status_, S * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMalloc(&d_qres_, (size_t)kSplitMaxPairs * kKpCap * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMalloc(&d_done_, (size_t)kSplitMaxPairs * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMemset(d_done_, 0, (size_t)kSplitMaxPairs * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMemset(d_kp_cnt_, 0, S * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMemset(d_status_, 0, S * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMemset(d_cand_cnt_, 0, S * kOrbLevels * sizeof(uint32_t)));
@@ -1063,8 +1197,14 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
   hipLaunchKernelGGL(k_select, dim3(n), dim3(256), 0, st, g, src.slot0, d_s1_cnt_, d_s1_, d_kp_, d_kp_cnt_,
                      d_status_);
   if (ev_ok_) hipEventRecord(ev_[3], st);
-  hipLaunchKernelGGL(k_describe, dim3(8, n), dim3(256), 0, st, g, src, d_pyr_, d_kp_, d_kp_cnt_, d_desc_,
-                     half_up_ ? 1 : 0);
+  {
+    // 4 key points per workgroup pass: 8 workgroups per frame keep a big batch busy; a single pair (the drop-in call)
+    // gets up to 128 so that its ~500 key points per frame are one pass instead of sixteen
+    int bx = 2048 / n;
+    bx = bx < 8 ? 8 : bx > 128 ? 128 : bx;
+    hipLaunchKernelGGL(k_describe, dim3(bx, n), dim3(256), 0, st, g, src, d_pyr_, d_kp_, d_kp_cnt_, d_desc_,
+                       half_up_ ? 1 : 0);
+  }
   if (ev_ok_) hipEventRecord(ev_[4], st);
   return hipGetLastError();
 }
@@ -1079,8 +1219,12 @@ hipError_t OrbPipeline::match(int n_pairs, const int32_t* d_slot_a, const int32_
     const int v = e ? atoi(e) : kTrainChunk;
     return v >= 16 && v <= kTrainChunk ? v : kTrainChunk;
   }();
-  hipLaunchKernelGGL(k_match, dim3(n_pairs), dim3(256), 0, st, n_pairs, d_slot_a, d_slot_b, d_kp_, d_kp_cnt_,
-                     d_desc_, d_status_, ratio, d_out, cap, d_n_out, chunk);
+  if (n_pairs <= kSplitMaxPairs && d_qres_)
+    hipLaunchKernelGGL(k_match_split, dim3(kSplitBlocks, n_pairs), dim3(256), 0, st, n_pairs, d_slot_a, d_slot_b, d_kp_,
+                       d_kp_cnt_, d_desc_, d_status_, ratio, d_out, cap, d_n_out, chunk, d_qres_, d_done_);
+  else
+    hipLaunchKernelGGL(k_match, dim3(n_pairs), dim3(256), 0, st, n_pairs, d_slot_a, d_slot_b, d_kp_, d_kp_cnt_,
+                       d_desc_, d_status_, ratio, d_out, cap, d_n_out, chunk);
   if (ev_ok_) {
     hipEventRecord(ev_[5], st);
     ev_recorded_ = true;

@@ -88,6 +88,8 @@ class OrbPipeline {
   uint8_t* d_desc_ = nullptr;      // [slots][kKpCap][32]
   uint32_t* d_kp_cnt_ = nullptr;   // [slots]
   uint32_t* d_status_ = nullptr;   // [slots]
+  uint32_t* d_qres_ = nullptr;     // [kSplitMaxPairs][kKpCap] per-query results of the small-batch matcher
+  uint32_t* d_done_ = nullptr;     // [kSplitMaxPairs] ticket counters (left at 0)
   hipEvent_t ev_[kOrbStages + 2] = {};
   bool ev_ok_ = false, ev_recorded_ = false;
   FrameSrc last_src_{};
