@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstring>
 #include <mutex>
 #include <new>
 #include <string>
@@ -35,7 +36,9 @@ struct msf_handle {
   msf::LoftrPipeline loftr;
   // staging for the host-image entry points
   uint8_t* d_stage = nullptr;   // [2 * max_pairs][H][pitch]
-  msf_match* d_out = nullptr;   // [max_pairs][stage_cap]
+  msf_match* d_out_base = nullptr;
+  msf_match* d_out = nullptr;   // [max_pairs][stage_cap] = d_out_base + 1
+  msf_match* h_pin = nullptr;   // pinned: [1 + kPinMatches]
   int32_t* d_n = nullptr;       // [max_pairs]
   int stage_pitch = 0;
   long long stage_frame = 0;
@@ -66,6 +69,7 @@ int hip_fail(msf_handle* h, const char* what, hipError_t e) {
   return fail(h, MSF_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
 
+constexpr int kPinMatches = 1024;  // matches fetched together with the count by the single-pair call
 constexpr int kStageCap = 4096;  // matches per pair kept by the host-image path (ORB <= n1 <= 2048; LoFTR: see below)
 
 int run_device(msf_handle* h, int n_pairs, const uint8_t* d_a, const uint8_t* d_b, long long frame_stride,
@@ -99,7 +103,11 @@ int ensure_stage(msf_handle* h) {
   h->stage_frame = (long long)h->stage_pitch * H;
   h->stage_cap = kStageCap;
   if ((e = hipMalloc(&h->d_stage, (size_t)2 * maxp * h->stage_frame)) != hipSuccess) return hip_fail(h, "hipMalloc stage", e);
-  if ((e = hipMalloc(&h->d_out, (size_t)maxp * h->stage_cap * sizeof(msf_match))) != hipSuccess) return hip_fail(h, "hipMalloc out", e);
+  // one leading record in front of the lists: the single-pair call puts its count there, so count + list come back
+  // in ONE device-to-host copy into pinned memory (one synchronisation per MatchFrames call instead of two)
+  if ((e = hipMalloc(&h->d_out_base, ((size_t)maxp * h->stage_cap + 1) * sizeof(msf_match))) != hipSuccess) return hip_fail(h, "hipMalloc out", e);
+  h->d_out = h->d_out_base + 1;
+  if ((e = hipHostMalloc(&h->h_pin, (size_t)(kPinMatches + 1) * sizeof(msf_match), hipHostMallocDefault)) != hipSuccess) return hip_fail(h, "hipHostMalloc", e);
   if ((e = hipMalloc(&h->d_n, (size_t)maxp * sizeof(int32_t))) != hipSuccess) return hip_fail(h, "hipMalloc n", e);
   return MSF_OK;
 }
@@ -184,7 +192,8 @@ void msf_destroy(msf_handle* h) {
   h->orb.destroy();
   h->loftr.destroy();
   hipFree(h->d_stage);
-  hipFree(h->d_out);
+  hipFree(h->d_out_base);
+  if (h->h_pin) hipHostFree(h->h_pin);
   hipFree(h->d_n);
   hipFree(h->d_maps);
   hipFree(h->d_store);
@@ -249,6 +258,27 @@ int msf_match_batch(msf_handle* h, int32_t n_pairs, const msf_image* a, const ms
                                 hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(h, "hipMemcpy2DAsync", e);
       if ((e = hipMemcpy2DAsync(dB + (size_t)i * h->stage_frame, h->stage_pitch, b[p0 + i].data, b[p0 + i].stride, W, H,
                                 hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(h, "hipMemcpy2DAsync", e);
+    }
+    if (n_pairs == 1) {   // the drop-in call: count in the record before the list, one copy, one synchronisation
+      int rc = run_device(h, 1, dA, dB, h->stage_frame, h->stage_pitch, h->d_out, h->stage_cap,
+                          reinterpret_cast<int32_t*>(h->d_out_base), st);
+      if (rc != MSF_OK) return rc;
+      int wmax = cap_per_pair < h->stage_cap ? cap_per_pair : h->stage_cap;
+      const int wfirst = wmax < kPinMatches ? wmax : kPinMatches;
+      if ((e = hipMemcpyAsync(h->h_pin, h->d_out_base, (size_t)(1 + wfirst) * sizeof(msf_match), hipMemcpyDeviceToHost, st)) != hipSuccess)
+        return hip_fail(h, "hipMemcpyAsync", e);
+      if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(h, "hipStreamSynchronize", e);
+      const int32_t c = *reinterpret_cast<const int32_t*>(h->h_pin);
+      n_out[0] = c;
+      if (c < 0) return fail(h, MSF_ERR_CAPACITY, "a fixed-capacity device list overflowed for at least one pair");
+      const int avail = c < h->stage_cap ? c : h->stage_cap;
+      const int w = avail < cap_per_pair ? avail : cap_per_pair;
+      const int w1 = w < wfirst ? w : wfirst;
+      if (w1 > 0) std::memcpy(out, h->h_pin + 1, (size_t)w1 * sizeof(msf_match));
+      if (w > w1 && (e = hipMemcpy(out + w1, h->d_out + w1, (size_t)(w - w1) * sizeof(msf_match), hipMemcpyDeviceToHost)) != hipSuccess)
+        return hip_fail(h, "hipMemcpy", e);
+      if (avail < c && cap_per_pair > avail) return fail(h, MSF_ERR_CAPACITY, "a fixed-capacity device list overflowed for at least one pair");
+      return MSF_OK;
     }
     int rc = run_device(h, n, dA, dB, h->stage_frame, h->stage_pitch, h->d_out, h->stage_cap, h->d_n, st);
     if (rc != MSF_OK) return rc;
