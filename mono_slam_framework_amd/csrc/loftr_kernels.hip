@@ -297,13 +297,14 @@ __device__ __forceinline__ float quad_sum(float v) {   // sum over the 4 lane gr
 
 // phase A: K = elu(s Wk) + 1, V = (s Wv) / 1200, KV = sum_t K_t^T V_t, Ksum = sum_t K_t.  One workgroup per source
 // sequence, 4 waves x 16-token tiles; tokens on MFMA rows so K and V tiles feed the KV product straight from registers.
-__global__ __launch_bounds__(256) void k_attn_kv(const float* __restrict__ src, long long seq_stride, BlockW w,
+constexpr int kKvWaves = 8;   // one workgroup per sequence: 8 waves (2 per SIMD) so loads and MFMAs of different waves overlap
+__global__ __launch_bounds__(64 * kKvWaves) void k_attn_kv(const float* __restrict__ src, long long seq_stride, BlockW w,
                                                  float* __restrict__ kv /*[n][1056]: KV in PD order | Ksum*/) {
   __shared__ float sWk[DM * DM], sWv[DM * DM];
-  __shared__ float red[4][DM * DM + DM];
+  __shared__ float red[kKvWaves][DM * DM + DM];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tl = lane & 15, g = lane >> 4;
   const float* s = src + (long long)blockIdx.x * seq_stride;
-  for (int i = tid; i < DM * DM; i += 256) { sWk[i] = w.wk_p[i]; sWv[i] = w.wv_p[i]; }
+  for (int i = tid; i < DM * DM; i += 64 * kKvWaves) { sWk[i] = w.wk_p[i]; sWv[i] = w.wv_p[i]; }
   __syncthreads();
   f32x4 acc[2][2];
 #pragma unroll
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(256) void k_attn_kv(const float* __restrict__ src, 
 #pragma unroll
     for (int n = 0; n < 2; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   float ksum[2] = {0.f, 0.f};
-  for (int tile = wave; tile < NTOK / 16; tile += 4) {
+  for (int tile = wave; tile < NTOK / 16; tile += kKvWaves) {
     const float* xr = s + (long long)(tile * 16 + tl) * DM + 8 * g;
     const f32x4 x0 = *reinterpret_cast<const f32x4*>(xr), x1 = *reinterpret_cast<const f32x4*>(xr + 4);
     const float xa[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
@@ -352,10 +353,15 @@ __global__ __launch_bounds__(256) void k_attn_kv(const float* __restrict__ src, 
     if (g == 0) red[wave][DM * DM + 16 * n + tl] = t;
   }
   __syncthreads();
-  for (int i = tid; i < DM * DM + DM; i += 256) red[0][i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+  for (int i = tid; i < DM * DM + DM; i += 64 * kKvWaves) {
+    float t = red[0][i];
+#pragma unroll
+    for (int w2 = 1; w2 < kKvWaves; w2++) t += red[w2][i];
+    red[0][i] = t;
+  }
   __syncthreads();
   float* o = kv + (long long)blockIdx.x * (DM * DM + DM);
-  for (int i = tid; i < DM * DM; i += 256) {     // KV as the A operand of msg = KV^T Q, PD slot order over d
+  for (int i = tid; i < DM * DM; i += 64 * kKvWaves) {     // KV as the A operand of msg = KV^T Q, PD slot order over d
     const int ln = i & 63, sl = (i >> 6) & 7, me = i >> 9;
     const int d = 16 * (sl >> 2) + 4 * (ln >> 4) + (sl & 3), e = 16 * me + (ln & 15);
     o[i] = red[0][d * DM + e];
@@ -1113,7 +1119,7 @@ hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf
       {f0, f0, t0}, {f1, f1, t1}, {t0, t1, f0}, {t1, f0, f1}, {f0, f0, t0}, {f1, f1, t1}, {t0, t1, f0}, {t1, f0, f1}};
   const int upd_blocks = (NTOK / 16 + 4 * kUpdTilesPerWave - 1) / (4 * kUpdTilesPerWave);
   for (int bi = 0; bi < 8; bi++) {
-    hipLaunchKernelGGL(k_attn_kv, dim3(n), dim3(256), 0, st, seq[bi].s, ts, P.blk[bi], P.kv);
+    hipLaunchKernelGGL(k_attn_kv, dim3(n), dim3(64 * kKvWaves), 0, st, seq[bi].s, ts, P.blk[bi], P.kv);
     hipLaunchKernelGGL(k_attn_update, dim3(upd_blocks, n), dim3(256), 0, st, seq[bi].x, ts, P.kv, P.blk[bi], seq[bi].o, ts);
   }
   if (ev) hipEventRecord(ev[2], st);
