@@ -48,12 +48,16 @@ struct ConvCfg {
   static constexpr int XO = PAD ? 4 - PAD : 0;
   static constexpr int W4 = (IN_W + XO + 3) / 4;     // float4 per tile row
   static constexpr int PITCH = 4 * W4;
-  // plane stride: == 16 (mod 32) for stride 1, odd for stride 2, so the 16 px x 2 k lanes of a
-  // ds_read_b32 group hit 32 distinct banks
+  // plane stride == 16 (mod 32), so the 16 px x 2 k lanes of a ds_read_b32 group hit 32 distinct banks.  Stride-2
+  // layers keep each tile row as two half rows (even columns, then odd columns): a fragment read of 16 pixels two
+  // columns apart is then 16 consecutive floats of one half row (stride-2 reads hit every bank twice), and a staged
+  // float4 becomes two 8-byte LDS writes instead of four scalar ones.
   static constexpr int RAW = IN_H * PITCH;
-  static constexpr int PLANE = S == 1 ? ((RAW + 15) / 32) * 32 + 16 : (RAW | 1);
+  static constexpr int PLANE = ((RAW + 15) / 32) * 32 + 16;
   static constexpr int KTOT = KY * KS * CIN;
   static constexpr int KSTEPS = (KTOT + 3) / 4;
+  // offset of tile column `col` inside a row (stride 2: even columns first, then the odd ones)
+  static __device__ __host__ constexpr int col_off(int col) { return S == 1 ? col : (col & 1) * (PITCH / 2) + (col >> 1); }
   static constexpr int G = KSTEPS >= 4 ? 4 : KSTEPS;   // k steps per weight-prefetch group
   static constexpr int NG = (KSTEPS + G - 1) / G;
 };
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(256) void k_conv(const void* __restrict__ in_, long
     const int rem = idx - c * (C::IN_H * C::W4);
     const int r = rem / C::W4;
     x4v[u] = rem - r * C::W4;
-    loff[u] = idx < TOTAL ? c * C::PLANE + r * C::PITCH + 4 * x4v[u] : -1;
+    loff[u] = idx < TOTAL ? c * C::PLANE + r * C::PITCH + (S == 1 ? 4 : 2) * x4v[u] : -1;
     const int gy = iy0 + r;
     const bool ok = idx < TOTAL && gy >= 0 && gy < Hin;
     grow[u] = !ok ? -1 : U8IN ? (long long)gy * in_row_stride : ((long long)c * Hin + gy) * Win;
@@ -143,9 +147,11 @@ __global__ __launch_bounds__(256) void k_conv(const void* __restrict__ in_, long
       if (loff[u] < 0) continue;
       float* t = &tile[loff[u]];
       if (S == 1) {
-        *reinterpret_cast<f32x4*>(t) = pre[u];        // PLANE and PITCH are multiples of 4 here
-      } else {
-        t[0] = pre[u].x; t[1] = pre[u].y; t[2] = pre[u].z; t[3] = pre[u].w;   // odd plane stride: scalar LDS writes
+        *reinterpret_cast<f32x4*>(t) = pre[u];        // PLANE and PITCH are multiples of 4
+      } else {                                         // columns 4q .. 4q+3 -> even half [2q, 2q+1], odd half [2q, 2q+1]
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<f32x2*>(t) = f32x2{pre[u].x, pre[u].z};
+        *reinterpret_cast<f32x2*>(t + C::PITCH / 2) = f32x2{pre[u].y, pre[u].w};
       }
     }
     __syncthreads();
@@ -200,16 +206,16 @@ __global__ __launch_bounds__(256) void k_conv(const void* __restrict__ in_, long
           const int kk = (step * 4) / CIN;           // (ky, kx) shared by the 4 k of this step
           const int c = (step * 4) % CIN + kq;
           const int ky = kk / KS, kx = kk - ky * KS;
-          a_off = c * C::PLANE + (wave * RP * S + ky) * C::PITCH + kx + C::XO;
+          a_off = c * C::PLANE + (wave * RP * S + ky) * C::PITCH + C::col_off(kx + C::XO);
         } else {                                      // stem: CIN = 1, k = ky * KS + kx, padded with zero weights
           int k = step * 4 + kq;
           k = k < C::KTOT ? k : C::KTOT - 1;
           const int ky = k / KS, kx = k - ky * KS;
-          a_off = (wave * RP * S + ky) * C::PITCH + kx + C::XO;
+          a_off = (wave * RP * S + ky) * C::PITCH + C::col_off(kx + C::XO);
         }
         float av[C::MT];
 #pragma unroll
-        for (int m = 0; m < C::MT; m++) av[m] = tile[a_off + (m * 16 + i) * S];
+        for (int m = 0; m < C::MT; m++) av[m] = tile[a_off + (m * 16 + i)];   // stride 2: same half row, consecutive
 #pragma unroll
         for (int m = 0; m < C::MT; m++)
 #pragma unroll
@@ -989,7 +995,7 @@ template <int CIN, int COUT, int KS, int S, int OTW, bool RELU, bool RES, bool U
 void launch_conv(const ConvDesc& c, const void* in, long long in_img_stride, int in_row_stride, const float* res,
                  float* out, int n_img, hipStream_t st, const ConvDesc* sc = nullptr, float* out_sc = nullptr) {
   using C = ConvCfg<CIN, COUT, KS, S, OTW, RELU, RES, U8IN, RP>;
-  static_assert(S == 2 || (C::PLANE % 32) == 16, "plane stride must be 16 mod 32 for stride-1 convs");
+  static_assert((C::PLANE % 32) == 16, "plane stride must be 16 mod 32");
   static_assert(C::PLANE >= C::RAW, "plane too small");
   const size_t lds = (size_t)CIN * C::PLANE * sizeof(float);
   auto kern = k_conv<CIN, COUT, KS, S, OTW, RELU, RES, U8IN, RP, SC>;
