@@ -21,7 +21,7 @@ namespace msf {
 // ------------------------------------------------------------------ constants
 constexpr int kEdge = 31;          // edgeThreshold
 constexpr int kFastT = 20;         // fastThreshold
-constexpr int TW = 64, TH = 32;    // FAST output tile
+constexpr int TW = 128, TH = 32;    // FAST output tile
 constexpr int SW = TW + 2, SH = TH + 2;    // scored region: tile + 1 halo (NMS neighbours)
 constexpr int kTileCandCap = TW * TH / 4;    // strict 3x3 maxima: at most one per 2x2
 constexpr int kTileX0 = 16, kTileY0 = kEdge;  // tile grid origin: first output column 31 rounded down to the 16-byte load grid
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uin
 }
 
 // ------------------------------------------------------------------ K3+K4: FAST-9/16 score, NMS, border, candidate list
-// Three dense phases per 64x32 tile instead of one divergent one:
+// Three dense phases per 128x32 tile instead of one divergent one:
 //  1. prefilter, 4 px per lane in one dword (SWAR): any arc of 9 contains two ADJACENT cardinal ring pixels
 //     ((0,3),(3,0),(0,-3),(-3,0)), so "some adjacent cardinal pair is all-brighter or all-darker" is necessary.
 //     Per-byte threshold tests use v_lerp_u8 as a carry-free byte adder: lerp(p, ~c) = (p + 255 - c) >> 1, and a
@@ -145,13 +145,13 @@ __global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uin
 //  2. survivors (compacted in LDS, one list per polarity) get the exact cornerScore<16>: max over the 16 arcs of the
 //     minimum over the arc, through min3/max3 window networks on the raw ring pixels; score > threshold <=> FAST_t's
 //     9-contiguous test.  Scores go into a zeroed score tile.
-//  3. strict 3x3 NMS + runByImageBorder, dense on 4 scores per lane (two passes over the 64 x 32 outputs).
+//  3. strict 3x3 NMS + runByImageBorder, dense on 4 scores per lane (two passes over the tile's outputs).
 // The kernel is VALU-issue bound: what counts is the number of vector instructions.
 constexpr int HX = 16, HY = 4;                     // pixel-tile halo: rows start 16-byte aligned (x0 - 16)
 constexpr int PW2 = TW + 2 * HX, PH2 = TH + 2 * HY;  // 96 x 40
 constexpr int SCO = 4;                              // byte offset of the score tile inside its LDS array
 // the score tile has the pixel tile's geometry (pitch PW2, same origin): one index serves both arrays
-constexpr int GPR = 18;                            // 4-px groups per score row: tile x = 4g-4 .. 4g-1
+constexpr int GPR = TW / 4 + 2;                          // 4-px groups per score row: tile x = 4g-4 .. 4g-1
 constexpr int kList1Cap = 2 * SW * SH;             // brighter-type survivors from the front, darker from the back
 constexpr uint32_t kLerpBright = 0x01010101u * (128 - kFastT / 2);  // L + K >= 256  <=>  L >= 128 + t/2
 constexpr uint32_t kLerpNotDark = 0x01010101u * (255 - (254 - kFastT) / 2);
@@ -213,7 +213,11 @@ __device__ __forceinline__ uint32_t reserve_packed(uint32_t mine, uint32_t* coun
   return base + incl - mine;
 }
 
-constexpr int kFastThreads = 256;   // 320 (two full prefilter passes) measured slower: 5 waves sit unevenly on 4 SIMDs
+// 8 waves (two per SIMD) on a 128 x 32 tile: 11.8 ms per 2048 720p frames.  Measured alternatives: 64x32 / 256 threads
+// 12.6, 64x64 / 512 12.0, 64x128 / 1024 13.5, 128x64 / 1024 12.9, 128x48 / 512 15.5, 192x32 / 512 16.0, 256x32 / 1024 13.2;
+// 320- or 768-thread workgroups sit unevenly on the 4 SIMDs.  The wider tile halves the share of the two
+// single-pixel edge groups per score row and of the halo columns.
+constexpr int kFastThreads = 512;
 __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
                                                        uint32_t* cand_cnt, uint32_t* cand_key, uint8_t* cand_sc) {
   __shared__ __attribute__((aligned(16))) uint8_t px[PW2 * PH2];
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
   const bool inner1 = txlo == -1 && txhi == TW && y0 - 1 >= kLo && y0 + TH < L.h - kLo;
   for (int i0 = 0; i0 < GPR * SH; i0 += kFastThreads) {
     const int i = i0 + tid;
-    if (i0 + (tid & ~63) >= GPR * SH) continue;       // wave-uniform: the last pass has work for two waves only
+    if (i0 + (tid & ~63) >= GPR * SH) continue;       // wave-uniform: the last pass does not fill all waves
     const int ic = i < GPR * SH ? i : GPR * SH - 1;   // idle lanes recompute the last task, masked below
     const int sr = ic / GPR, gq = ic % GPR;        // score row, 4-px group
     const int ty = sr - 1, tx0 = 4 * gq - 4;
@@ -330,8 +334,8 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
   __syncthreads();
 
   // phase 3: strict 3x3 NMS + runByImageBorder(31), dense on 4 scores per lane: "c > n" per byte is bit 7 of
-  // lerp(c, ~n) = (c + 255 - n) >> 1; non-corners hold 0 and can never be strictly greater.  The 64 x 32 outputs are
-  // exactly 16 x 32 dwords = two passes of the workgroup.
+  // lerp(c, ~n) = (c + 255 - n) >> 1; non-corners hold 0 and can never be strictly greater.  The 128 x 32 outputs are
+  // exactly 32 x 32 dwords = two passes of the workgroup.
   {
     const uint32_t* S = reinterpret_cast<const uint32_t*>(sc) + SCO / 4;
     constexpr int SPD = PW2 / 4;                                    // score-tile pitch in dwords
