@@ -32,10 +32,11 @@ constexpr int MASK_WORDS = 38;  // ceil(1200 / 32)
 // RP = 2 ("row packing", for COUT = 8): the 16 MFMA columns carry 8 output channels of TWO adjacent output rows; k then
 // spans KS + S input rows, with zero weights where a row does not contribute (3x3 stride 1: 75 % useful MFMA work
 // instead of 50 %; the 7x7 stride-2 stem: 16 k steps per row pair instead of 2 x 13).
+constexpr int kConvWaves = 4;   // waves (= output rows or row pairs) per workgroup; 8 measured slower on every layer (conv stack 8.8 -> 9.4 ms)
 template <int CIN, int COUT, int KS, int S, int OTW, bool RELU, bool RES, bool U8IN, int RP = 1>
 struct ConvCfg {
   static_assert(RP == 1 || (RP == 2 && COUT * RP <= 16), "row packing: 2 * COUT <= 16");
-  static constexpr int OTH = 4 * RP;
+  static constexpr int OTH = kConvWaves * RP;
   static constexpr int MT = OTW / 16;
   static constexpr int NT = (COUT * RP + 15) / 16;
   static constexpr int NPAD = NT * 16;
@@ -66,7 +67,7 @@ struct ConvCfg {
 // 3x3 stride-2 convolution, so it rides along: extra accumulators fed only in the centre-tap k steps, second output
 // (bias, no ReLU).  Saves a full pass over the block input and a launch.
 template <int CIN, int COUT, int KS, int S, int OTW, bool RELU, bool RES, bool U8IN, int RP = 1, bool SC = false>
-__global__ __launch_bounds__(256) void k_conv(const void* __restrict__ in_, long long in_img_stride, int in_row_stride,
+__global__ __launch_bounds__(64 * kConvWaves) void k_conv(const void* __restrict__ in_, long long in_img_stride, int in_row_stride,
                                               const float* __restrict__ wB, const float* __restrict__ bias,
                                               const float* __restrict__ res, float* __restrict__ out, int Hin, int Win,
                                               int Hout, int Wout, const float* __restrict__ wSC,
@@ -90,13 +91,13 @@ __global__ __launch_bounds__(256) void k_conv(const void* __restrict__ in_, long
   // epilogue stores of neighbouring tiles overlap (co-resident workgroups start together and would otherwise all
   // load, then all compute: measured, the phases simply added up).
   constexpr int TOTAL = CIN * C::IN_H * C::W4;          // float4 groups per tile
-  constexpr int NLD = (TOTAL + 255) / 256;
+  constexpr int NLD = (TOTAL + 64 * kConvWaves - 1) / (64 * kConvWaves);
   f32x4 pre[NLD];
   int loff[NLD], x4v[NLD];
   long long grow[NLD];                                  // element offset of the source row (or -1: outside the image)
 #pragma unroll
   for (int u = 0; u < NLD; u++) {
-    const int idx = tid + 256 * u;
+    const int idx = tid + 64 * kConvWaves * u;
     const int c = idx / (C::IN_H * C::W4);
     const int rem = idx - c * (C::IN_H * C::W4);
     const int r = rem / C::W4;
@@ -1005,7 +1006,7 @@ void launch_conv(const ConvDesc& c, const void* in, long long in_img_stride, int
     attr_set = true;
   }
   const int n_bands = (c.hout + C::OTH - 1) / C::OTH;     // a workgroup walks the x tiles of its row band
-  hipLaunchKernelGGL(kern, dim3(n_bands * n_img), dim3(256), lds, st, in, in_img_stride, in_row_stride,
+  hipLaunchKernelGGL(kern, dim3(n_bands * n_img), dim3(64 * kConvWaves), lds, st, in, in_img_stride, in_row_stride,
                      RP == 2 ? c.d_w2 : c.d_w, c.d_b, res, out, c.hin, c.win, c.hout, c.wout, sc ? sc->d_w : nullptr,
                      sc ? sc->d_b : nullptr, out_sc, n_bands);
 }
