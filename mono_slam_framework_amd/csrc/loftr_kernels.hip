@@ -539,37 +539,55 @@ __global__ __launch_bounds__(256) void k_sim_stats(const float* __restrict__ fa,
   float a[8];
   load8(A + (long long)(it * 16 + tl) * DM + 8 * g, a);
   float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, sm[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int jt = 0; jt < NTOK / 16; jt++) {
-    float b[8];
-    load8(B + (long long)(jt * 16 + tl) * DM + 8 * g, b);
-    f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+  // three column tiles per step: three independent MFMA chains in flight, and the running (max, sum) of a row is
+  // rescaled once per three new entries (4 exponentials per 3 entries, no divergent branch)
+  constexpr int TJ = 3;
+  static_assert((NTOK / 16) % TJ == 0, "column tiles per step");
+  for (int jt0 = 0; jt0 < NTOK / 16; jt0 += TJ) {
+    f32x4 d[TJ];
 #pragma unroll
-    for (int sI = 0; sI < 8; sI++) d = mfma4(a[sI], b[sI], d);
-    float sv[4];
+    for (int u = 0; u < TJ; u++) {
+      float b[8];
+      load8(B + (long long)((jt0 + u) * 16 + tl) * DM + 8 * g, b);
+      d[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sI = 0; sI < 8; sI++) d[u] = mfma4(a[sI], b[sI], d[u]);
+    }
+    float sv[TJ][4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      const float s = div_temperature(d[r]);
-      sv[r] = s;
-      if (s > mx[r]) { sm[r] = sm[r] * __expf(mx[r] - s) + 1.f; mx[r] = s; }
-      else sm[r] += __expf(s - mx[r]);
+      float mn = mx[r];
+#pragma unroll
+      for (int u = 0; u < TJ; u++) {
+        sv[u][r] = div_temperature(d[u][r]);
+        mn = fmaxf(mn, sv[u][r]);
+      }
+      float add = 0.f;
+#pragma unroll
+      for (int u = 0; u < TJ; u++) add += __expf(sv[u][r] - mn);
+      sm[r] = sm[r] * __expf(mx[r] - mn) + add;
+      mx[r] = mn;
     }
     if (EMIT) {
-      // here the tile is S^T: this lane holds s_ij for i = jt*16 + tl (the row of S) and j = it*16 + 4g + r
-      const int i = jt * 16 + tl;
-      const float li = lim[(long long)pair * NTOK + i];
-      const bool h0 = sv[0] >= li, h1 = sv[1] >= li, h2 = sv[2] >= li, h3 = sv[3] >= li;
-      if (__any(h0 | h1 | h2 | h3)) {
-        const uint32_t nh = (uint32_t)h0 + h1 + h2 + h3;
-        if (nh) {
-          uint32_t k = atomicAdd(&cand_cnt[pair], nh);
-          SimCand* c = cand + (long long)pair * kCandCap;
-          const bool hs[4] = {h0, h1, h2, h3};
 #pragma unroll
-          for (int r = 0; r < 4; r++)
-            if (hs[r]) {
-              if (k < (uint32_t)kCandCap) c[k] = SimCand{(uint32_t)i | ((uint32_t)(it * 16 + 4 * g + r) << 16), sv[r]};
-              k++;
-            }
+      for (int u = 0; u < TJ; u++) {
+        // here the tile is S^T: this lane holds s_ij for i = jt*16 + tl (the row of S) and j = it*16 + 4g + r
+        const int i = (jt0 + u) * 16 + tl;
+        const float li = lim[(long long)pair * NTOK + i];
+        const bool h0 = sv[u][0] >= li, h1 = sv[u][1] >= li, h2 = sv[u][2] >= li, h3 = sv[u][3] >= li;
+        if (__any(h0 | h1 | h2 | h3)) {
+          const uint32_t nh = (uint32_t)h0 + h1 + h2 + h3;
+          if (nh) {
+            uint32_t k = atomicAdd(&cand_cnt[pair], nh);
+            SimCand* c = cand + (long long)pair * kCandCap;
+            const bool hs[4] = {h0, h1, h2, h3};
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+              if (hs[r]) {
+                if (k < (uint32_t)kCandCap) c[k] = SimCand{(uint32_t)i | ((uint32_t)(it * 16 + 4 * g + r) << 16), sv[u][r]};
+                k++;
+              }
+          }
         }
       }
     }
