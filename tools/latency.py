@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Single-pair drop-in latency (msf_match_pair on host images, the call the reference app makes per MatchFrames) and
+the per-stage kernel times of that call.  Prints one line per matcher."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mono_slam_framework_amd import _lib, synth                                     # noqa: E402
+from mono_slam_framework_amd.matcher import DNNFeatureMatcher, FeatureMatcher       # noqa: E402
+
+for name, make in (("orb", lambda: FeatureMatcher(0.6, 640, 480, flags=_lib.MSF_FLAG_PROFILE)),
+                   ("loftr", lambda: DNNFeatureMatcher(None, 0.15, 640, 480, flags=_lib.MSF_FLAG_PROFILE))):
+    fm = make()
+    a, b = synth.synth_pair(5, 640, 480, mode=0 if name == "orb" else 1)
+    for _ in range(20):
+        fm.MatchFrames(a, b)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        fm.MatchFrames(a, b)
+    dt = (time.perf_counter() - t0) / 200
+    st = fm.stage_times()
+    print(name, "640x480 MatchFrames latency %.3f ms; kernel stages (ms):" % (dt * 1e3),
+          {k: round(v, 3) for k, v in st.items()}, "sum %.3f" % sum(st.values()))
