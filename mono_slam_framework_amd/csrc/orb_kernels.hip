@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uin
   if (tid < rows) {
     const uint32_t yt = ytab[Y0 + tid];
     const uint32_t wy1 = yt >> 16;
-    ysh[2 * tid] = (uint32_t)(((int)(yt & 0xFFFF) - sy0) * n4);       // LDS word index of the upper source row
-    ysh[2 * tid + 1] = (256u - wy1) | (wy1 << 16);                     // (w0, w1) as a u16 pair for v_dot2_u32_u16
+    ysh[2 * tid] = (uint32_t)(((int)(yt & 0xFFFF) - sy0) * n4 * 4);   // LDS byte offset of the upper source row
+    ysh[2 * tid + 1] = wy1;                                            // weight of the lower source row
   }
   for (int i = tid; i < nrow * n16; i += nthr) {
     const int r = (int)__umulhi((uint32_t)i, magic_n16), c = i - r * n16;   // i / n16 (exact for i < 2^16)
@@ -114,24 +114,39 @@ __global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uin
       wxp[k] = (256u - wx1) | (wx1 << 16);
     }
     const int ry0 = 4 * rg, ry1 = min(ry0 + 4, rows);
+    const char* Tb = reinterpret_cast<const char*>(T);
+    const int rowb = 4 * n4;                               // staged row pitch in bytes
+    uint8_t* dp = d + (long long)(Y0 + ry0) * L.pitch + x4;
+    uint32_t hlow[4] = {0u, 0u, 0u, 0u};                   // horizontal sums of the previous row's LOWER source row
+    int prev = -0x40000000;
     for (int ry = ry0; ry < ry1; ry++) {
-      const int rbase = (int)ysh[2 * ry];
-      const uint32_t wyp = ysh[2 * ry + 1];
-      uint32_t packed = 0;
+      const int rb = (int)ysh[2 * ry];
+      const uint32_t wy1 = ysh[2 * ry + 1], wy0 = 256u - wy1;
+      // consecutive output rows usually step one source row: the lower row of the previous output row is this row's
+      // upper row, its horizontal sums are reused (exactly the same integers)
+      const bool reuse = rb == prev + rowb;
+      prev = rb;
+      uint32_t v[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const int w0i = rbase + w0[k];
-        const uint32_t a = __builtin_amdgcn_alignbyte(T[w0i + 1], T[w0i], shf[k]);            // row sy:   p[cx], p[cx+1]
-        const uint32_t c = __builtin_amdgcn_alignbyte(T[w0i + n4 + 1], T[w0i + n4], shf[k]);  // row sy+1
-        // bytes (p0, p1) -> u16 pair, then w0*p0 + w1*p1 in one v_dot2_u32_u16 (<= 255 * 256: fits 16 bits)
-        const uint32_t h0 = udot2_u16(__builtin_amdgcn_perm(0u, a, 0x0c010c00u), wxp[k], 0u);
+        const uint32_t* pa = reinterpret_cast<const uint32_t*>(Tb + 4 * w0[k] + rb);
+        uint32_t h0 = hlow[k];
+        if (!reuse) {
+          const uint32_t a = __builtin_amdgcn_alignbyte(pa[1], pa[0], shf[k]);               // row sy:   p[cx], p[cx+1]
+          // bytes (p0, p1) -> u16 pair, then w0*p0 + w1*p1 in one v_dot2_u32_u16 (<= 255 * 256: fits 16 bits)
+          h0 = udot2_u16(__builtin_amdgcn_perm(0u, a, 0x0c010c00u), wxp[k], 0u);
+        }
+        const uint32_t* pc = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(pa) + rowb);
+        const uint32_t c = __builtin_amdgcn_alignbyte(pc[1], pc[0], shf[k]);                 // row sy+1
         const uint32_t h1 = udot2_u16(__builtin_amdgcn_perm(0u, c, 0x0c010c00u), wxp[k], 0u);
-        // weights sum to 256 * 256, so the result is <= 255 without a clamp
-        const uint32_t v = udot2_u16(h0 | (h1 << 16), wyp, 32768u) >> 16;
-        packed |= v << (8 * k);
+        hlow[k] = h1;
+        // weights sum to 256 * 256, so bits 16..23 hold the result (<= 255) without a clamp
+        v[k] = __umul24(h0, wy0) + __umul24(h1, wy1) + 32768u;
       }
-      // pitch % 16 == 0, pad bytes are never read as pixels
-      *reinterpret_cast<uint32_t*>(d + (long long)(Y0 + ry) * L.pitch + x4) = packed;
+      // byte 2 of each of the four sums -> one dword
+      const uint32_t packed = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u) | __builtin_amdgcn_perm(v[3], v[2], 0x06020c0cu);
+      *reinterpret_cast<uint32_t*>(dp) = packed;           // pitch % 16 == 0, pad bytes are never read as pixels
+      dp += L.pitch;
     }
   }
 }
