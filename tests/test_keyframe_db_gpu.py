@@ -176,3 +176,26 @@ def test_loftr_database_matches_reference_logic():
     exp, exp_num = oracle_db.detect_relocalization_candidates(cpu_kfs, mf, KeyFrame(901, q_img))
     np.testing.assert_array_equal(db.last_num_matches, exp_num)
     assert [k.id() for k in got] == [k.id() for k in exp]
+
+
+def test_one_to_many_error_paths():
+    """bad slots / sizes / missing state give MSF_ERR_INVALID_ARG (never a crash), for both matchers"""
+    from mono_slam_framework_amd.matcher import DNNFeatureMatcher, FeatureMatcher, MsfError
+    img = synth.synth_pair(3, W, H)[0]
+    for fm in (FeatureMatcher(0.6, W, H, max_batch_pairs=4), DNNFeatureMatcher(None, 0.15, W, H, max_batch_pairs=4)):
+        with pytest.raises(MsfError):
+            fm.match_one_to_many(0, [1])                    # nothing stored yet
+        fm.store_frame(0, img)
+        fm.store_frame(7, img)                              # last slot of [0, 2*max_batch_pairs)
+        for bad in (lambda: fm.store_frame(8, img), lambda: fm.store_frame(-1, img),
+                    lambda: fm.store_frame(1, img[:100]),  # wrong size
+                    lambda: fm.match_one_to_many(0, [8]), lambda: fm.match_one_to_many(9, [1]),
+                    lambda: fm.match_one_to_many(0, [1, 2, 3, 4, 5]),          # n > max_batch_pairs
+                    lambda: fm.match_one_to_many(0, [7], with_map_points=True)):  # no map slot was ever set
+            with pytest.raises(MsfError) as ei:
+                bad()
+            assert ei.value.code == -1
+        num, _, lists = fm.match_one_to_many(0, [7, 0], cap=64)   # a frame against itself, twice
+        assert num[0] == num[1] and num[0] > 0 and len(lists[0]) == min(num[0], 64)
+        assert (lists[0][:, :2] == lists[0][:, 2:]).all()          # every match maps a point onto itself
+        assert len(fm.match_one_to_many(0, [])[0]) == 0
