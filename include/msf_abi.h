@@ -161,6 +161,14 @@ int msf_check_hypotheses(msf_handle* h, int32_t model, int32_t n_hyp, const floa
                          int32_t n_matches, const msf_match* matches, float sigma, float* scores, int32_t* best,
                          uint8_t* best_inliers);
 
+/* Tracking::CreateCurrentMatchImage (slam_pipeline/src/Tracking.cc:899-940): out_rgb [H][2*W][3] (rows out_stride
+ * bytes apart, HOST) = the two gray frames side by side as RGB with a filled radius-3 circle on every match end point:
+ * (0,255,0) where neither side has a map point, then (255,0,0) over those where either side has one.
+ * has_mp1 / has_mp2: [n_matches] bytes (GetMapPoint1/2 != null), NULL = none. */
+int msf_render_match_image(msf_handle* h, const msf_image* f1, const msf_image* f2, const msf_match* matches,
+                           int32_t n_matches, const uint8_t* has_mp1, const uint8_t* has_mp2, uint8_t* out_rgb,
+                           int64_t out_stride);
+
 /* Packs [n_pairs][cap_per_pair] match lists + counts into one contiguous device list:
  * d_offsets[i] = start of pair i, d_offsets[n_pairs] = total; pairs with n_out < 0 contribute nothing.
  * This is the payload of the multi-GPU gather of match lists (and of MatchFramesResult's vectors). */

@@ -27,7 +27,8 @@ ABI_SYMBOLS = ["msf_abi_version", "msf_default_config", "msf_create", "msf_destr
                "msf_last_error", "msf_match_pair", "msf_match_batch", "msf_match_batch_device",
                "msf_extract_device", "msf_match_slots_device", "msf_pack_matches_device", "msf_debug_get",
                "msf_stage_times", "msf_set_mappoints", "msf_count_mappoint_matches_device",
-               "msf_store_frame", "msf_match_one_to_many", "msf_check_hypotheses"]
+               "msf_store_frame", "msf_match_one_to_many", "msf_check_hypotheses",
+               "msf_render_match_image"]
 
 
 class Config(C.Structure):
@@ -80,6 +81,7 @@ def load():
     L.msf_store_frame.argtypes = [vp, i32, C.POINTER(Image)]
     L.msf_match_one_to_many.argtypes = [vp, i32, i32, vp, vp, vp, vp, i32]
     L.msf_check_hypotheses.argtypes = [vp, i32, i32, vp, vp, i32, vp, f32, vp, C.POINTER(i32), vp]
+    L.msf_render_match_image.argtypes = [vp, C.POINTER(Image), C.POINTER(Image), vp, i32, vp, vp, vp, i64]
     L.msf_stage_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(f32), i32]
     _lib = L
     return L

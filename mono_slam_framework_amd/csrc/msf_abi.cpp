@@ -18,6 +18,9 @@ hipError_t pack_matches(int n, const msf_match* d_in, int cap, const int32_t* d_
 hipError_t count_mappoint_matches(int n, const msf_match* d_matches, int cap, const int32_t* d_cnt,
                                   const int32_t* d_map_a, const int32_t* d_map_b, const uint32_t* d_maps, int n_maps,
                                   int map_words, int width, int height, int32_t* d_num_mp, hipStream_t st);
+hipError_t render_match_image(const uint8_t* d_f1, const uint8_t* d_f2, int w, int h, long long pitch,
+                              const msf_match* d_m, const uint8_t* d_mp1, const uint8_t* d_mp2, int n, uint8_t* d_out,
+                              long long out_stride, hipStream_t st);
 hipError_t check_hypotheses(int model, int n_hyp, const float* d_m21, const float* d_m12, int n,
                             const msf_match* d_matches, float sigma, float* d_scores, uint8_t* d_inliers,
                             hipStream_t st);
@@ -527,6 +530,49 @@ int msf_check_hypotheses(msf_handle* h, int32_t model, int32_t n_hyp, const floa
       (e = hipMemcpy(best_inliers, h->d_hyp_inl + (size_t)*best * n_matches, (size_t)n_matches, hipMemcpyDeviceToHost)) != hipSuccess)
     return hip_fail(h, "hipMemcpy", e);
   return MSF_OK;
+}
+
+int msf_render_match_image(msf_handle* h, const msf_image* f1, const msf_image* f2, const msf_match* matches,
+                           int32_t n_matches, const uint8_t* has_mp1, const uint8_t* has_mp2, uint8_t* out_rgb,
+                           int64_t out_stride) {
+  if (!h) return MSF_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lk(h->mu);
+  const int W = h->cfg.image_width, H = h->cfg.image_height;
+  if (!f1 || !f2 || !f1->data || !f2->data || f1->width != W || f1->height != H || f2->width != W || f2->height != H ||
+      f1->stride < W || f2->stride < W || n_matches < 0 || (n_matches > 0 && !matches) || !out_rgb || out_stride < 6ll * W)
+    return fail(h, MSF_ERR_INVALID_ARG, "msf_render_match_image: bad argument or image size differs from the handle's");
+  hipError_t e = hipSetDevice(h->cfg.device);
+  if (e != hipSuccess) return hip_fail(h, "hipSetDevice", e);
+  if (int rc = ensure_stage(h)) return rc;
+  hipStream_t st = h->stream;
+  // workspace: the two frames use the staging buffers; the list, flags and the RGB image are allocated per call
+  uint8_t* dA = h->d_stage;
+  uint8_t* dB = h->d_stage + (size_t)h->cfg.max_batch_pairs * h->stage_frame;
+  uint8_t* d_out = nullptr;
+  msf_match* d_m = nullptr;
+  uint8_t* d_flags = nullptr;
+  const size_t out_bytes = (size_t)6 * W * H;
+  int rc = MSF_OK;
+  do {
+    if ((e = hipMalloc(&d_out, out_bytes)) != hipSuccess) { rc = hip_fail(h, "hipMalloc", e); break; }
+    if (n_matches) {
+      if ((e = hipMalloc(&d_m, (size_t)n_matches * sizeof(msf_match))) != hipSuccess) { rc = hip_fail(h, "hipMalloc", e); break; }
+      if ((e = hipMalloc(&d_flags, (size_t)2 * n_matches)) != hipSuccess) { rc = hip_fail(h, "hipMalloc", e); break; }
+      hipMemcpyAsync(d_m, matches, (size_t)n_matches * sizeof(msf_match), hipMemcpyHostToDevice, st);
+      hipMemsetAsync(d_flags, 0, (size_t)2 * n_matches, st);
+      if (has_mp1) hipMemcpyAsync(d_flags, has_mp1, n_matches, hipMemcpyHostToDevice, st);
+      if (has_mp2) hipMemcpyAsync(d_flags + n_matches, has_mp2, n_matches, hipMemcpyHostToDevice, st);
+    }
+    hipMemcpy2DAsync(dA, h->stage_pitch, f1->data, f1->stride, W, H, hipMemcpyHostToDevice, st);
+    hipMemcpy2DAsync(dB, h->stage_pitch, f2->data, f2->stride, W, H, hipMemcpyHostToDevice, st);
+    if ((e = msf::render_match_image(dA, dB, W, H, h->stage_pitch, d_m, d_flags, d_flags ? d_flags + n_matches : nullptr,
+                                     n_matches, d_out, 6ll * W, st)) != hipSuccess) { rc = hip_fail(h, "render_match_image", e); break; }
+    if ((e = hipMemcpy2DAsync(out_rgb, out_stride, d_out, (size_t)6 * W, (size_t)6 * W, H, hipMemcpyDeviceToHost, st)) != hipSuccess) { rc = hip_fail(h, "hipMemcpy2DAsync", e); break; }
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) { rc = hip_fail(h, "hipStreamSynchronize", e); break; }
+  } while (0);
+  hipStreamSynchronize(st);
+  hipFree(d_out); hipFree(d_m); hipFree(d_flags);
+  return rc;
 }
 
 int msf_debug_get(msf_handle* h, int32_t what, int32_t slot, int32_t level, void* host_out, size_t cap_bytes,

@@ -90,4 +90,60 @@ hipError_t count_mappoint_matches(int n, const msf_match* d_matches, int cap, co
   return hipGetLastError();
 }
 
+// Tracking::CreateCurrentMatchImage (slam_pipeline/src/Tracking.cc:899-940): the two gray frames side by side as RGB,
+// a filled radius-3 circle on every match end point -- first the matches without a map point on either side
+// (0, 255, 0), then, over them, the ones with a map point on either side (255, 0, 0).
+// cv::circle(img, c, 3, color, FILLED) sets, per the midpoint loop of OpenCV's Circle(): row c.y: x-3..x+3,
+// rows c.y +- 1 and c.y +- 2: x-2..x+2, rows c.y +- 3: x only; spans are clipped to the image.
+__global__ __launch_bounds__(256) void k_gray2rgb_pair(const uint8_t* __restrict__ f1, const uint8_t* __restrict__ f2,
+                                                       int w, int h, long long pitch, uint8_t* __restrict__ out,
+                                                       long long out_stride) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= 2 * w) return;
+  const uint8_t v = x < w ? f1[(long long)y * pitch + x] : f2[(long long)y * pitch + (x - w)];
+  uint8_t* o = out + (long long)y * out_stride + 3ll * x;
+  o[0] = v; o[1] = v; o[2] = v;      // cvtColor(GRAY2RGB)
+}
+
+__global__ __launch_bounds__(256) void k_match_circles(const msf_match* __restrict__ m, const uint8_t* __restrict__ mp1,
+                                                       const uint8_t* __restrict__ mp2, int n, int want_mp, int w, int h,
+                                                       uint8_t* __restrict__ out, long long out_stride) {
+  // 29 pixels per circle, two circles per match
+  constexpr int kPix = 29;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int i = idx / (2 * kPix), r = idx - i * (2 * kPix);
+  if (i >= n) return;
+  const bool has = (mp1 && mp1[i]) || (mp2 && mp2[i]);
+  if ((int)has != want_mp) return;
+  const int side = r / kPix, p = r - side * kPix;
+  // pixel p of the shape: rows -3..3 with half widths 0, 2, 2, 3, 2, 2, 0 (1 + 5 + 5 + 7 + 5 + 5 + 1 = 29)
+  int dy, dx;
+  if (p < 1) { dy = -3; dx = 0; }
+  else if (p < 6) { dy = -2; dx = p - 1 - 2; }
+  else if (p < 11) { dy = -1; dx = p - 6 - 2; }
+  else if (p < 18) { dy = 0; dx = p - 11 - 3; }
+  else if (p < 23) { dy = 1; dx = p - 18 - 2; }
+  else if (p < 28) { dy = 2; dx = p - 23 - 2; }
+  else { dy = 3; dx = 0; }
+  const msf_match q = m[i];
+  const int cx = side ? q.x2 : q.x1, cy = side ? q.y2 : q.y1;
+  const int x = cx + dx, y = cy + dy;
+  if (x < 0 || x >= w || y < 0 || y >= h) return;   // clipped to the half image the circle is drawn into
+  uint8_t* o = out + (long long)y * out_stride + 3ll * (x + (side ? w : 0));
+  o[0] = want_mp ? 255 : 0; o[1] = want_mp ? 0 : 255; o[2] = 0;
+}
+
+hipError_t render_match_image(const uint8_t* d_f1, const uint8_t* d_f2, int w, int h, long long pitch,
+                              const msf_match* d_m, const uint8_t* d_mp1, const uint8_t* d_mp2, int n, uint8_t* d_out,
+                              long long out_stride, hipStream_t st) {
+  hipLaunchKernelGGL(k_gray2rgb_pair, dim3((2 * w + 255) / 256, h), dim3(256), 0, st, d_f1, d_f2, w, h, pitch, d_out,
+                     out_stride);
+  if (n > 0) {
+    const int blocks = (n * 58 + 255) / 256;
+    hipLaunchKernelGGL(k_match_circles, dim3(blocks), dim3(256), 0, st, d_m, d_mp1, d_mp2, n, 0, w, h, d_out, out_stride);
+    hipLaunchKernelGGL(k_match_circles, dim3(blocks), dim3(256), 0, st, d_m, d_mp1, d_mp2, n, 1, w, h, d_out, out_stride);
+  }
+  return hipGetLastError();
+}
+
 }  // namespace msf

@@ -147,6 +147,19 @@ class _Matcher:
                                                  float(sigma), scores.ctypes.data, C.byref(best), inl.ctypes.data))
         return best.value, scores, inl[:len(m)].astype(bool)
 
+    def render_match_image(self, frame1, frame2, matches, has_mp1=None, has_mp2=None):
+        """Tracking::CreateCurrentMatchImage (Tracking.cc:899-940) -> uint8 [H, 2W, 3]."""
+        a, b = self._image(frame1), self._image(frame2)
+        m = np.ascontiguousarray(matches, np.int32).reshape(-1, 4)
+        f1 = None if has_mp1 is None else np.ascontiguousarray(has_mp1, np.uint8)
+        f2 = None if has_mp2 is None else np.ascontiguousarray(has_mp2, np.uint8)
+        out = np.zeros((self.height, 2 * self.width, 3), np.uint8)
+        self._check(self._L.msf_render_match_image(self._h, C.byref(a), C.byref(b), m.ctypes.data, len(m),
+                                                   None if f1 is None else f1.ctypes.data,
+                                                   None if f2 is None else f2.ctypes.data, out.ctypes.data,
+                                                   out.strides[0]))
+        return out
+
     def store_frame(self, slot, frame):
         """Uploads a host frame into resident frame slot `slot` (ORB: and extracts its features once)."""
         img = self._image(frame)
