@@ -707,11 +707,15 @@ __global__ __launch_bounds__(256) void k_decode(const uint32_t* __restrict__ mas
   msf_match* o = out + (long long)pair * cap;
   if (tid == 0) running = 0;
   __syncthreads();
-  const int total = NTOK * MASK_WORDS;
-  for (int w0 = 0; w0 < total; w0 += 256) {
-    const int w = w0 + tid;
-    const uint32_t bits = w < total ? mk[w] : 0u;
-    const uint32_t c = __popc(bits);
+  constexpr int total = NTOK * MASK_WORDS;
+  static_assert(total % 4 == 0, "mask rows are read four words at a time");
+  for (int w0 = 0; w0 < total; w0 += 4 * 256) {
+    const int w = w0 + 4 * tid;
+    uint4 b4 = make_uint4(0u, 0u, 0u, 0u);
+    if (w < total) b4 = *reinterpret_cast<const uint4*>(mk + w);
+    const uint32_t wb[4] = {b4.x, b4.y, b4.z, b4.w};
+    const uint32_t c = __popc(wb[0]) + __popc(wb[1]) + __popc(wb[2]) + __popc(wb[3]);
+    if (!__syncthreads_or(c != 0u)) continue;      // almost every 1024-word chunk of the mask is empty
     // inclusive scan inside the wave
     uint32_t s = c;
 #pragma unroll
@@ -724,9 +728,12 @@ __global__ __launch_bounds__(256) void k_decode(const uint32_t* __restrict__ mas
     uint32_t base = running;
     for (int k = 0; k < wave; k++) base += wsum[k];
     uint32_t pos = base + s - c;
-    if (bits) {
-      const int i = w / MASK_WORDS, jw = (w % MASK_WORDS) * 32;
-      uint32_t bb = bits;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      uint32_t bb = wb[q];
+      if (!bb) continue;
+      const int ww = w + q;
+      const int i = ww / MASK_WORDS, jw = (ww % MASK_WORDS) * 32;
       while (bb) {
         const int bit = __ffs(bb) - 1;
         bb &= bb - 1;
