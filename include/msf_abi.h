@@ -53,6 +53,7 @@ typedef enum msf_kind {
 /* msf_config.flags */
 #define MSF_FLAG_BLUR_TIE_HALF_UP 1u /* ORB 7x7 blur: (sum+32768)>>16 instead of round-half-even */
 #define MSF_FLAG_PROFILE 2u          /* record per-stage HIP events on the launch stream (msf_stage_times) */
+#define MSF_FLAG_KEEP_DEBUG 4u       /* LoFTR: keep pair 0's confidence matrix and coarse features for msf_debug_get */
 
 typedef struct msf_config {
   uint32_t struct_size;      /* sizeof(msf_config) */

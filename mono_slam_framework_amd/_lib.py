@@ -18,6 +18,7 @@ MSF_KIND_LOFTR = 1
 
 MSF_FLAG_BLUR_TIE_HALF_UP = 1
 MSF_FLAG_PROFILE = 2
+MSF_FLAG_KEEP_DEBUG = 4
 
 (DBG_LEVEL_SIZES, DBG_LEVEL_PIXELS, DBG_FAST_CANDS, DBG_KEYPOINTS, DBG_DESCRIPTORS, DBG_STAGE1,
  DBG_LOFTR_CONF, DBG_LOFTR_FEAT) = range(8)

@@ -782,6 +782,7 @@ struct LoftrPipeline::Impl {
   SimCand* cand = nullptr;   // [max_pairs][kCandCap]
   uint32_t* cand_cnt = nullptr;
   bool dense_head = false;
+  bool keep_debug = false;   // MSF_FLAG_KEEP_DEBUG: pair 0's confidence matrix + features for the parity tests
   float* conf_dbg = nullptr; // [1200][1200]
   float* feat_dbg = nullptr; // [2][1200][32]
   int dbg_pair = 0;
@@ -851,7 +852,7 @@ std::string default_weights() {
     if (e_ != hipSuccess) return std::string(#expr) + ": " + hipGetErrorString(e_);      \
   } while (0)
 
-std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool profile) {
+std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool profile, bool keep_debug) {
   destroy();
   p_ = new Impl();
   Impl& P = *p_;
@@ -863,6 +864,7 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
     P.chunk = max_pairs < want ? max_pairs : (want > 0 ? want : 64);
   }
   P.profile = profile;
+  P.keep_debug = keep_debug;
   Blob blob;
   std::string err = load_blob(weights_path && weights_path[0] ? weights_path : default_weights(), &blob);
   if (!err.empty()) return err;
@@ -1171,20 +1173,23 @@ hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf
     hipLaunchKernelGGL(k_sim_stats<true>, dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats, 2LL * NTOK, P.lim,
                        P.cand, P.cand_cnt);
     // pair 0's confidence matrix (+ its mask, densely) is kept for the parity tests
-    hipLaunchKernelGGL(k_conf_mask, dim3(head_blocks, 1), dim3(256), 0, st, f0s, f1s, ts, P.rstats, P.cstats, 2LL * NTOK,
-                       threshold, P.mask, P.conf_dbg, 0);
+    if (P.keep_debug)
+      hipLaunchKernelGGL(k_conf_mask, dim3(head_blocks, 1), dim3(256), 0, st, f0s, f1s, ts, P.rstats, P.cstats, 2LL * NTOK,
+                         threshold, P.mask, P.conf_dbg, 0);
     hipLaunchKernelGGL(k_conf_cand, dim3(8, n), dim3(256), 0, st, P.cand, P.cand_cnt, P.rstats, P.cstats, 2LL * NTOK, threshold,
                        P.mask);
   } else {
     hipLaunchKernelGGL(k_sim_stats<false>, dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats, 2LL * NTOK, nullptr,
                        nullptr, nullptr);
     hipLaunchKernelGGL(k_conf_mask, dim3(head_blocks, n), dim3(256), 0, st, f0s, f1s, ts, P.rstats, P.cstats, 2LL * NTOK,
-                       threshold, P.mask, P.conf_dbg, 0);
+                       threshold, P.mask, P.keep_debug ? P.conf_dbg : nullptr, 0);
   }
   hipLaunchKernelGGL(k_decode, dim3(n), dim3(256), 0, st, P.mask, d_out, cap, d_n_out);
-  hipMemcpyAsync(P.feat_dbg, f0, ts * sizeof(float), hipMemcpyDeviceToDevice, st);
-  hipMemcpyAsync(P.feat_dbg + ts, f1, ts * sizeof(float), hipMemcpyDeviceToDevice, st);
-  P.have_dbg = true;
+  if (P.keep_debug) {
+    hipMemcpyAsync(P.feat_dbg, f0, ts * sizeof(float), hipMemcpyDeviceToDevice, st);
+    hipMemcpyAsync(P.feat_dbg + ts, f1, ts * sizeof(float), hipMemcpyDeviceToDevice, st);
+    P.have_dbg = true;
+  }
   if (ev) { hipEventRecord(ev[3], st); P.ev_rec = true; }
   return hipGetLastError();
 }
@@ -1203,7 +1208,7 @@ int LoftrPipeline::stage_times(const char** names, float* ms, int cap) {
 
 int LoftrPipeline::debug_get(int what, int slot, int level, void* host_out, size_t cap, size_t* n_bytes,
                              std::string* err) {
-  if (!p_ || !p_->have_dbg) { *err = "no LoFTR batch has run yet"; return MSF_ERR_INVALID_ARG; }
+  if (!p_ || !p_->have_dbg) { *err = "no LoFTR batch has run yet, or the handle was created without MSF_FLAG_KEEP_DEBUG"; return MSF_ERR_INVALID_ARG; }
   if (slot != 0) { *err = "LoFTR debug tensors are kept for pair 0 of the last call only"; return MSF_ERR_INVALID_ARG; }
   if (hipDeviceSynchronize() != hipSuccess) { *err = "hipDeviceSynchronize failed"; return MSF_ERR_HIP; }
   const float* src = nullptr;

@@ -17,7 +17,7 @@ class LoftrPipeline {
   LoftrPipeline() = default;
   ~LoftrPipeline();
   // returns empty string on success; "io: ..." for weight-file problems
-  std::string init(const char* weights_path, int max_pairs, bool profile);
+  std::string init(const char* weights_path, int max_pairs, bool profile, bool keep_debug);
   void destroy();
   hipError_t match(int n_pairs, const uint8_t* d_a, const uint8_t* d_b, long long frame_stride, int row_stride,
                    float threshold, msf_match* d_out, int cap_per_pair, int32_t* d_n_out, hipStream_t st);

@@ -173,7 +173,7 @@ int msf_create(const msf_config* cfg, msf_handle** out) {
       delete h;
       return fail(nullptr, MSF_ERR_UNSUPPORTED, "LoFTR_teacher is a fixed-shape 1x1x480x640 graph (model/LoFTR_teacher.onnx)");
     }
-    err = h->loftr.init(cfg->weights_path, cfg->max_batch_pairs, profile);
+    err = h->loftr.init(cfg->weights_path, cfg->max_batch_pairs, profile, (cfg->flags & MSF_FLAG_KEEP_DEBUG) != 0);
   }
   if (!err.empty()) {
     const bool io = err.rfind("io:", 0) == 0, arg = err.rfind("arg:", 0) == 0;

@@ -17,7 +17,8 @@ CONF_TOL = 1e-3   # north_star: "LoFTR match confidences within 1e-3"
 
 def _dm(thr=0.15, pairs=1):
     from mono_slam_framework_amd.matcher import DNNFeatureMatcher
-    return DNNFeatureMatcher(threshold=thr, max_batch_pairs=pairs)
+    from mono_slam_framework_amd import _lib
+    return DNNFeatureMatcher(threshold=thr, max_batch_pairs=pairs, flags=_lib.MSF_FLAG_KEEP_DEBUG)
 
 
 def _check_lists(got, conf_ref, thr):
