@@ -54,6 +54,7 @@ typedef enum msf_kind {
 #define MSF_FLAG_BLUR_TIE_HALF_UP 1u /* ORB 7x7 blur: (sum+32768)>>16 instead of round-half-even */
 #define MSF_FLAG_PROFILE 2u          /* record per-stage HIP events on the launch stream (msf_stage_times) */
 #define MSF_FLAG_KEEP_DEBUG 4u       /* LoFTR: keep pair 0's confidence matrix and coarse features for msf_debug_get */
+#define MSF_FLAG_FAST_DENSE 8u       /* ORB: score every pixel at fastThreshold (no output-sensitive first pass); same results */
 
 typedef struct msf_config {
   uint32_t struct_size;      /* sizeof(msf_config) */
@@ -180,12 +181,15 @@ int msf_pack_matches_device(msf_handle* h, int32_t n_pairs, const msf_match* d_i
 typedef enum msf_debug_what {
   MSF_DBG_LEVEL_SIZES = 0,   /* int32 [nlevels][4] = w, h, row pitch, quota */
   MSF_DBG_LEVEL_PIXELS = 1,  /* uint8 [h][pitch] of (slot, level); level 0 is the input frame itself (not kept) */
-  MSF_DBG_FAST_CANDS = 2,    /* int32 [n][3] (x, y, score) of (slot, level), unordered */
+  MSF_DBG_FAST_CANDS = 2,    /* int32 [n][3] (x, y, score) of (slot, level), unordered: the strict 3x3 maxima with
+                                score >= the level's MSF_DBG_FAST_TAU (all FAST corners after NMS when that is 20) */
   MSF_DBG_KEYPOINTS = 3,     /* msf_keypoint [n] of slot */
   MSF_DBG_DESCRIPTORS = 4,   /* uint8 [n][32] of slot */
   MSF_DBG_STAGE1 = 5,        /* msf_keypoint [n] (lx, ly, octave, fast_score, response) of (slot, level), unordered */
   MSF_DBG_LOFTR_CONF = 6,    /* float [1200][1200] confidence matrix of pair `slot` (debug launch only) */
-  MSF_DBG_LOFTR_FEAT = 7     /* float [2][1200][32] coarse features after the transformer of pair `slot` */
+  MSF_DBG_LOFTR_FEAT = 7,    /* float [2][1200][32] coarse features after the transformer of pair `slot` */
+  MSF_DBG_FAST_TAU = 8       /* int32 [nlevels][2] of slot: FAST score threshold the candidate list was built with
+                                (20 = dense, also after a failed check), and the first estimate */
 } msf_debug_what;
 /* copies to host; *n_bytes = bytes available (may exceed cap_bytes, then only cap_bytes are written) */
 int msf_debug_get(msf_handle* h, int32_t what, int32_t slot, int32_t level,

@@ -19,9 +19,10 @@ MSF_KIND_LOFTR = 1
 MSF_FLAG_BLUR_TIE_HALF_UP = 1
 MSF_FLAG_PROFILE = 2
 MSF_FLAG_KEEP_DEBUG = 4
+MSF_FLAG_FAST_DENSE = 8
 
 (DBG_LEVEL_SIZES, DBG_LEVEL_PIXELS, DBG_FAST_CANDS, DBG_KEYPOINTS, DBG_DESCRIPTORS, DBG_STAGE1,
- DBG_LOFTR_CONF, DBG_LOFTR_FEAT) = range(8)
+ DBG_LOFTR_CONF, DBG_LOFTR_FEAT, DBG_FAST_TAU) = range(9)
 
 # every symbol include/msf_abi.h declares
 ABI_SYMBOLS = ["msf_abi_version", "msf_default_config", "msf_create", "msf_destroy", "msf_set_threshold",

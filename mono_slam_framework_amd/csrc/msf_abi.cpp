@@ -167,7 +167,7 @@ int msf_create(const msf_config* cfg, msf_handle** out) {
   const bool profile = (cfg->flags & MSF_FLAG_PROFILE) != 0;
   if (cfg->kind == MSF_KIND_ORB) {
     err = h->orb.init(cfg->image_width, cfg->image_height, 2 * cfg->max_batch_pairs,
-                      (cfg->flags & MSF_FLAG_BLUR_TIE_HALF_UP) != 0, profile);
+                      (cfg->flags & MSF_FLAG_BLUR_TIE_HALF_UP) != 0, profile, (cfg->flags & MSF_FLAG_FAST_DENSE) != 0);
   } else {
     if (cfg->image_width != 640 || cfg->image_height != 480) {
       delete h;

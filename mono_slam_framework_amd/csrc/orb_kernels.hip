@@ -168,8 +168,6 @@ constexpr int SCO = 4;                              // byte offset of the score 
 // the score tile has the pixel tile's geometry (pitch PW2, same origin): one index serves both arrays
 constexpr int GPR = TW / 4 + 2;                          // 4-px groups per score row: tile x = 4g-4 .. 4g-1
 constexpr int kList1Cap = 2 * SW * SH;             // brighter-type survivors from the front, darker from the back
-constexpr uint32_t kLerpBright = 0x01010101u * (128 - kFastT / 2);  // L + K >= 256  <=>  L >= 128 + t/2
-constexpr uint32_t kLerpNotDark = 0x01010101u * (255 - (254 - kFastT) / 2);
 static_assert(kFastT % 2 == 0, "prefilter constants assume an even FAST threshold (cv::ORB default 20)");
 
 __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m) {   // set bits of m below this lane
@@ -179,7 +177,7 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m) {   // set bit
 // cornerScore<16> restricted to one polarity (a pixel cannot have both a brighter and a darker arc of 9):
 // max over the 16 arcs of the minimum of e over the arc, e = p - v (brighter) or v - p (darker).
 template <bool BRIGHT>
-__device__ __forceinline__ int fast_score_pol(const uint8_t* p) {
+__device__ __forceinline__ int fast_score_pol(const uint8_t* p, int tau) {
   constexpr int off[16] = {3 * PW2 + 0,  3 * PW2 + 1,  2 * PW2 + 2,  1 * PW2 + 3,  0 * PW2 + 3, -1 * PW2 + 3,
                            -2 * PW2 + 2, -3 * PW2 + 1, -3 * PW2 + 0, -3 * PW2 - 1, -2 * PW2 - 2, -1 * PW2 - 3,
                            0 * PW2 - 3,  1 * PW2 - 3,  2 * PW2 - 2,  3 * PW2 - 1};
@@ -201,7 +199,7 @@ __device__ __forceinline__ int fast_score_pol(const uint8_t* p) {
   }
   const int v = p[0];
   const int A = BRIGHT ? W - v : v - W;
-  return A > kFastT ? A - 1 : 0;   // = max(t, A, B) - 1 for corners, 0 otherwise
+  return A > tau ? A - 1 : 0;   // = max(t, A, B) - 1 for corners (tau = t), 0 otherwise; tau > t keeps score >= tau only
 }
 
 // inclusive prefix sum over the 64 lanes of a wave (DPP row shifts + row broadcasts, the gfx9 scan idiom)
@@ -233,36 +231,36 @@ __device__ __forceinline__ uint32_t reserve_packed(uint32_t mine, uint32_t* coun
 // 320- or 768-thread workgroups sit unevenly on the 4 SIMDs.  The wider tile halves the share of the two
 // single-pixel edge groups per score row and of the halo columns.
 constexpr int kFastThreads = 512;
-__global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
-                                                       uint32_t* cand_cnt, uint32_t* cand_key, uint8_t* cand_sc) {
-  __shared__ __attribute__((aligned(16))) uint8_t px[PW2 * PH2];
-  __shared__ __attribute__((aligned(16))) uint8_t sc[PW2 * PH2 + 2 * SCO];   // one dword of slack either side
-  __shared__ uint16_t list1[kList1Cap];
-  __shared__ uint2 llist[kTileCandCap];
-  __shared__ uint32_t nbd, lcount, gbase;   // nbd: brighter count (low 16) | darker count (high 16)
 
-  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so workgroup b
-  // takes tile start(b % 8) + b / 8 of the flattened (frame, tile) list: one XCD walks one contiguous run of tiles and
-  // the cache lines neighbouring tiles share are fetched into one L2 instead of eight.  Speed only, any placement works.
-  int G;
-  {
-    const uint32_t total = gridDim.x, lin = blockIdx.x;
-    const uint32_t xcd = lin & 7u, q = total >> 3, r = total & 7u;
-    G = (int)(xcd * q + (xcd < r ? xcd : r) + (lin >> 3));
-  }
-  const int fi = G / g.total_tiles, bt = G - fi * g.total_tiles;
+struct FastSmem {
+  __attribute__((aligned(16))) uint8_t px[PW2 * PH2];
+  __attribute__((aligned(16))) uint8_t sc[PW2 * PH2 + 2 * SCO];   // one dword of slack either side
+  uint16_t list1[kList1Cap];
+  uint2 llist[kTileCandCap];
+  uint32_t nbd, lcount, gbase;   // nbd: brighter count (low 16) | darker count (high 16)
+};
+
+// One tile of level l of frame fi with score threshold tau (even, >= kFastT): emits exactly the strict 3x3 maxima whose
+// score is >= tau.  With tau = kFastT that is FAST_t<16> + NMS; with a larger tau it is the subset retainBest(2N) can
+// still keep: a pixel whose score is below tau gets 0 in the score tile, which is what a maximum with score >= tau
+// needs to know about it (it loses), and every pixel with score >= tau passes the prefilter at tau and is scored exactly.
+// All threads of the workgroup must call this together; the LDS block may be reused after the call returns.
+__device__ __forceinline__ void fast_tile(const OrbGeometry& g, const FrameSrc& src, const uint8_t* pyr, int fi, int l,
+                                          int t, int tau, uint32_t* cand_cnt, uint32_t* cand_key, uint8_t* cand_sc,
+                                          FastSmem& S_) {
+  uint8_t* px = S_.px;
+  uint8_t* sc = S_.sc;
+  uint16_t* list1 = S_.list1;
+  uint2* llist = S_.llist;
   const int slot = src.slot0 + fi;
-  int l = 0;
-#pragma unroll
-  for (int i = 1; i < kOrbLevels; i++)
-    if (i < g.nlevels && bt >= g.lv[i].tile_base) l = i;
   const OrbLevelInfo L = g.lv[l];
-  const int t = bt - L.tile_base;
   const int x0 = kTileX0 + (t % L.tiles_x) * TW, y0 = kTileY0 + (t / L.tiles_x) * TH;
   int pitch;
   const uint8_t* img = level_ptr(g, src, pyr, fi, l, &pitch);
   const int tid = threadIdx.x, lane = tid & 63;
-  if (tid == 0) { nbd = 0; lcount = 0; }
+  if (tid == 0) { S_.nbd = 0; S_.lcount = 0; }
+  const uint32_t lerp_bright = 0x01010101u * (uint32_t)(128 - tau / 2);          // L + K >= 256  <=>  L >= 128 + tau/2
+  const uint32_t lerp_not_dark = 0x01010101u * (uint32_t)(255 - (254 - tau) / 2);
 
   // stage the pixel tile through aligned 16-byte loads (rows are 16-byte aligned: pitch % 16 == 0, x0 % 64 == 0);
   // zero the score tile
@@ -298,10 +296,10 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
     const uint32_t nC = ~C;
     const uint32_t l0 = __builtin_amdgcn_lerp(D, nC, 0), l4 = __builtin_amdgcn_lerp(E3, nC, 0);
     const uint32_t l8 = __builtin_amdgcn_lerp(U, nC, 0), l12 = __builtin_amdgcn_lerp(W3, nC, 0);
-    const uint32_t b0 = __builtin_amdgcn_lerp(l0, kLerpBright, 0), b4 = __builtin_amdgcn_lerp(l4, kLerpBright, 0);
-    const uint32_t b8 = __builtin_amdgcn_lerp(l8, kLerpBright, 0), b12 = __builtin_amdgcn_lerp(l12, kLerpBright, 0);
-    const uint32_t n0 = __builtin_amdgcn_lerp(l0, kLerpNotDark, 0), n4 = __builtin_amdgcn_lerp(l4, kLerpNotDark, 0);
-    const uint32_t n8 = __builtin_amdgcn_lerp(l8, kLerpNotDark, 0), n12 = __builtin_amdgcn_lerp(l12, kLerpNotDark, 0);
+    const uint32_t b0 = __builtin_amdgcn_lerp(l0, lerp_bright, 0), b4 = __builtin_amdgcn_lerp(l4, lerp_bright, 0);
+    const uint32_t b8 = __builtin_amdgcn_lerp(l8, lerp_bright, 0), b12 = __builtin_amdgcn_lerp(l12, lerp_bright, 0);
+    const uint32_t n0 = __builtin_amdgcn_lerp(l0, lerp_not_dark, 0), n4 = __builtin_amdgcn_lerp(l4, lerp_not_dark, 0);
+    const uint32_t n8 = __builtin_amdgcn_lerp(l8, lerp_not_dark, 0), n12 = __builtin_amdgcn_lerp(l12, lerp_not_dark, 0);
     // the score tile spans tile +- 1 (group 0 holds only x = -1, group 17 only x = TW)
     uint32_t vm = 0;
     if (inner1) {   // uniform: the whole score tile lies inside the scored domain
@@ -320,7 +318,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
     if (__ballot((cb | cd) != 0u) == 0ull) continue;   // flat region: nothing to append for this wave
     const uint32_t e0 = (uint32_t)b << 2;   // byte index of the group's first pixel in the pixel / score tile
     // lane order = x order, so phase 2's LDS reads stay bank-friendly
-    const uint32_t slots = reserve_packed(__popc(cb) | (__popc(cd) << 16), &nbd, lane);
+    const uint32_t slots = reserve_packed(__popc(cb) | (__popc(cd) << 16), &S_.nbd, lane);
     uint32_t k = slots & 0xFFFFu;
     if (cb & 0x80u) list1[k++] = (uint16_t)e0;
     if (cb & 0x8000u) list1[k++] = (uint16_t)(e0 + 1);
@@ -335,23 +333,23 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
   __syncthreads();
 
   // phase 2: exact score of the survivors, one polarity per loop, written into the (zeroed) score tile
-  const uint32_t mb = nbd & 0xFFFFu, md = nbd >> 16;
-  for (uint32_t i = tid; i < mb; i += kFastThreads) {
-    const int e = list1[i];
-    const int s = fast_score_pol<true>(&px[e]);
-    if (s) sc[SCO + e] = (uint8_t)s;
-  }
-  for (uint32_t i = tid; i < md; i += kFastThreads) {
-    const int e = list1[kList1Cap - 1 - i];
-    const int s = fast_score_pol<false>(&px[e]);
-    if (s) sc[SCO + e] = (uint8_t)s;
-  }
-  __syncthreads();
+  const uint32_t mb = S_.nbd & 0xFFFFu, md = S_.nbd >> 16;
+  if (mb | md) {   // uniform
+    for (uint32_t i = tid; i < mb; i += kFastThreads) {
+      const int e = list1[i];
+      const int s = fast_score_pol<true>(&px[e], tau);
+      if (s) sc[SCO + e] = (uint8_t)s;
+    }
+    for (uint32_t i = tid; i < md; i += kFastThreads) {
+      const int e = list1[kList1Cap - 1 - i];
+      const int s = fast_score_pol<false>(&px[e], tau);
+      if (s) sc[SCO + e] = (uint8_t)s;
+    }
+    __syncthreads();
 
-  // phase 3: strict 3x3 NMS + runByImageBorder(31), dense on 4 scores per lane: "c > n" per byte is bit 7 of
-  // lerp(c, ~n) = (c + 255 - n) >> 1; non-corners hold 0 and can never be strictly greater.  The 128 x 32 outputs are
-  // exactly 32 x 32 dwords = two passes of the workgroup.
-  {
+    // phase 3: strict 3x3 NMS + runByImageBorder(31), dense on 4 scores per lane: "c > n" per byte is bit 7 of
+    // lerp(c, ~n) = (c + 255 - n) >> 1; non-corners hold 0 and can never be strictly greater.  The 128 x 32 outputs
+    // are exactly 32 x 32 dwords = two passes of the workgroup.
     const uint32_t* S = reinterpret_cast<const uint32_t*>(sc) + SCO / 4;
     constexpr int SPD = PW2 / 4;                                    // score-tile pitch in dwords
     const int txlo3 = max(0, kEdge - x0), txhi3 = min(TW - 1, L.w - kEdge - 1 - x0);   // 31-px border
@@ -386,29 +384,178 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
         }
       }
       const uint32_t mine = __popc(keep);
-      uint32_t k = reserve_packed(mine, &lcount, lane);
+      uint32_t k = reserve_packed(mine, &S_.lcount, lane);
       const uint32_t key = ((uint32_t)gy << 16) | (uint32_t)(x0 + 4 * j);
       if (keep & 0x80u) llist[k++] = make_uint2(key, C & 0xFFu);
       if (keep & 0x8000u) llist[k++] = make_uint2(key + 1, (C >> 8) & 0xFFu);
       if (keep & 0x800000u) llist[k++] = make_uint2(key + 2, (C >> 16) & 0xFFu);
       if (keep & 0x80000000u) llist[k++] = make_uint2(key + 3, C >> 24);
     }
-  }
-  __syncthreads();
-  const uint32_t n = lcount;
-  if (n == 0) return;
-  if (tid == 0) gbase = atomicAdd(&cand_cnt[slot * kOrbLevels + l], n);
-  __syncthreads();
-  const uint32_t base = gbase;
-  // structure of arrays: the retainBest threshold pass reads every score (1 byte) but only a few hundred keys
-  uint32_t* outk = cand_key + (long long)slot * g.cand_total + L.cand_off;
-  uint8_t* outs = cand_sc + (long long)slot * g.cand_total + L.cand_off;
-  for (uint32_t i = tid; i < n; i += kFastThreads)
-    if (base + i < (uint32_t)L.cand_cap) {
-      const uint2 e = llist[i];
-      outk[base + i] = e.x;
-      outs[base + i] = (uint8_t)e.y;
+    __syncthreads();
+    const uint32_t n = S_.lcount;
+    if (n != 0) {   // uniform
+      if (tid == 0) S_.gbase = atomicAdd(&cand_cnt[slot * kOrbLevels + l], n);
+      __syncthreads();
+      const uint32_t base = S_.gbase;
+      // structure of arrays: the retainBest threshold pass reads every score (1 byte) but only a few hundred keys
+      uint32_t* outk = cand_key + (long long)slot * g.cand_total + L.cand_off;
+      uint8_t* outs = cand_sc + (long long)slot * g.cand_total + L.cand_off;
+      for (uint32_t i = tid; i < n; i += kFastThreads)
+        if (base + i < (uint32_t)L.cand_cap) {
+          const uint2 e = llist[i];
+          outk[base + i] = e.x;
+          outs[base + i] = (uint8_t)e.y;
+        }
     }
+  }
+}
+
+// K3+K4 over every tile of every level of every frame of the batch, threshold tau[slot][level] (k_fast_tau).
+__global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
+                                                       const uint32_t* __restrict__ tau,
+                                                       uint32_t* cand_cnt, uint32_t* cand_key, uint8_t* cand_sc) {
+  __shared__ FastSmem sm;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so workgroup b
+  // takes tile start(b % 8) + b / 8 of the flattened (frame, tile) list: one XCD walks one contiguous run of tiles and
+  // the cache lines neighbouring tiles share are fetched into one L2 instead of eight.  Speed only, any placement works.
+  int G;
+  {
+    const uint32_t total = gridDim.x, lin = blockIdx.x;
+    const uint32_t xcd = lin & 7u, q = total >> 3, r = total & 7u;
+    G = (int)(xcd * q + (xcd < r ? xcd : r) + (lin >> 3));
+  }
+  const int fi = G / g.total_tiles, bt = G - fi * g.total_tiles;
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < kOrbLevels; i++)
+    if (i < g.nlevels && bt >= g.lv[i].tile_base) l = i;
+  const int tv = (int)tau[(src.slot0 + fi) * kOrbLevels + l];
+  fast_tile(g, src, pyr, fi, l, bt - g.lv[l].tile_base, tv, cand_cnt, cand_key, cand_sc, sm);
+}
+
+// ------------------------------------------------------------------ output-sensitive FAST: threshold estimate, check, redo
+// retainBest(2N) (KeyPointsFilter) keeps, per level, the strict maxima whose FAST score reaches the
+// (2N)-th largest one: a few hundred of the tens of thousands a textured frame has.  Every maximum with score >= tau
+// is found exactly by fast_tile(tau), so if at least 2N of them exist the kept set is already complete and nothing
+// below tau was ever needed.  k_fast_tau picks tau per (frame, level) from exact scores on a sparse sample of the
+// level, k_fast_check verifies the count afterwards and queues the (frame, level)s that fell short for a dense
+// (tau = fastThreshold) second pass by k_fast_redo.  Whatever tau is picked, the result is the dense one bit for bit.
+constexpr int kTauBins = 64;          // score histogram bins of width 4
+constexpr int kTauMinHits = 32;       // sample hits the estimate must rest on
+constexpr int kTauOversample = 24;    // estimated pixels with score >= tau per key point to keep (clusters, NMS, ties)
+
+__device__ __forceinline__ int fast_score_px(const uint8_t* p, int pitch) {
+  const int off[16][2] = {{0, 3}, {1, 3}, {2, 2}, {3, 1}, {3, 0}, {3, -1}, {2, -2}, {1, -3},
+                          {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+  int q[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) q[k] = (int)p[off[k][1] * pitch + off[k][0]];
+  int mn3[16], mx3[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    mn3[k] = min(min(q[k], q[(k + 1) & 15]), q[(k + 2) & 15]);
+    mx3[k] = max(max(q[k], q[(k + 1) & 15]), q[(k + 2) & 15]);
+  }
+  int Wb = -1, Wd = 1000;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    Wb = max(Wb, min(min(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]));
+    Wd = min(Wd, max(max(mx3[k], mx3[(k + 3) & 15]), mx3[(k + 6) & 15]));
+  }
+  const int v = p[0];
+  const int A = max(Wb - v, v - Wd);
+  return A > kFastT ? A - 1 : 0;
+}
+
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+
+// One workgroup per (level, frame): exact scores at sampled pixels (rows samp_sy apart with a hashed jitter, columns
+// samp_sx apart -- odd, hashed phase per row, so a periodic texture is not aliased), histogram in LDS, tau = the
+// largest multiple of 4 with enough sample hits above it.
+__global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, const uint8_t* pyr, int force_tau,
+                                                  uint32_t* tau, uint32_t* tau_first) {
+  __shared__ uint32_t hist[kTauBins];
+  const int l = blockIdx.x, fi = blockIdx.y, slot = src.slot0 + fi, tid = threadIdx.x;
+  const OrbLevelInfo L = g.lv[l];
+  int tv = kFastT;
+  if (force_tau > 0) {
+    tv = force_tau;
+  } else if (L.samp_rows > 0) {
+    if (tid < kTauBins) hist[tid] = 0;
+    __syncthreads();
+    int pitch;
+    const uint8_t* img = level_ptr(g, src, pyr, fi, l, &pitch);
+    const int rw = L.w - 2 * kEdge, rh = L.h - 2 * kEdge;
+    const int total = L.samp_rows * L.samp_cols;
+    for (int s = tid; s < total; s += 256) {
+      const int j = s / L.samp_cols, k = s - j * L.samp_cols;
+      const uint32_t hj = hash_u32((uint32_t)(l * 4099 + j) * 2654435761u + 12345u);
+      int y = j * L.samp_sy + (int)(hj % (uint32_t)L.samp_sy);
+      int x = k * L.samp_sx + (int)((hj >> 16) % (uint32_t)L.samp_sx);
+      y = y < rh ? y : rh - 1;
+      x = x < rw ? x : rw - 1;
+      const int sc = fast_score_px(img + (long long)(kEdge + y) * pitch + kEdge + x, pitch);
+      if (sc) atomicAdd(&hist[sc >> 2], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {
+      // suffix sums over the 64 bins: c = hits with score >= 4 * tid
+      uint32_t c = hist[tid];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_down(c, o);
+        if (tid + o < 64) c += up;
+      }
+      const uint32_t factor = (uint32_t)(L.samp_sx * L.samp_sy);
+      uint32_t need = ((uint32_t)kTauOversample * 2u * (uint32_t)L.quota + factor - 1u) / factor;
+      need = need < (uint32_t)kTauMinHits ? (uint32_t)kTauMinHits : need;
+      const unsigned long long ok = __ballot(c >= need);
+      const int top = ok ? 63 - __builtin_clzll(ok) : 0;     // largest qualifying bin
+      tv = 4 * top;
+      if (tv < kFastT + 8) tv = kFastT;                      // nothing to gain: dense
+    }
+  }
+  if (tid == 0) {
+    tau[slot * kOrbLevels + l] = (uint32_t)tv;
+    tau_first[slot * kOrbLevels + l] = (uint32_t)tv;
+  }
+}
+
+// After k_fast: a (frame, level) that ran with tau above fastThreshold and found fewer than 2N maxima is queued for the
+// dense pass (its candidate list restarts from empty).
+__global__ __launch_bounds__(256) void k_fast_check(OrbGeometry g, int slot0, int n_frames, uint32_t* tau,
+                                                    uint32_t* cand_cnt, uint32_t* redo_cnt, uint32_t* redo_list) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_frames * kOrbLevels) return;
+  const int fi = i / kOrbLevels, l = i - fi * kOrbLevels, idx = (slot0 + fi) * kOrbLevels + l;
+  if (l >= g.nlevels || tau[idx] <= (uint32_t)kFastT) return;
+  if (cand_cnt[idx] < 2u * (uint32_t)g.lv[l].quota) {
+    tau[idx] = kFastT;
+    cand_cnt[idx] = 0;
+    redo_list[atomicAdd(redo_cnt, 1u)] = (uint32_t)(fi * kOrbLevels + l);
+  }
+}
+
+// Dense second pass over the queued (frame, level)s: fixed grid, unit u = (queue entry, tile index); tile indices past
+// the level's tile count are skipped (levels differ in size; the queue is short or empty in practice).
+__global__ __launch_bounds__(kFastThreads) void k_fast_redo(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
+                                                            const uint32_t* __restrict__ redo_cnt,
+                                                            const uint32_t* __restrict__ redo_list, int max_tiles,
+                                                            uint32_t* cand_cnt, uint32_t* cand_key, uint8_t* cand_sc) {
+  __shared__ FastSmem sm;
+  const uint32_t n = *redo_cnt;
+  const unsigned long long units = (unsigned long long)n * (unsigned)max_tiles;
+  for (unsigned long long u = blockIdx.x; u < units; u += gridDim.x) {
+    const uint32_t item = redo_list[u / (unsigned)max_tiles];
+    const int t = (int)(u % (unsigned)max_tiles);
+    const int fi = (int)(item / kOrbLevels), l = (int)(item % kOrbLevels);
+    if (t >= g.lv[l].tiles_x * g.lv[l].tiles_y) continue;   // uniform
+    fast_tile(g, src, pyr, fi, l, t, kFastT, cand_cnt, cand_key, cand_sc, sm);
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------ K5+K6: retainBest(2N) by FAST score, Harris response
@@ -1038,6 +1185,7 @@ static void make_table(int src, int dst, uint32_t* tab) {
 OrbPipeline::~OrbPipeline() { destroy(); }
 
 void OrbPipeline::destroy() {
+  hipFree(d_tau_); hipFree(d_redo_); d_tau_ = nullptr; d_redo_ = nullptr;
   hipFree(d_pyr_); hipFree(d_tab_); hipFree(d_cand_cnt_); hipFree(d_cand_); hipFree(d_cand_sc_); hipFree(d_qres_); hipFree(d_done_); hipFree(d_s1_cnt_); hipFree(d_s1_);
   hipFree(d_kp_); hipFree(d_desc_); hipFree(d_kp_cnt_); hipFree(d_status_);
   d_pyr_ = nullptr; d_tab_ = nullptr; d_cand_cnt_ = nullptr; d_cand_ = nullptr; d_cand_sc_ = nullptr; d_qres_ = nullptr; d_done_ = nullptr; d_s1_cnt_ = nullptr;
@@ -1052,12 +1200,19 @@ void OrbPipeline::destroy() {
     if (e_ != hipSuccess) return std::string(#expr) + ": " + hipGetErrorString(e_);       \
   } while (0)
 
-std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_half_up, bool profile) {
+std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_half_up, bool profile, bool dense_fast) {
   if (width < 64 || height < 64 || width > 8192 || height > 8192) return "arg: ORB image size must be in [64, 8192] x [64, 8192]";
   if (max_slots < 2) return "arg: ORB max_slots < 2";
   max_slots_ = max_slots;
   half_up_ = blur_half_up;
   profile_ = profile;
+  // MSF_ORB_FAST_TAU forces the first-pass FAST threshold (tests: a value no level can reach sends every level through
+  // the check + dense second pass); MSF_FLAG_FAST_DENSE = 20 = the plain dense detector
+  force_tau_ = dense_fast ? kFastT : 0;
+  if (const char* e = getenv("MSF_ORB_FAST_TAU")) {
+    const int v = atoi(e) & ~1;
+    if (v >= kFastT && v <= 254) force_tau_ = v;
+  }
   OrbGeometry& g = g_;
   g.nlevels = kOrbLevels;
   g.w0 = width;
@@ -1092,6 +1247,7 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   }
   long long pix = 0;
   int cand = 0, tiles = 0, tab = 0, s1 = 0;
+  g.max_level_tiles = 0;
   for (int l = 0; l < g.nlevels; l++) {
     OrbLevelInfo& L = g.lv[l];
     const float s = (float)pow(scale_factor, (double)l);
@@ -1118,6 +1274,23 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     if (L.tiles_x == 0 || L.tiles_y == 0) L.tiles_x = L.tiles_y = 0;
     L.tile_base = tiles;
     tiles += L.tiles_x * L.tiles_y;
+    if (L.tiles_x * L.tiles_y > g.max_level_tiles) g.max_level_tiles = L.tiles_x * L.tiles_y;
+    // sample lattice of k_fast_tau: about 4096 pixels of the kept region, rows sparser than columns (a sampled pixel
+    // touches 7 rows), column step odd so that block textures with power-of-two periods are not aliased
+    L.samp_sx = L.samp_sy = 1;
+    L.samp_rows = L.samp_cols = 0;
+    if (L.tiles_x > 0) {
+      const int rw = L.w - 2 * kEdge, rh = L.h - 2 * kEdge;
+      const double s2 = (double)rw * rh / 4096.0;
+      int sx = (int)(sqrt(s2 > 1.0 ? s2 : 1.0) / 2.0);
+      sx = (sx < 1 ? 1 : sx) | 1;
+      int sy = (int)(s2 / sx + 0.5);
+      sy = sy < 1 ? 1 : sy;
+      L.samp_sx = sx;
+      L.samp_sy = sy;
+      L.samp_rows = (rh + sy - 1) / sy;
+      L.samp_cols = (rw + sx - 1) / sx;
+    }
     L.tab_off = tab;
     if (l > 0) tab += ((L.w + 3) & ~3) + ((L.h + 3) & ~3);
   }
@@ -1139,6 +1312,9 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   MSF_HIP_TRY(hipMalloc(&d_tab_, htab.size() * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMemcpy(d_tab_, htab.data(), htab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   MSF_HIP_TRY(hipMalloc(&d_cand_cnt_, S * kOrbLevels * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMalloc(&d_tau_, 2 * S * kOrbLevels * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMemset(d_tau_, 0, 2 * S * kOrbLevels * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMalloc(&d_redo_, (1 + S * kOrbLevels) * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMalloc(&d_cand_, S * g.cand_total * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMalloc(&d_cand_sc_, S * g.cand_total));
   MSF_HIP_TRY(hipMalloc(&d_s1_cnt_, S * kOrbLevels * sizeof(uint32_t)));
@@ -1189,6 +1365,7 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
   hipError_t e;
   if ((e = hipMemsetAsync(d_cand_cnt_ + (size_t)src.slot0 * kOrbLevels, 0, (size_t)n * kOrbLevels * 4, st))) return e;
   if ((e = hipMemsetAsync(d_status_ + src.slot0, 0, (size_t)n * 4, st))) return e;
+  if ((e = hipMemsetAsync(d_redo_, 0, 4, st))) return e;
   if (ev_ok_) hipEventRecord(ev_[0], st);
   for (int l = 1; l < g.nlevels; l++) {
     const OrbLevelInfo& L = g.lv[l];
@@ -1207,9 +1384,21 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
                        st, g, src, d_pyr_, d_tab_, l, rth, lds_rows, magic_n16, magic_groups);
   }
   if (ev_ok_) hipEventRecord(ev_[1], st);
-  if (g.total_tiles > 0)
-    hipLaunchKernelGGL(k_fast, dim3((unsigned)g.total_tiles * (unsigned)n), dim3(kFastThreads), 0, st, g, src, d_pyr_, d_cand_cnt_,
-                       d_cand_, d_cand_sc_);
+  if (g.total_tiles > 0) {
+    uint32_t* tau = d_tau_;
+    uint32_t* tau_first = d_tau_ + (size_t)max_slots_ * kOrbLevels;
+    hipLaunchKernelGGL(k_fast_tau, dim3(g.nlevels, n), dim3(256), 0, st, g, src, d_pyr_, force_tau_, tau, tau_first);
+    hipLaunchKernelGGL(k_fast, dim3((unsigned)g.total_tiles * (unsigned)n), dim3(kFastThreads), 0, st, g, src, d_pyr_, tau,
+                       d_cand_cnt_, d_cand_, d_cand_sc_);
+    if (force_tau_ != kFastT) {   // dense first pass: nothing to verify
+      hipLaunchKernelGGL(k_fast_check, dim3((n * kOrbLevels + 255) / 256), dim3(256), 0, st, g, src.slot0, n, tau, d_cand_cnt_,
+                         d_redo_, d_redo_ + 1);
+      long long units = (long long)n * kOrbLevels * g.max_level_tiles;
+      const unsigned grid = (unsigned)(units < 2048 ? units : 2048);
+      hipLaunchKernelGGL(k_fast_redo, dim3(grid), dim3(kFastThreads), 0, st, g, src, d_pyr_, d_redo_, d_redo_ + 1,
+                         g.max_level_tiles, d_cand_cnt_, d_cand_, d_cand_sc_);
+    }
+  }
   if (ev_ok_) hipEventRecord(ev_[2], st);
   hipLaunchKernelGGL(k_thr_harris, dim3(g.nlevels, n), dim3(256), 0, st, g, src, d_pyr_, d_cand_cnt_, d_cand_, d_cand_sc_,
                      d_s1_cnt_, d_s1_, d_status_);
@@ -1305,6 +1494,16 @@ int OrbPipeline::debug_get(int what, int slot, int level, void* host_out, size_t
       for (uint32_t i = 0; i < n; i++) { o[i * 3] = tk[i] & 0xFFFF; o[i * 3 + 1] = tk[i] >> 16; o[i * 3 + 2] = ts[i]; }
       *n_bytes = o.size() * 4;
       memcpy(host_out, o.data(), *n_bytes < cap ? *n_bytes : cap);
+      return 0;
+    }
+    case MSF_DBG_FAST_TAU: {
+      int32_t v[kOrbLevels][2];
+      uint32_t t[2][kOrbLevels];
+      hipMemcpy(t[0], d_tau_ + (size_t)slot * kOrbLevels, sizeof(t[0]), hipMemcpyDeviceToHost);
+      hipMemcpy(t[1], d_tau_ + ((size_t)max_slots_ + slot) * kOrbLevels, sizeof(t[1]), hipMemcpyDeviceToHost);
+      for (int l = 0; l < kOrbLevels; l++) { v[l][0] = (int32_t)t[0][l]; v[l][1] = (int32_t)t[1][l]; }
+      *n_bytes = sizeof(v);
+      memcpy(host_out, v, sizeof(v) < cap ? sizeof(v) : cap);
       return 0;
     }
     case MSF_DBG_STAGE1: {

@@ -29,6 +29,7 @@ struct OrbLevelInfo {
   int s1_off;          // offset (entries) of this level inside a slot's stage-1 array
   int tiles_x, tiles_y, tile_base;  // FAST tiling
   int tab_off;         // offset (entries) of this level's resize tables
+  int samp_sx, samp_sy, samp_rows, samp_cols;   // k_fast_tau's sample lattice over [31, w-31) x [31, h-31); rows 0 = none
   long long pix_off;   // byte offset of this level inside a slot's pyramid blob (levels >= 1)
 };
 
@@ -36,6 +37,7 @@ struct OrbGeometry {
   int nlevels;
   int w0, h0;
   int total_tiles;
+  int max_level_tiles;     // largest tile count of one level
   int cand_total;          // candidate entries per slot
   int s1_total;            // stage-1 entries per slot
   long long pyr_bytes;     // pyramid blob bytes per slot (levels 1..)
@@ -58,7 +60,7 @@ class OrbPipeline {
   OrbPipeline() = default;
   ~OrbPipeline();
   // returns empty string on success
-  std::string init(int width, int height, int max_slots, bool blur_half_up, bool profile);
+  std::string init(int width, int height, int max_slots, bool blur_half_up, bool profile, bool dense_fast = false);
   void destroy();
 
   // extract features of n frames into slots [src.slot0, src.slot0 + n)
@@ -76,10 +78,13 @@ class OrbPipeline {
   OrbGeometry g_{};
   int max_slots_ = 0;
   bool half_up_ = false, profile_ = false;
+  int force_tau_ = 0;              // > 0: every (frame, level) starts at this FAST score threshold (20 = dense)
   // device storage
   uint8_t* d_pyr_ = nullptr;
   uint32_t* d_tab_ = nullptr;      // resize tables: per output x / y, source offset | w1 << 16
   uint32_t* d_cand_cnt_ = nullptr; // [slots][8]
+  uint32_t* d_tau_ = nullptr;      // [2][slots][8] FAST score threshold used per (slot, level) | first estimate
+  uint32_t* d_redo_ = nullptr;     // [1 + slots * 8] dense-pass queue: count, entries (frame * 8 + level)
   uint32_t* d_cand_ = nullptr;     // [slots][cand_total] key = y << 16 | x
   uint8_t* d_cand_sc_ = nullptr;   // [slots][cand_total] FAST score
   uint32_t* d_s1_cnt_ = nullptr;   // [slots][8]

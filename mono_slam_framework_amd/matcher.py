@@ -214,6 +214,10 @@ class FeatureMatcher(_Matcher):
     def fast_candidates(self, slot, level):
         return self._debug(_lib.DBG_FAST_CANDS, slot, level, np.int32, 1 << 20).reshape(-1, 3)
 
+    def fast_tau(self, slot):
+        """int32 [8, 2]: per level the FAST score threshold the candidate list was built with, and its first estimate."""
+        return self._debug(_lib.DBG_FAST_TAU, slot, 0, np.int32, 64).reshape(-1, 2)
+
     def stage1(self, slot, level):
         return self._debug(_lib.DBG_STAGE1, slot, level, _lib.KP_DTYPE, 1 << 18)
 

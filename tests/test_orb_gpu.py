@@ -49,23 +49,37 @@ def _sorted_cands(c):
     return c[np.lexsort((c[:, 0], c[:, 1]))]
 
 
+def _cands_at(oracle_cands, tau):
+    c = np.asarray(oracle_cands).reshape(-1, 3)
+    return c[c[:, 2] >= tau]
+
+
+@pytest.mark.parametrize("dense", [False, True], ids=["tau", "dense"])
 @pytest.mark.parametrize("name,a,b", CASES, ids=[c[0] for c in CASES])
-def test_stage_parity(name, a, b):
+def test_stage_parity(name, a, b, dense):
+    """Every stage against the oracle, with the output-sensitive FAST pass (candidate list = the maxima with score >=
+    the level's threshold; everything retainBest(2N) keeps is unchanged) and with MSF_FLAG_FAST_DENSE (all maxima)."""
+    from mono_slam_framework_amd import _lib
     h, w = a.shape
-    fm = _matcher(w, h)
+    fm = _matcher(w, h, flags=_lib.MSF_FLAG_FAST_DENSE if dense else 0)
     got = fm.MatchFrames(a, b)
     orc = oracle_orb.FeatureMatcherOracle(0.8)
     exp = orc.MatchFrames(a, b)
     oa, ob = orc._orb(a.shape)
     for slot, o in ((0, oa), (1, ob)):
         sizes = fm.level_sizes()
+        taus = fm.fast_tau(slot)
+        if dense:
+            assert (taus[:, 0] == 20).all()
         for l in range(8):
             assert (int(sizes[l][0]), int(sizes[l][1])) == o.level_size(l)
             assert int(sizes[l][3]) == o.level_quota(l)
             if l >= 1:
                 np.testing.assert_array_equal(fm.level_pixels(slot, l), o.level_pixels(l), err_msg="pyramid L%d" % l)
-            np.testing.assert_array_equal(_sorted_cands(fm.fast_candidates(slot, l)), _sorted_cands(o.fast_candidates(l)),
-                                          err_msg="FAST candidates L%d" % l)
+            assert taus[l][0] >= 20 and taus[l][0] % 2 == 0 and (taus[l][0] == taus[l][1] or taus[l][0] == 20)
+            np.testing.assert_array_equal(_sorted_cands(fm.fast_candidates(slot, l)),
+                                          _sorted_cands(_cands_at(o.fast_candidates(l), taus[l][0])),
+                                          err_msg="FAST candidates L%d (tau %d)" % (l, taus[l][0]))
         s1o = o.stage1_keypoints()
         for l in range(8):
             g = fm.stage1(slot, l)
@@ -85,6 +99,34 @@ def test_stage_parity(name, a, b):
             np.testing.assert_array_equal(kg[f].view(np.uint32), ko[f].view(np.uint32), err_msg=f)
         np.testing.assert_array_equal(dg, do, err_msg="descriptors")
     np.testing.assert_array_equal(got, exp, err_msg="match list")
+
+
+def test_fast_threshold_fallback_path():
+    """MSF_ORB_FAST_TAU forces a first-pass threshold no level can satisfy (and one that only some can): every level
+    must then go through k_fast_check + the dense second pass and still give the oracle's lists bit for bit."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from mono_slam_framework_amd import synth\n"
+        "from mono_slam_framework_amd.matcher import FeatureMatcher\n"
+        "from oracle import orb\n"
+        "for (w, h, mode) in ((640, 480, 0), (333, 257, 1), (1280, 720, 2)):\n"
+        "    A, B = synth.synth_batch(900, 3, w, h, mode=mode)\n"
+        "    fm = FeatureMatcher(0.8, w, h, max_batch_pairs=3)\n"
+        "    got = fm.match_batch(list(A), list(B))\n"
+        "    t = fm.fast_tau(0)\n"
+        "    assert (t[:, 1] == int(sys.argv[1])).all(), t\n"
+        "    assert (t[:, 0] == 20).any(), t\n"
+        "    for i in range(3):\n"
+        "        exp = orb.FeatureMatcherOracle(0.8).MatchFrames(A[i], B[i])\n"
+        "        assert len(exp) > 20 and np.array_equal(got[i], exp), (w, h, mode, i)\n"
+    ) % ROOT
+    for tau in ("254", "150"):
+        env = dict(os.environ, MSF_ORB_FAST_TAU=tau)
+        r = subprocess.run([sys.executable, "-c", code, tau], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
 
 
 def test_threshold_and_blur_mode():

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Prints, for a few synthetic pairs, the FAST score threshold every level ran with (first estimate -> used)."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mono_slam_framework_amd import synth                      # noqa: E402
+from mono_slam_framework_amd.matcher import FeatureMatcher     # noqa: E402
+
+w, h, n = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+A, B = synth.synth_batch(0, n, w, h, mode=mode)
+fm = FeatureMatcher(0.6, w, h, max_batch_pairs=n)
+fm.match_batch(list(A), list(B))
+redo = 0
+for s in range(2 * n):
+    t = fm.fast_tau(s)
+    redo += int((t[:, 0] != t[:, 1]).sum())
+    if s < 4:
+        cnt = [len(fm.fast_candidates(s, l)) for l in range(8)]
+        print("slot", s, "tau first->used", [(int(a), int(b)) for b, a in t], "cands", cnt)
+print("levels redone: %d of %d" % (redo, 16 * n))
