@@ -176,11 +176,11 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m) {   // set bit
 
 // cornerScore<16> restricted to one polarity (a pixel cannot have both a brighter and a darker arc of 9):
 // max over the 16 arcs of the minimum of e over the arc, e = p - v (brighter) or v - p (darker).
-template <bool BRIGHT>
+template <bool BRIGHT, int PITCH = PW2>
 __device__ __forceinline__ int fast_score_pol(const uint8_t* p, int tau) {
-  constexpr int off[16] = {3 * PW2 + 0,  3 * PW2 + 1,  2 * PW2 + 2,  1 * PW2 + 3,  0 * PW2 + 3, -1 * PW2 + 3,
-                           -2 * PW2 + 2, -3 * PW2 + 1, -3 * PW2 + 0, -3 * PW2 - 1, -2 * PW2 - 2, -1 * PW2 - 3,
-                           0 * PW2 - 3,  1 * PW2 - 3,  2 * PW2 - 2,  3 * PW2 - 1};
+  constexpr int off[16] = {3 * PITCH + 0,  3 * PITCH + 1,  2 * PITCH + 2,  1 * PITCH + 3,  0 * PITCH + 3, -1 * PITCH + 3,
+                           -2 * PITCH + 2, -3 * PITCH + 1, -3 * PITCH + 0, -3 * PITCH - 1, -2 * PITCH - 2, -1 * PITCH - 3,
+                           0 * PITCH - 3,  1 * PITCH - 3,  2 * PITCH - 2,  3 * PITCH - 1};
   // brighter: max over arcs of min(p - v) = (max over arcs of min p) - v ; darker: max of min(v - p) = v - (min of max p):
   // the window networks run on the raw ring pixels and v is applied once at the end.
   int q[16];
@@ -201,6 +201,15 @@ __device__ __forceinline__ int fast_score_pol(const uint8_t* p, int tau) {
   const int A = BRIGHT ? W - v : v - W;
   return A > tau ? A - 1 : 0;   // = max(t, A, B) - 1 for corners (tau = t), 0 otherwise; tau > t keeps score >= tau only
 }
+
+// LDS operations of one wave execute in issue order: a wavefront-scope fence (compiler ordering + lgkmcnt wait) is all
+// that wave-private LDS data needs between a write by one lane and a read by another
+#define MSF_WAVE_SYNC()                                        \
+  do {                                                         \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     \
+    __builtin_amdgcn_wave_barrier();                           \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
+  } while (0)
 
 // inclusive prefix sum over the 64 lanes of a wave (DPP row shifts + row broadcasts, the gfx9 scan idiom)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
@@ -410,9 +419,8 @@ __device__ __forceinline__ void fast_tile(const OrbGeometry& g, const FrameSrc& 
   }
 }
 
-// K3+K4 over every tile of every level of every frame of the batch, threshold tau[slot][level] (k_fast_tau).
+// K3+K4 over every tile of every level of every frame of the batch at fastThreshold (MSF_FLAG_FAST_DENSE).
 __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
-                                                       const uint32_t* __restrict__ tau,
                                                        uint32_t* cand_cnt, uint32_t* cand_key, uint8_t* cand_sc) {
   __shared__ FastSmem sm;
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so workgroup b
@@ -429,8 +437,556 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
 #pragma unroll
   for (int i = 1; i < kOrbLevels; i++)
     if (i < g.nlevels && bt >= g.lv[i].tile_base) l = i;
+  fast_tile(g, src, pyr, fi, l, bt - g.lv[l].tile_base, kFastT, cand_cnt, cand_key, cand_sc, sm);
+}
+
+// ---- the same tile for a threshold tau well above fastThreshold, where pixels that pass the prefilter are rare
+// (a few per cent) but almost every wave still meets one: the dense kernel's per-wave scan + append, its two scoring
+// loops and the dense NMS passes would run for nearly every wave.  Here the prefilter only drops one packed record per
+// 4-px group with a survivor (one LDS atomic by the lanes concerned), and the records are expanded, scored and
+// non-maximum-suppressed as lists.  28-row tiles: 34 x 30 prefilter tasks = two full passes of the 512 threads.
+constexpr int STH = 28, SSH = STH + 2, SPH2 = STH + 2 * HY;
+constexpr int kGCap = GPR * SSH;            // one record per prefilter task: cannot overflow
+constexpr int kPxChunk = kFastThreads;      // records expanded per round, one per thread
+constexpr int kPCap = 4 * kPxChunk;         // pixel entries of a round (brighter from the front, darker from the back)
+constexpr int kHitCap = 512;                // scored corners (score >= tau) handled by the list NMS; more -> dense NMS
+constexpr int kTileCandCapS = TW * STH / 4;
+static_assert(kGCap <= 2 * kFastThreads, "sparse prefilter is two passes");
+
+struct FastSparseSmem {
+  __attribute__((aligned(16))) uint8_t px[PW2 * SPH2];
+  __attribute__((aligned(16))) uint8_t sc[PW2 * SPH2 + 2 * SCO];
+  uint2 glist[kGCap];               // (dword index of the group in the tile, brighter flags | darker flags >> 1)
+  uint16_t plist[kPCap];
+  uint16_t hlist[kHitCap];
+  uint32_t okey[kTileCandCapS];
+  uint8_t osc[kTileCandCapS];
+  uint32_t wtot[kFastThreads / 64];
+  uint32_t n1, nh, lcount, gbase;
+};
+
+__device__ __forceinline__ void fast_tile_sparse(const OrbGeometry& g, const FrameSrc& src, const uint8_t* pyr, int fi,
+                                                 int l, int t, int tau, uint32_t* cand_cnt, uint32_t* cand_key,
+                                                 uint8_t* cand_sc, FastSparseSmem& S_, int ablate) {
+  uint8_t* px = S_.px;
+  uint8_t* sc = S_.sc;
+  const int slot = src.slot0 + fi;
+  const OrbLevelInfo L = g.lv[l];
+  const int x0 = kTileX0 + (t % L.tiles_x) * TW, y0 = kTileY0 + (t / L.tiles_x) * STH;
+  int pitch;
+  const uint8_t* img = level_ptr(g, src, pyr, fi, l, &pitch);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) { S_.n1 = 0; S_.nh = 0; S_.lcount = 0; }
+  const uint32_t lerp_bright = 0x01010101u * (uint32_t)(128 - tau / 2);
+  const uint32_t lerp_not_dark = 0x01010101u * (uint32_t)(255 - (254 - tau) / 2);
+
+  for (int i = tid; i < (PW2 / 16) * SPH2; i += kFastThreads) {
+    const int r = i / (PW2 / 16), c = i % (PW2 / 16);
+    const int gx = x0 - HX + 16 * c, gy = y0 - HY + r;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (gx >= 0 && gx + 16 <= pitch && gy >= 0 && gy < L.h)
+      v = *reinterpret_cast<const uint4*>(img + (long long)gy * pitch + gx);
+    reinterpret_cast<uint4*>(px)[i] = v;
+  }
+  for (int i = tid; i < (PW2 * SPH2 + 2 * SCO) / 4; i += kFastThreads) reinterpret_cast<uint32_t*>(sc)[i] = 0;
+  __syncthreads();
+  if (ablate == 1) { if (px[tid] == 77 && sc[tid] == 3) cand_cnt[0] = 1; return; }
+
+  // phase 1: cardinal prefilter at tau, 4 px per lane (see fast_tile); survivors leave one record per group
+  const uint32_t* T = reinterpret_cast<const uint32_t*>(px);
+  constexpr int kLo = kEdge - 1;
+  const int txlo = max(-1, kLo - x0), txhi = min(TW, L.w - kLo - 1 - x0);
+  const bool inner1 = txlo == -1 && txhi == TW && y0 - 1 >= kLo && y0 + STH < L.h - kLo;
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    const int i = pass * kFastThreads + tid;
+    const int ic = i < kGCap ? i : kGCap - 1;
+    const int sr = ic / GPR, gq = ic % GPR;
+    const int ty = sr - 1, tx0 = 4 * gq - 4;
+    const int b = ((ty + HY) * PW2 + tx0 + HX) >> 2;
+    const uint32_t C = T[b], Lf = T[b - 1], Rt = T[b + 1];
+    const uint32_t U = T[b - 3 * (PW2 / 4)], D = T[b + 3 * (PW2 / 4)];
+    const uint32_t W3 = __builtin_amdgcn_alignbyte(C, Lf, 1);
+    const uint32_t E3 = __builtin_amdgcn_alignbyte(Rt, C, 3);
+    const uint32_t nC = ~C;
+    const uint32_t l0 = __builtin_amdgcn_lerp(D, nC, 0), l4 = __builtin_amdgcn_lerp(E3, nC, 0);
+    const uint32_t l8 = __builtin_amdgcn_lerp(U, nC, 0), l12 = __builtin_amdgcn_lerp(W3, nC, 0);
+    const uint32_t b0 = __builtin_amdgcn_lerp(l0, lerp_bright, 0), b4 = __builtin_amdgcn_lerp(l4, lerp_bright, 0);
+    const uint32_t b8 = __builtin_amdgcn_lerp(l8, lerp_bright, 0), b12 = __builtin_amdgcn_lerp(l12, lerp_bright, 0);
+    const uint32_t n0 = __builtin_amdgcn_lerp(l0, lerp_not_dark, 0), n4 = __builtin_amdgcn_lerp(l4, lerp_not_dark, 0);
+    const uint32_t n8 = __builtin_amdgcn_lerp(l8, lerp_not_dark, 0), n12 = __builtin_amdgcn_lerp(l12, lerp_not_dark, 0);
+    uint32_t vm = 0;
+    if (inner1) {
+      vm = gq == 0 ? 0x80000000u : gq == GPR - 1 ? 0x00000080u : 0x80808080u;
+      vm = i < kGCap ? vm : 0u;
+    } else {
+      const int gy = y0 + ty;
+      int first = txlo - tx0, last = txhi - tx0;
+      first = first < 0 ? 0 : first;
+      last = last > 3 ? 3 : last;
+      if (i < kGCap && gy >= kLo && gy < L.h - kLo && first <= last)
+        vm = (0x80808080u << (8 * first)) & (0x80808080u >> (8 * (3 - last)));
+    }
+    const uint32_t cb = ((b0 | b8) & (b4 | b12)) & vm;
+    const uint32_t cd = ~((n0 & n8) | (n4 & n12)) & vm;
+    if (cb | cd) S_.glist[atomicAdd(&S_.n1, 1u)] = make_uint2((uint32_t)b, cb | (cd >> 1));
+  }
+  __syncthreads();
+
+  // phase 2: expand the records into per-pixel entries (one polarity from each end of plist) and score them exactly
+  const uint32_t n1 = S_.n1;
+  if (ablate == 2) { if (n1 == 77777) cand_cnt[0] = 1; return; }
+  for (uint32_t c0 = 0; c0 < n1; c0 += kPxChunk) {   // uniform; one round unless the tile is crowded
+    uint32_t e0 = 0, mb = 0, md = 0;
+    if (c0 + tid < n1) {
+      const uint2 rec = S_.glist[c0 + tid];
+      e0 = rec.x << 2;
+      mb = rec.y & 0x80808080u;
+      md = (rec.y << 1) & 0x80808080u;
+    }
+    const uint32_t mine = __popc(mb) | (__popc(md) << 16);
+    const uint32_t incl = wave_incl_scan(mine);
+    if (lane == 63) S_.wtot[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kFastThreads / 64; w++) {
+      const uint32_t v = S_.wtot[w];
+      base += w < wave ? v : 0u;
+      total += v;
+    }
+    const uint32_t slots = base + incl - mine;
+    uint32_t k = slots & 0xFFFFu;
+    if (mb & 0x80u) S_.plist[k++] = (uint16_t)e0;
+    if (mb & 0x8000u) S_.plist[k++] = (uint16_t)(e0 + 1);
+    if (mb & 0x800000u) S_.plist[k++] = (uint16_t)(e0 + 2);
+    if (mb & 0x80000000u) S_.plist[k++] = (uint16_t)(e0 + 3);
+    k = kPCap - 1 - (slots >> 16);
+    if (md & 0x80u) S_.plist[k--] = (uint16_t)e0;
+    if (md & 0x8000u) S_.plist[k--] = (uint16_t)(e0 + 1);
+    if (md & 0x800000u) S_.plist[k--] = (uint16_t)(e0 + 2);
+    if (md & 0x80000000u) S_.plist[k--] = (uint16_t)(e0 + 3);
+    __syncthreads();
+    const uint32_t nb = total & 0xFFFFu, nd = total >> 16;
+    for (uint32_t i = tid; i < nb; i += kFastThreads) {
+      const int e = S_.plist[i];
+      const int s = fast_score_pol<true>(&px[e], tau);
+      if (s) {
+        sc[SCO + e] = (uint8_t)s;
+        const uint32_t hh = atomicAdd(&S_.nh, 1u);
+        if (hh < (uint32_t)kHitCap) S_.hlist[hh] = (uint16_t)e;
+      }
+    }
+    for (uint32_t i = tid; i < nd; i += kFastThreads) {
+      const int e = S_.plist[kPCap - 1 - i];
+      const int s = fast_score_pol<false>(&px[e], tau);
+      if (s) {
+        sc[SCO + e] = (uint8_t)s;
+        const uint32_t hh = atomicAdd(&S_.nh, 1u);
+        if (hh < (uint32_t)kHitCap) S_.hlist[hh] = (uint16_t)e;
+      }
+    }
+    __syncthreads();
+  }
+
+  // phase 3: strict 3x3 NMS + runByImageBorder(31) over the scored corners
+  const uint32_t nh = S_.nh;
+  if (ablate == 3) { if (nh == 77777) cand_cnt[0] = 1; return; }
+  if (nh == 0) return;   // uniform
+  if (nh <= (uint32_t)kHitCap) {
+    for (uint32_t i = tid; i < nh; i += kFastThreads) {
+      const int e = S_.hlist[i];
+      const uint8_t* q = sc + SCO + e;
+      const int c = q[0];
+      const int ry = e / PW2, tx = e - ry * PW2 - HX, ty = ry - HY;
+      const int gx = x0 + tx, gy = y0 + ty;
+      bool keep = tx >= 0 && tx < TW && ty >= 0 && ty < STH && gx >= kEdge && gx < L.w - kEdge && gy >= kEdge &&
+                  gy < L.h - kEdge;
+      keep = keep && c > q[-1] && c > q[1] && c > q[-PW2 - 1] && c > q[-PW2] && c > q[-PW2 + 1] && c > q[PW2 - 1] &&
+             c > q[PW2] && c > q[PW2 + 1];
+      if (keep) {
+        const uint32_t k = atomicAdd(&S_.lcount, 1u);
+        S_.okey[k] = ((uint32_t)gy << 16) | (uint32_t)gx;
+        S_.osc[k] = (uint8_t)c;
+      }
+    }
+  } else {
+    const uint32_t* S = reinterpret_cast<const uint32_t*>(sc) + SCO / 4;
+    constexpr int SPD = PW2 / 4;
+    const int txlo3 = max(0, kEdge - x0), txhi3 = min(TW - 1, L.w - kEdge - 1 - x0);
+    for (int i = tid; i < (TW / 4) * STH; i += kFastThreads) {
+      const int ty = i / (TW / 4), j = i % (TW / 4);
+      const int w = (ty + HY) * SPD + HX / 4 + j;
+      const uint32_t C = S[w];
+      const int gy = y0 + ty;
+      if (C == 0 || gy < kEdge || gy >= L.h - kEdge) continue;
+      const uint32_t Cl = S[w - 1], Cr = S[w + 1];
+      const uint32_t U = S[w - SPD], Ul = S[w - SPD - 1], Ur = S[w - SPD + 1];
+      const uint32_t D = S[w + SPD], Dl = S[w + SPD - 1], Dr = S[w + SPD + 1];
+      uint32_t keep = __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(C, Cl, 3), 0);
+      keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(Cr, C, 1), 0);
+      keep &= __builtin_amdgcn_lerp(C, ~U, 0);
+      keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(U, Ul, 3), 0);
+      keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(Ur, U, 1), 0);
+      keep &= __builtin_amdgcn_lerp(C, ~D, 0);
+      keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(D, Dl, 3), 0);
+      keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(Dr, D, 1), 0);
+      int first = txlo3 - 4 * j, last = txhi3 - 4 * j;
+      first = first < 0 ? 0 : first;
+      last = last > 3 ? 3 : last;
+      keep &= first <= last ? (0x80808080u << (8 * first)) & (0x80808080u >> (8 * (3 - last))) : 0u;
+      if (keep == 0u) continue;
+      uint32_t k = atomicAdd(&S_.lcount, (uint32_t)__popc(keep));
+      const uint32_t key = ((uint32_t)gy << 16) | (uint32_t)(x0 + 4 * j);
+      if (keep & 0x80u) { S_.okey[k] = key; S_.osc[k++] = (uint8_t)(C & 0xFFu); }
+      if (keep & 0x8000u) { S_.okey[k] = key + 1; S_.osc[k++] = (uint8_t)((C >> 8) & 0xFFu); }
+      if (keep & 0x800000u) { S_.okey[k] = key + 2; S_.osc[k++] = (uint8_t)((C >> 16) & 0xFFu); }
+      if (keep & 0x80000000u) { S_.okey[k] = key + 3; S_.osc[k++] = (uint8_t)(C >> 24); }
+    }
+  }
+  __syncthreads();
+  const uint32_t n = S_.lcount;
+  if (n == 0) return;   // uniform
+  if (tid == 0) S_.gbase = atomicAdd(&cand_cnt[slot * kOrbLevels + l], n);
+  __syncthreads();
+  const uint32_t base = S_.gbase;
+  uint32_t* outk = cand_key + (long long)slot * g.cand_total + L.cand_off;
+  uint8_t* outs = cand_sc + (long long)slot * g.cand_total + L.cand_off;
+  for (uint32_t i = tid; i < n; i += kFastThreads)
+    if (base + i < (uint32_t)L.cand_cap) {
+      outk[base + i] = S_.okey[i];
+      outs[base + i] = S_.osc[i];
+    }
+}
+
+// First pass over the 28-row tiling: (frame, level)s whose threshold is above fastThreshold; the others are already in
+// the dense queue (k_fast_tau put them there).
+__global__ __launch_bounds__(kFastThreads) void k_fast_sparse(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
+                                                              const uint32_t* __restrict__ tau, uint32_t* cand_cnt,
+                                                              uint32_t* cand_key, uint8_t* cand_sc, int ablate) {
+  __shared__ FastSparseSmem sm;
+  int G;
+  {
+    const uint32_t total = gridDim.x, lin = blockIdx.x;
+    const uint32_t xcd = lin & 7u, q = total >> 3, r = total & 7u;
+    G = (int)(xcd * q + (xcd < r ? xcd : r) + (lin >> 3));
+  }
+  const int fi = G / g.total_tiles_s, bt = G - fi * g.total_tiles_s;
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < kOrbLevels; i++)
+    if (i < g.nlevels && bt >= g.lv[i].tile_base_s) l = i;
   const int tv = (int)tau[(src.slot0 + fi) * kOrbLevels + l];
-  fast_tile(g, src, pyr, fi, l, bt - g.lv[l].tile_base, tv, cand_cnt, cand_key, cand_sc, sm);
+  if (tv <= kFastT) return;   // uniform
+  if (ablate == 4) return;
+  fast_tile_sparse(g, src, pyr, fi, l, bt - g.lv[l].tile_base_s, tv, cand_cnt, cand_key, cand_sc, sm, ablate);
+}
+
+// ------------------------------------------------------------------ K3+K4, streaming form for tau well above fastThreshold
+// The tile kernels above are bound by workgroup dispatch and by their barriers once the scoring work is gone (measured:
+// 1.9 ms to dispatch the 10^6 tiles of a 1024-pair batch, 6 ms of phase latency).  Here ONE WAVE walks a column strip
+// of the level, 248 px wide (lanes 1..62 hold 4 px each, lanes 0 and 63 the halo), top to bottom, with no barrier:
+//  * every pixel is fetched once, as one dword per lane and row, four rows ahead of its use (register queue q0..q3);
+//  * the rows live in a wave-private LDS ring of 16 rows (+ mirror rows, so the +-3-row ring reads never wrap);
+//  * the cardinal prefilter of row y reads rows y-3, y, y+3 from the ring, the left / right dwords come by DPP;
+//  * groups with a survivor leave one record; every 8 rows (or when the record list fills) the records are expanded,
+//    scored exactly (fast_score_pol on the ring), the scores go into a second ring and, as (address, row) hits, into a
+//    list; strict 3x3 NMS + runByImageBorder run over the hits whose three score rows are final; kept corners are
+//    buffered and appended to the level's candidate list with one global atomic per buffer flush.
+// Emits exactly the maxima with score >= tau of the strip's pixels, like fast_tile(tau).
+constexpr int SR = 64;                   // output rows per strip
+constexpr int RK = 16;                   // ring rows (power of two)
+constexpr int SPX = 248;                 // output px per strip
+constexpr int kSX0 = 24;                 // x of lane 0's first px in strip 0: lane 1 then holds px 28..31
+constexpr int kSGCap = 128, kSPCap = 256, kSHCap = 256, kSOCap = 128;
+constexpr int kFlushRows = 8;            // rows between flushes: RK >= kFlushRows + 3 (queue) + 6 (ring reach), see put
+static_assert(kFlushRows + 2 < RK - 5, "ring too short for the flush interval");
+
+struct StreamSmem {
+  __attribute__((aligned(16))) uint8_t px[(RK + 6) * 256 + 16];   // rows: 3 mirror, RK, 3 mirror
+  __attribute__((aligned(16))) uint8_t sc[(RK + 2) * 256 + 16];   // rows: 1 mirror, RK, 1 mirror
+  uint2 g[kSGCap];
+  uint32_t p[kSPCap];
+  uint32_t h[kSHCap];
+  uint32_t okey[kSOCap];
+  uint8_t osc[kSOCap];
+};
+
+__global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
+                                                    const uint32_t* __restrict__ tau, uint32_t* cand_cnt,
+                                                    uint32_t* cand_key, uint8_t* cand_sc, int ablate) {
+  __shared__ StreamSmem sm;
+  int G;
+  {
+    const uint32_t total = gridDim.x, lin = blockIdx.x;
+    const uint32_t xcd = lin & 7u, q = total >> 3, r = total & 7u;
+    G = (int)(xcd * q + (xcd < r ? xcd : r) + (lin >> 3));
+  }
+  const int fi = G / g.total_strips, bt = G - fi * g.total_strips;
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < kOrbLevels; i++)
+    if (i < g.nlevels && bt >= g.lv[i].strip_base) l = i;
+  const int slot = src.slot0 + fi;
+  const int tv = (int)tau[slot * kOrbLevels + l];
+  if (tv <= kFastT) return;
+  const OrbLevelInfo L = g.lv[l];
+  const int t = bt - L.strip_base;
+  const int sy = t / L.strips_x, sx = t - sy * L.strips_x;
+  const int lane = threadIdx.x;
+  int pitch;
+  const uint8_t* img = level_ptr(g, src, pyr, fi, l, &pitch);
+  const uint32_t lerp_bright = 0x01010101u * (uint32_t)(128 - tv / 2);
+  const uint32_t lerp_not_dark = 0x01010101u * (uint32_t)(255 - (254 - tv) / 2);
+
+  const int xs = kSX0 + SPX * sx;                 // x of lane 0's first px
+  const int xb = xs + 4 * lane;
+  const int ya = kEdge + SR * sy, yb = min(ya + SR, L.h - kEdge);   // output rows [ya, yb)
+  const int y0 = ya - 1;                          // first scored row (NMS neighbour of row ya); rel row r = y - y0
+  const int r_last = yb - y0;                     // last scored row (NMS neighbour of row yb - 1)
+  // scored domain of this lane's 4 px: [30, w-30), halo lanes score only the px next to the strip
+  uint32_t vm = 0, om = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int x = xb + j;
+    const bool in_lane = (lane >= 1 && lane <= 62) || (lane == 0 && j == 3) || (lane == 63 && j == 0);
+    if (in_lane && x >= kEdge - 1 && x < L.w - (kEdge - 1)) vm |= 0x80u << (8 * j);
+    if (lane >= 1 && lane <= 62 && x >= kEdge && x < L.w - kEdge) om |= 0x80u << (8 * j);
+  }
+  const bool ld_ok = xb + 4 <= pitch;
+  const uint8_t* gp = img + xb;
+  uint32_t* pxw = reinterpret_cast<uint32_t*>(sm.px);
+  uint32_t* scw = reinterpret_cast<uint32_t*>(sm.sc);
+  uint8_t* pxb = sm.px;
+  uint8_t* scb = sm.sc;
+
+  // wave-uniform state
+  uint32_t nG = 0, nH = 0, nO = 0;
+  int nms_lo = 1, last_flush = -1;               // first rel row whose NMS is pending; rel row of the last flush
+
+#define LOAD_ROW(y_) ((ld_ok && (y_) < L.h) ? *reinterpret_cast<const uint32_t*>(gp + (long long)(y_) * pitch) : 0u)
+  // pixel row with ring index k (= rel row + 3) -> ring row k & 15, stored at px row (k & 15) + 3; its score row is zeroed
+#define PUT_ROW(k_, v_)                                                                      \
+  do {                                                                                       \
+    const int sl_ = (k_) & (RK - 1);                                                         \
+    pxw[(sl_ + 3) * 64 + lane] = (v_);                                                       \
+    if (sl_ < 3) pxw[(sl_ + 3 + RK) * 64 + lane] = (v_);                                     \
+    if (sl_ >= RK - 3) pxw[(sl_ + 3 - RK) * 64 + lane] = (v_);                               \
+    scw[(sl_ + 1) * 64 + lane] = 0u;                                                         \
+    if (sl_ == 0) scw[(RK + 1) * 64 + lane] = 0u;                                            \
+    if (sl_ == RK - 1) scw[lane] = 0u;                                                       \
+  } while (0)
+
+  auto flush_out = [&]() {
+    if (nO == 0) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&cand_cnt[slot * kOrbLevels + l], nO);
+    base = __builtin_amdgcn_readfirstlane(base);
+    uint32_t* outk = cand_key + (long long)slot * g.cand_total + L.cand_off;
+    uint8_t* outs = cand_sc + (long long)slot * g.cand_total + L.cand_off;
+    for (uint32_t i = lane; i < nO; i += 64)
+      if (base + i < (uint32_t)L.cand_cap) {
+        outk[base + i] = sm.okey[i];
+        outs[base + i] = sm.osc[i];
+      }
+    MSF_WAVE_SYNC();
+    nO = 0;
+  };
+
+  // append (keep ? one output : nothing) of every lane, in lane order
+  auto emit = [&](bool keep, uint32_t key, uint32_t score) {
+    const unsigned long long bal = __ballot(keep);
+    if (bal == 0ull) return;
+    const uint32_t cnt = (uint32_t)__popcll(bal);
+    if (nO + cnt > (uint32_t)kSOCap) flush_out();
+    if (keep) {
+      const uint32_t k = nO + mbcnt64(bal);
+      sm.okey[k] = key;
+      sm.osc[k] = (uint8_t)score;
+    }
+    nO += cnt;
+  };
+
+  // scores everything recorded so far (rel rows <= s), then NMS of rel rows [nms_lo, s - 1]
+  auto flush = [&](int s) {
+    bool overflow = false;
+    if (ablate == 2) { nG = 0; last_flush = s; return; }
+    for (uint32_t c0 = 0; c0 < nG; c0 += 64) {
+      uint32_t e0 = 0, mb = 0, md = 0, rr = 0;
+      if (c0 + lane < nG) {
+        const uint2 rec = sm.g[c0 + lane];
+        rr = rec.x >> 8;
+        e0 = ((((rr + 3) & (RK - 1)) + 3) << 8) + ((rec.x & 63u) << 2);   // px-ring byte address of the group's px 0
+        mb = rec.y & 0x80808080u;
+        md = (rec.y << 1) & 0x80808080u;
+      }
+      const uint32_t mine = __popc(mb) | (__popc(md) << 16);
+      const uint32_t incl = wave_incl_scan(mine);
+      const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+      const uint32_t slots = incl - mine;
+      const uint32_t tag = rr << 16;
+      uint32_t k = slots & 0xFFFFu;
+      if (mb & 0x80u) sm.p[k++] = e0 | tag;
+      if (mb & 0x8000u) sm.p[k++] = (e0 + 1) | tag;
+      if (mb & 0x800000u) sm.p[k++] = (e0 + 2) | tag;
+      if (mb & 0x80000000u) sm.p[k++] = (e0 + 3) | tag;
+      k = kSPCap - 1 - (slots >> 16);
+      if (md & 0x80u) sm.p[k--] = e0 | tag;
+      if (md & 0x8000u) sm.p[k--] = (e0 + 1) | tag;
+      if (md & 0x800000u) sm.p[k--] = (e0 + 2) | tag;
+      if (md & 0x80000000u) sm.p[k--] = (e0 + 3) | tag;
+      MSF_WAVE_SYNC();
+      const uint32_t nb = total & 0xFFFFu, nd = total >> 16;
+#pragma unroll
+      for (int pol = 0; pol < 2; pol++) {
+        const uint32_t cntp = pol == 0 ? nb : nd;
+        for (uint32_t i0 = 0; i0 < cntp; i0 += 64) {
+          const uint32_t i = i0 + lane;
+          int sv = 0;
+          uint32_t pe = 0;
+          if (i < cntp) {
+            pe = pol == 0 ? sm.p[i] : sm.p[kSPCap - 1 - i];
+            const uint8_t* q = pxb + (pe & 0xFFFFu);
+            sv = pol == 0 ? fast_score_pol<true, 256>(q, tv) : fast_score_pol<false, 256>(q, tv);
+            if (sv) {
+              const uint32_t a = (pe & 0xFFFFu) - 512u;    // score-ring byte address (ring row r at sc row r + 1)
+              scb[a] = (uint8_t)sv;
+              const uint32_t ringrow = (a >> 8) - 1u;
+              if (ringrow == 0u) scb[a + RK * 256] = (uint8_t)sv;
+              if (ringrow == (uint32_t)(RK - 1)) scb[a - RK * 256] = (uint8_t)sv;
+            }
+          }
+          const unsigned long long bal = __ballot(sv != 0);
+          if (bal) {
+            const uint32_t cnt = (uint32_t)__popcll(bal);
+            if (nH + cnt > (uint32_t)kSHCap) overflow = true;
+            else {
+              if (sv) sm.h[nH + mbcnt64(bal)] = (pe & 0xFFFFu) - 512u | (pe & 0xFFFF0000u);
+              nH += cnt;
+            }
+          }
+        }
+      }
+      MSF_WAVE_SYNC();
+    }
+    nG = 0;
+    if (ablate == 3) { nH = 0; last_flush = s; return; }
+    // ---- NMS of rel rows [nms_lo, s - 1]: all their neighbours' scores are final
+    const int hi = s - 1;
+    if (!overflow) {
+      for (uint32_t i0 = 0; i0 < nH; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        bool keep = false;
+        uint32_t key = 0, c = 0;
+        if (i < nH) {
+          const uint32_t he = sm.h[i];
+          const int rr = (int)(he >> 16);
+          const uint32_t a = he & 0xFFFFu;
+          const uint8_t* q = scb + a;
+          c = q[0];
+          const int xl = (int)(a & 255u);                 // byte inside the row = 4 * lane + j
+          const int x = xs + xl, y = y0 + rr;
+          keep = rr >= nms_lo && rr <= hi && rr >= 1 && rr < r_last && xl >= 4 && xl < 252 && x >= kEdge &&
+                 x < L.w - kEdge;
+          keep = keep && c > q[-1] && c > q[1] && c > q[-257] && c > q[-256] && c > q[-255] && c > q[255] &&
+                 c > q[256] && c > q[257];
+          key = ((uint32_t)y << 16) | (uint32_t)x;
+        }
+        emit(keep, key, c);
+      }
+    } else {
+      for (int rr = nms_lo; rr <= hi; rr++) {
+        if (rr < 1 || rr >= r_last) continue;
+        const int w = ((((rr + 3) & (RK - 1)) + 1) << 6) + lane;
+        const uint32_t C = scw[w];
+        if (__ballot(C != 0u) == 0ull) continue;
+        const uint32_t Cl = scw[w - 1], Cr = scw[w + 1];
+        const uint32_t U = scw[w - 64], Ul = scw[w - 65], Ur = scw[w - 63];
+        const uint32_t D = scw[w + 64], Dl = scw[w + 63], Dr = scw[w + 65];
+        uint32_t keep = __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(C, Cl, 3), 0);
+        keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(Cr, C, 1), 0);
+        keep &= __builtin_amdgcn_lerp(C, ~U, 0);
+        keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(U, Ul, 3), 0);
+        keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(Ur, U, 1), 0);
+        keep &= __builtin_amdgcn_lerp(C, ~D, 0);
+        keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(D, Dl, 3), 0);
+        keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(Dr, D, 1), 0);
+        keep &= om;
+        const uint32_t ykey = (uint32_t)(y0 + rr) << 16;
+#pragma unroll
+        for (int j = 0; j < 4; j++) emit((keep >> (8 * j + 7)) & 1u, ykey | (uint32_t)(xb + j), (C >> (8 * j)) & 255u);
+      }
+    }
+    // the list restarts with the scored corners of row s (their NMS needs row s + 1)
+    nH = 0;
+    {
+      const uint32_t rowaddr = (((uint32_t)(s + 3) & (RK - 1)) + 1u) << 8;
+      const uint32_t C = scw[(rowaddr >> 2) + lane];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const bool hit = ((C >> (8 * j)) & 255u) != 0u;
+        const unsigned long long bal = __ballot(hit);
+        if (bal) {
+          if (hit) sm.h[nH + mbcnt64(bal)] = (rowaddr + 4u * lane + j) | ((uint32_t)s << 16);
+          nH += (uint32_t)__popcll(bal);
+        }
+      }
+    }
+    MSF_WAVE_SYNC();
+    nms_lo = s;
+    last_flush = s;
+  };
+
+  // prefilter of rel row s (ring index s + 3): rows s, s + 3, s + 6 of the ring
+  auto step = [&](int s) {
+    if (s > r_last || ablate == 1) return;
+    const uint32_t U = pxw[(((s) & (RK - 1)) + 3) * 64 + lane];
+    const uint32_t C = pxw[(((s + 3) & (RK - 1)) + 3) * 64 + lane];
+    const uint32_t D = pxw[(((s + 6) & (RK - 1)) + 3) * 64 + lane];
+    const uint32_t Lf = __builtin_amdgcn_update_dpp(0u, C, 0x138, 0xf, 0xf, true);   // wave_shr:1: lane i <- lane i - 1
+    const uint32_t Rt = __builtin_amdgcn_update_dpp(0u, C, 0x130, 0xf, 0xf, true);   // wave_shl:1: lane i <- lane i + 1
+    const uint32_t W3 = __builtin_amdgcn_alignbyte(C, Lf, 1);
+    const uint32_t E3 = __builtin_amdgcn_alignbyte(Rt, C, 3);
+    const uint32_t nC = ~C;
+    const uint32_t l0 = __builtin_amdgcn_lerp(D, nC, 0), l4 = __builtin_amdgcn_lerp(E3, nC, 0);
+    const uint32_t l8 = __builtin_amdgcn_lerp(U, nC, 0), l12 = __builtin_amdgcn_lerp(W3, nC, 0);
+    const uint32_t b0 = __builtin_amdgcn_lerp(l0, lerp_bright, 0), b4 = __builtin_amdgcn_lerp(l4, lerp_bright, 0);
+    const uint32_t b8 = __builtin_amdgcn_lerp(l8, lerp_bright, 0), b12 = __builtin_amdgcn_lerp(l12, lerp_bright, 0);
+    const uint32_t n0 = __builtin_amdgcn_lerp(l0, lerp_not_dark, 0), n4 = __builtin_amdgcn_lerp(l4, lerp_not_dark, 0);
+    const uint32_t n8 = __builtin_amdgcn_lerp(l8, lerp_not_dark, 0), n12 = __builtin_amdgcn_lerp(l12, lerp_not_dark, 0);
+    const uint32_t cb = ((b0 | b8) & (b4 | b12)) & vm;
+    const uint32_t cd = ~((n0 & n8) | (n4 & n12)) & vm;
+    const bool has = (cb | cd) != 0u;
+    const unsigned long long bal = __ballot(has);
+    if (bal) {
+      if (has) sm.g[nG + mbcnt64(bal)] = make_uint2((uint32_t)lane | ((uint32_t)s << 8), cb | (cd >> 1));
+      nG += (uint32_t)__popcll(bal);
+    }
+    if (nG > (uint32_t)(kSGCap - 64) || s - last_flush >= kFlushRows || s == r_last) {
+      MSF_WAVE_SYNC();
+      flush(s);
+    }
+  };
+
+  // warm-up: pixel rows y0 - 3 .. y0 + 2 (ring indices 0 .. 5), then the queue holds rows y0 + 3 .. y0 + 6
+  {
+    uint32_t v[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) v[k] = LOAD_ROW(y0 - 3 + k);
+#pragma unroll
+    for (int k = 0; k < 6; k++) PUT_ROW(k, v[k]);
+  }
+  uint32_t q0 = LOAD_ROW(y0 + 3), q1 = LOAD_ROW(y0 + 4), q2 = LOAD_ROW(y0 + 5), q3 = LOAD_ROW(y0 + 6);
+  // the scored domain's rows: all of [y0, y0 + r_last] lie in [30, h - 30)
+  for (int s = 0; s <= r_last; s += 4) {
+    PUT_ROW(s + 6, q0); q0 = LOAD_ROW(y0 + s + 7); MSF_WAVE_SYNC(); step(s);
+    PUT_ROW(s + 7, q1); q1 = LOAD_ROW(y0 + s + 8); MSF_WAVE_SYNC(); step(s + 1);
+    PUT_ROW(s + 8, q2); q2 = LOAD_ROW(y0 + s + 9); MSF_WAVE_SYNC(); step(s + 2);
+    PUT_ROW(s + 9, q3); q3 = LOAD_ROW(y0 + s + 10); MSF_WAVE_SYNC(); step(s + 3);
+  }
+  flush_out();
+#undef LOAD_ROW
+#undef PUT_ROW
 }
 
 // ------------------------------------------------------------------ output-sensitive FAST: threshold estimate, check, redo
@@ -476,7 +1032,8 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
 // samp_sx apart -- odd, hashed phase per row, so a periodic texture is not aliased), histogram in LDS, tau = the
 // largest multiple of 4 with enough sample hits above it.
 __global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, const uint8_t* pyr, int force_tau,
-                                                  uint32_t* tau, uint32_t* tau_first) {
+                                                  uint32_t* tau, uint32_t* tau_first, uint32_t* redo_cnt,
+                                                  uint32_t* redo_list) {
   __shared__ uint32_t hist[kTauBins];
   const int l = blockIdx.x, fi = blockIdx.y, slot = src.slot0 + fi, tid = threadIdx.x;
   const OrbLevelInfo L = g.lv[l];
@@ -521,6 +1078,8 @@ __global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, c
   if (tid == 0) {
     tau[slot * kOrbLevels + l] = (uint32_t)tv;
     tau_first[slot * kOrbLevels + l] = (uint32_t)tv;
+    // nothing to gain from a threshold: straight to the dense pass
+    if (tv <= kFastT && L.tiles_x > 0) redo_list[atomicAdd(redo_cnt, 1u)] = (uint32_t)(fi * kOrbLevels + l);
   }
 }
 
@@ -548,7 +1107,11 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_redo(OrbGeometry g, Frame
   __shared__ FastSmem sm;
   const uint32_t n = *redo_cnt;
   const unsigned long long units = (unsigned long long)n * (unsigned)max_tiles;
-  for (unsigned long long u = blockIdx.x; u < units; u += gridDim.x) {
+  // workgroups b, b + 8, ... share an XCD (L2): they walk one contiguous eighth of the units together
+  const unsigned long long per_xcd = (units + 7ull) >> 3;
+  const unsigned long long u_begin = (blockIdx.x & 7u) * per_xcd;
+  const unsigned long long u_end = u_begin + per_xcd < units ? u_begin + per_xcd : units;
+  for (unsigned long long u = u_begin + (blockIdx.x >> 3); u < u_end; u += (gridDim.x >> 3)) {
     const uint32_t item = redo_list[u / (unsigned)max_tiles];
     const int t = (int)(u % (unsigned)max_tiles);
     const int fi = (int)(item / kOrbLevels), l = (int)(item % kOrbLevels);
@@ -857,12 +1420,6 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
   uint32_t* raw32 = reinterpret_cast<uint32_t*>(raw);
   // Each wave owns its LDS patch and walks its own key points: waves never wait for each other.  LDS operations of
   // one wave are executed in issue order, so a wavefront-scope fence (compiler ordering) is all the staging needs.
-#define MSF_WAVE_SYNC()                                        \
-  do {                                                         \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     \
-    __builtin_amdgcn_wave_barrier();                           \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
-  } while (0)
   for (uint32_t k = blockIdx.x * 4 + wave; k < count; k += gridDim.x * 4) {
     const bool active = true;
     msf_keypoint* K = kp + (long long)slot * kKpCap + k;
@@ -975,7 +1532,6 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
     MSF_WAVE_SYNC();
   }
 }
-#undef MSF_WAVE_SYNC
 
 // ------------------------------------------------------------------ K11: brute-force Hamming 2-NN + ratio + ordered compaction
 constexpr int kTrainChunk = 1024;  // train descriptors staged per LDS pass (32 KB)
@@ -1246,7 +1802,7 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     for (int v = 0; v < 16; v++) g.umax[v] = umax[v];
   }
   long long pix = 0;
-  int cand = 0, tiles = 0, tab = 0, s1 = 0;
+  int cand = 0, tiles = 0, tiles_s = 0, strips = 0, tab = 0, s1 = 0;
   g.max_level_tiles = 0;
   for (int l = 0; l < g.nlevels; l++) {
     OrbLevelInfo& L = g.lv[l];
@@ -1274,6 +1830,14 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     if (L.tiles_x == 0 || L.tiles_y == 0) L.tiles_x = L.tiles_y = 0;
     L.tile_base = tiles;
     tiles += L.tiles_x * L.tiles_y;
+    L.tiles_y_s = L.tiles_x > 0 ? (L.h - 2 * kEdge + STH - 1) / STH : 0;
+    L.tile_base_s = tiles_s;
+    tiles_s += L.tiles_x * L.tiles_y_s;
+    // strips: lane 1 of strip 0 holds px 28..31; 248 output px per strip over [31, w - 31), 64 output rows
+    L.strips_x = L.tiles_x > 0 ? (L.w - kEdge - (kSX0 + 4) + SPX - 1) / SPX : 0;
+    L.strips_y = L.tiles_x > 0 ? (L.h - 2 * kEdge + SR - 1) / SR : 0;
+    L.strip_base = strips;
+    strips += L.strips_x * L.strips_y;
     if (L.tiles_x * L.tiles_y > g.max_level_tiles) g.max_level_tiles = L.tiles_x * L.tiles_y;
     // sample lattice of k_fast_tau: about 4096 pixels of the kept region, rows sparser than columns (a sampled pixel
     // touches 7 rows), column step odd so that block textures with power-of-two periods are not aliased
@@ -1298,6 +1862,8 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   g.cand_total = cand;
   g.s1_total = s1;
   g.total_tiles = tiles;
+  g.total_tiles_s = tiles_s;
+  g.total_strips = strips;
 
   std::vector<uint32_t> htab(tab > 0 ? tab : 1, 0u);
   for (int l = 1; l < g.nlevels; l++) {
@@ -1387,14 +1953,25 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
   if (g.total_tiles > 0) {
     uint32_t* tau = d_tau_;
     uint32_t* tau_first = d_tau_ + (size_t)max_slots_ * kOrbLevels;
-    hipLaunchKernelGGL(k_fast_tau, dim3(g.nlevels, n), dim3(256), 0, st, g, src, d_pyr_, force_tau_, tau, tau_first);
-    hipLaunchKernelGGL(k_fast, dim3((unsigned)g.total_tiles * (unsigned)n), dim3(kFastThreads), 0, st, g, src, d_pyr_, tau,
-                       d_cand_cnt_, d_cand_, d_cand_sc_);
-    if (force_tau_ != kFastT) {   // dense first pass: nothing to verify
+    hipLaunchKernelGGL(k_fast_tau, dim3(g.nlevels, n), dim3(256), 0, st, g, src, d_pyr_, force_tau_, tau, tau_first, d_redo_,
+                       d_redo_ + 1);
+    if (force_tau_ == kFastT) {   // MSF_FLAG_FAST_DENSE: the plain detector over every tile, nothing to verify
+      hipLaunchKernelGGL(k_fast, dim3((unsigned)g.total_tiles * (unsigned)n), dim3(kFastThreads), 0, st, g, src, d_pyr_,
+                         d_cand_cnt_, d_cand_, d_cand_sc_);
+    } else {
+      if (getenv("MSF_ORB_TILE_SPARSE"))
+      hipLaunchKernelGGL(k_fast_sparse, dim3((unsigned)g.total_tiles_s * (unsigned)n), dim3(kFastThreads), 0, st, g, src,
+                         d_pyr_, tau, d_cand_cnt_, d_cand_, d_cand_sc_, getenv("MSF_ORB_ABLATE") ? atoi(getenv("MSF_ORB_ABLATE")) : 0);
+      else
+      hipLaunchKernelGGL(k_fast_stream, dim3((unsigned)g.total_strips * (unsigned)n), dim3(64), 0, st, g, src, d_pyr_, tau,
+                         d_cand_cnt_, d_cand_, d_cand_sc_, getenv("MSF_ORB_ABLATE") ? atoi(getenv("MSF_ORB_ABLATE")) : 0);
+      if (!getenv("MSF_ORB_ABLATE"))
       hipLaunchKernelGGL(k_fast_check, dim3((n * kOrbLevels + 255) / 256), dim3(256), 0, st, g, src.slot0, n, tau, d_cand_cnt_,
                          d_redo_, d_redo_ + 1);
+      // fixed grid (a multiple of 8: see the XCD-contiguous unit order), sized to what the batch could need
       long long units = (long long)n * kOrbLevels * g.max_level_tiles;
-      const unsigned grid = (unsigned)(units < 2048 ? units : 2048);
+      unsigned grid = (unsigned)(units < 2048 ? units : 2048);
+      grid = (grid + 7u) & ~7u;
       hipLaunchKernelGGL(k_fast_redo, dim3(grid), dim3(kFastThreads), 0, st, g, src, d_pyr_, d_redo_, d_redo_ + 1,
                          g.max_level_tiles, d_cand_cnt_, d_cand_, d_cand_sc_);
     }

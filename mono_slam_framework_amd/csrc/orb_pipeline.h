@@ -27,7 +27,9 @@ struct OrbLevelInfo {
   int cand_cap;        // capacity of the FAST candidate list of this level
   int cand_off;        // offset (entries) of this level inside a slot's candidate array
   int s1_off;          // offset (entries) of this level inside a slot's stage-1 array
-  int tiles_x, tiles_y, tile_base;  // FAST tiling
+  int tiles_x, tiles_y, tile_base;  // FAST tiling (128 x 32 tiles, dense kernel)
+  int tiles_y_s, tile_base_s;       // 128 x 28 tiling of the output-sensitive first pass
+  int strips_x, strips_y, strip_base;   // 248 x 64 column strips of the streaming first pass (one wave each)
   int tab_off;         // offset (entries) of this level's resize tables
   int samp_sx, samp_sy, samp_rows, samp_cols;   // k_fast_tau's sample lattice over [31, w-31) x [31, h-31); rows 0 = none
   long long pix_off;   // byte offset of this level inside a slot's pyramid blob (levels >= 1)
@@ -37,6 +39,8 @@ struct OrbGeometry {
   int nlevels;
   int w0, h0;
   int total_tiles;
+  int total_tiles_s;
+  int total_strips;
   int max_level_tiles;     // largest tile count of one level
   int cand_total;          // candidate entries per slot
   int s1_total;            // stage-1 entries per slot
