@@ -687,30 +687,57 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_sparse(OrbGeometry g, Fra
 // 1.9 ms to dispatch the 10^6 tiles of a 1024-pair batch, 6 ms of phase latency).  Here ONE WAVE walks a column strip
 // of the level, 248 px wide (lanes 1..62 hold 4 px each, lanes 0 and 63 the halo), top to bottom, with no barrier:
 //  * every pixel is fetched once, as one dword per lane and row, four rows ahead of its use (register queue q0..q3);
-//  * the rows live in a wave-private LDS ring of 16 rows (+ mirror rows, so the +-3-row ring reads never wrap);
+//  * the rows live in a wave-private LDS ring of 16 rows;
 //  * the cardinal prefilter of row y reads rows y-3, y, y+3 from the ring, the left / right dwords come by DPP;
-//  * groups with a survivor leave one record; every 8 rows (or when the record list fills) the records are expanded,
-//    scored exactly (fast_score_pol on the ring), the scores go into a second ring and, as (address, row) hits, into a
-//    list; strict 3x3 NMS + runByImageBorder run over the hits whose three score rows are final; kept corners are
-//    buffered and appended to the level's candidate list with one global atomic per buffer flush.
+//  * groups with a survivor leave one record; every few rows (or when the record list fills) the records are expanded
+//    into one pixel list, scored exactly (darker-type pixels on the complemented values, so one routine serves both
+//    polarities), the scores go into a second ring and, as (address, row) hits, into a list; strict 3x3 NMS +
+//    runByImageBorder run over the hits whose three score rows are final; kept corners are buffered and appended to
+//    the level's candidate list with one global atomic per buffer flush.
 // Emits exactly the maxima with score >= tau of the strip's pixels, like fast_tile(tau).
 constexpr int SR = 64;                   // output rows per strip
 constexpr int RK = 16;                   // ring rows (power of two)
 constexpr int SPX = 248;                 // output px per strip
 constexpr int kSX0 = 24;                 // x of lane 0's first px in strip 0: lane 1 then holds px 28..31
-constexpr int kSGCap = 128, kSPCap = 256, kSHCap = 256, kSOCap = 128;
-constexpr int kFlushRows = 8;            // rows between flushes: RK >= kFlushRows + 3 (queue) + 6 (ring reach), see put
-static_assert(kFlushRows + 2 < RK - 5, "ring too short for the flush interval");
+constexpr int kSGCap = 320, kSPCap = 256, kSHCap = 128, kSOCap = 96;
+// A row put at step s overwrites rel row s - 13; pending records read pixel rows >= last_flush - 2 and pending NMS
+// score rows >= last_flush - 1: the flush interval (a multiple of the four-step group) must stay below 11 rows.
+constexpr int kFlushRows = 8;
+static_assert(kFlushRows < RK - 5 && kFlushRows % 4 == 0, "ring too short for the flush interval");
 
 struct StreamSmem {
-  __attribute__((aligned(16))) uint8_t px[(RK + 6) * 256 + 16];   // rows: 3 mirror, RK, 3 mirror
-  __attribute__((aligned(16))) uint8_t sc[(RK + 2) * 256 + 16];   // rows: 1 mirror, RK, 1 mirror
+  __attribute__((aligned(16))) uint8_t px[RK * 256];
+  __attribute__((aligned(16))) uint8_t sc[RK * 256];
   uint2 g[kSGCap];
   uint32_t p[kSPCap];
   uint32_t h[kSHCap];
   uint32_t okey[kSOCap];
   uint8_t osc[kSOCap];
 };
+
+// cornerScore<16> of the pixel at byte x of ring row r0 (rows wrap modulo RK), both polarities in one routine:
+// darker-type = brighter-type on 255 - p.  Returns score (>= tau) or 0.
+__device__ __forceinline__ int stream_score(const uint8_t* ring, uint32_t r0, uint32_t x, bool dark, int tau) {
+  uint32_t rb[7];
+#pragma unroll
+  for (int d = 0; d < 7; d++) rb[d] = (((r0 + (uint32_t)(d + RK - 3)) & (uint32_t)(RK - 1)) << 8) + x;
+  // ring offsets (dx, dy), k = 0..15: (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
+  constexpr int dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+  constexpr int dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+  const uint32_t flip = dark ? 255u : 0u;
+  int q[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) q[k] = (int)((uint32_t)ring[rb[dy[k] + 3] + dx[k]] ^ flip);
+  const int v = (int)((uint32_t)ring[rb[3]] ^ flip);
+  int m3[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) m3[k] = min(min(q[k], q[(k + 1) & 15]), q[(k + 2) & 15]);
+  int W = -1;
+#pragma unroll
+  for (int k = 0; k < 16; k++) W = max(W, min(min(m3[k], m3[(k + 3) & 15]), m3[(k + 6) & 15]));
+  const int A = W - v;
+  return A > tau ? A - 1 : 0;
+}
 
 __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
                                                     const uint32_t* __restrict__ tau, uint32_t* cand_cnt,
@@ -753,8 +780,10 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
     if (in_lane && x >= kEdge - 1 && x < L.w - (kEdge - 1)) vm |= 0x80u << (8 * j);
     if (lane >= 1 && lane <= 62 && x >= kEdge && x < L.w - kEdge) om |= 0x80u << (8 * j);
   }
-  const bool ld_ok = xb + 4 <= pitch;
-  const uint8_t* gp = img + xb;
+  // lanes right of the row's end re-read its last dword (never used: vm = 0 there); rows past the image re-read the
+  // last row (only in the idle tail steps after r_last)
+  const uint8_t* gp = img + (xb + 4 <= pitch ? xb : pitch - 4);
+  const int ylim = L.h - 1;
   uint32_t* pxw = reinterpret_cast<uint32_t*>(sm.px);
   uint32_t* scw = reinterpret_cast<uint32_t*>(sm.sc);
   uint8_t* pxb = sm.px;
@@ -764,17 +793,13 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
   uint32_t nG = 0, nH = 0, nO = 0;
   int nms_lo = 1, last_flush = -1;               // first rel row whose NMS is pending; rel row of the last flush
 
-#define LOAD_ROW(y_) ((ld_ok && (y_) < L.h) ? *reinterpret_cast<const uint32_t*>(gp + (long long)(y_) * pitch) : 0u)
-  // pixel row with ring index k (= rel row + 3) -> ring row k & 15, stored at px row (k & 15) + 3; its score row is zeroed
+#define LOAD_ROW(y_) (*reinterpret_cast<const uint32_t*>(gp + (long long)min((y_), ylim) * pitch))
+  // pixel row with ring index k (= rel row + 3) -> ring row k & 15; its score row is zeroed
 #define PUT_ROW(k_, v_)                                                                      \
   do {                                                                                       \
     const int sl_ = (k_) & (RK - 1);                                                         \
-    pxw[(sl_ + 3) * 64 + lane] = (v_);                                                       \
-    if (sl_ < 3) pxw[(sl_ + 3 + RK) * 64 + lane] = (v_);                                     \
-    if (sl_ >= RK - 3) pxw[(sl_ + 3 - RK) * 64 + lane] = (v_);                               \
-    scw[(sl_ + 1) * 64 + lane] = 0u;                                                         \
-    if (sl_ == 0) scw[(RK + 1) * 64 + lane] = 0u;                                            \
-    if (sl_ == RK - 1) scw[lane] = 0u;                                                       \
+    pxw[sl_ * 64 + lane] = (v_);                                                             \
+    scw[sl_ * 64 + lane] = 0u;                                                               \
   } while (0)
 
   auto flush_out = [&]() {
@@ -809,61 +834,50 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
 
   // scores everything recorded so far (rel rows <= s), then NMS of rel rows [nms_lo, s - 1]
   auto flush = [&](int s) {
-    bool overflow = false;
+    // the hit list was rebuilt from one row's scores at the end of the last flush: if that row held more corners than
+    // the list, this NMS is the dense one
+    bool overflow = nH > (uint32_t)kSHCap;
     if (ablate == 2) { nG = 0; last_flush = s; return; }
-    for (uint32_t c0 = 0; c0 < nG; c0 += 64) {
-      uint32_t e0 = 0, mb = 0, md = 0, rr = 0;
-      if (c0 + lane < nG) {
+    // 32 records per round: at most 32 x 8 pixel entries (a pixel can pass both polarity prefilters)
+    for (uint32_t c0 = 0; c0 < nG; c0 += 32) {
+      uint32_t e0 = 0, mb = 0, md = 0;
+      if (lane < 32 && c0 + lane < nG) {
         const uint2 rec = sm.g[c0 + lane];
-        rr = rec.x >> 8;
-        e0 = ((((rr + 3) & (RK - 1)) + 3) << 8) + ((rec.x & 63u) << 2);   // px-ring byte address of the group's px 0
+        // pixel entry: byte in row (8 bits) | ring row (4 bits) << 8 | dark << 12 | rel row << 16
+        e0 = ((rec.x & 63u) << 2) | ((((rec.x >> 8) + 3u) & (uint32_t)(RK - 1)) << 8) | ((rec.x >> 8) << 16);
         mb = rec.y & 0x80808080u;
         md = (rec.y << 1) & 0x80808080u;
       }
-      const uint32_t mine = __popc(mb) | (__popc(md) << 16);
+      const uint32_t mine = __popc(mb) + __popc(md);
       const uint32_t incl = wave_incl_scan(mine);
       const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-      const uint32_t slots = incl - mine;
-      const uint32_t tag = rr << 16;
-      uint32_t k = slots & 0xFFFFu;
-      if (mb & 0x80u) sm.p[k++] = e0 | tag;
-      if (mb & 0x8000u) sm.p[k++] = (e0 + 1) | tag;
-      if (mb & 0x800000u) sm.p[k++] = (e0 + 2) | tag;
-      if (mb & 0x80000000u) sm.p[k++] = (e0 + 3) | tag;
-      k = kSPCap - 1 - (slots >> 16);
-      if (md & 0x80u) sm.p[k--] = e0 | tag;
-      if (md & 0x8000u) sm.p[k--] = (e0 + 1) | tag;
-      if (md & 0x800000u) sm.p[k--] = (e0 + 2) | tag;
-      if (md & 0x80000000u) sm.p[k--] = (e0 + 3) | tag;
+      uint32_t k = incl - mine;
+      if (mb & 0x80u) sm.p[k++] = e0;
+      if (mb & 0x8000u) sm.p[k++] = e0 + 1;
+      if (mb & 0x800000u) sm.p[k++] = e0 + 2;
+      if (mb & 0x80000000u) sm.p[k++] = e0 + 3;
+      e0 |= 0x1000u;
+      if (md & 0x80u) sm.p[k++] = e0;
+      if (md & 0x8000u) sm.p[k++] = e0 + 1;
+      if (md & 0x800000u) sm.p[k++] = e0 + 2;
+      if (md & 0x80000000u) sm.p[k++] = e0 + 3;
       MSF_WAVE_SYNC();
-      const uint32_t nb = total & 0xFFFFu, nd = total >> 16;
-#pragma unroll
-      for (int pol = 0; pol < 2; pol++) {
-        const uint32_t cntp = pol == 0 ? nb : nd;
-        for (uint32_t i0 = 0; i0 < cntp; i0 += 64) {
-          const uint32_t i = i0 + lane;
-          int sv = 0;
-          uint32_t pe = 0;
-          if (i < cntp) {
-            pe = pol == 0 ? sm.p[i] : sm.p[kSPCap - 1 - i];
-            const uint8_t* q = pxb + (pe & 0xFFFFu);
-            sv = pol == 0 ? fast_score_pol<true, 256>(q, tv) : fast_score_pol<false, 256>(q, tv);
-            if (sv) {
-              const uint32_t a = (pe & 0xFFFFu) - 512u;    // score-ring byte address (ring row r at sc row r + 1)
-              scb[a] = (uint8_t)sv;
-              const uint32_t ringrow = (a >> 8) - 1u;
-              if (ringrow == 0u) scb[a + RK * 256] = (uint8_t)sv;
-              if (ringrow == (uint32_t)(RK - 1)) scb[a - RK * 256] = (uint8_t)sv;
-            }
-          }
-          const unsigned long long bal = __ballot(sv != 0);
-          if (bal) {
-            const uint32_t cnt = (uint32_t)__popcll(bal);
-            if (nH + cnt > (uint32_t)kSHCap) overflow = true;
-            else {
-              if (sv) sm.h[nH + mbcnt64(bal)] = (pe & 0xFFFFu) - 512u | (pe & 0xFFFF0000u);
-              nH += cnt;
-            }
+      for (uint32_t i0 = 0; i0 < total; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        int sv = 0;
+        uint32_t pe = 0;
+        if (i < total) {
+          pe = sm.p[i];
+          sv = stream_score(pxb, (pe >> 8) & 15u, pe & 255u, (pe & 0x1000u) != 0u, tv);
+          if (sv) scb[pe & 0xFFFu] = (uint8_t)sv;
+        }
+        const unsigned long long bal = __ballot(sv != 0);
+        if (bal) {
+          const uint32_t cnt = (uint32_t)__popcll(bal);
+          if (overflow || nH + cnt > (uint32_t)kSHCap) overflow = true;
+          else {
+            if (sv) sm.h[nH + mbcnt64(bal)] = pe & 0xFFFF0FFFu;
+            nH += cnt;
           }
         }
       }
@@ -881,15 +895,16 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
         if (i < nH) {
           const uint32_t he = sm.h[i];
           const int rr = (int)(he >> 16);
-          const uint32_t a = he & 0xFFFFu;
-          const uint8_t* q = scb + a;
-          c = q[0];
-          const int xl = (int)(a & 255u);                 // byte inside the row = 4 * lane + j
-          const int x = xs + xl, y = y0 + rr;
-          keep = rr >= nms_lo && rr <= hi && rr >= 1 && rr < r_last && xl >= 4 && xl < 252 && x >= kEdge &&
+          const uint32_t xl = he & 255u, row = (he >> 8) & 15u;                 // byte inside the row = 4 * lane + j
+          const uint8_t* qc = scb + (row << 8) + xl;
+          const uint8_t* qu = scb + (((row + RK - 1) & (RK - 1)) << 8) + xl;
+          const uint8_t* qd = scb + (((row + 1) & (RK - 1)) << 8) + xl;
+          c = qc[0];
+          const int x = xs + (int)xl, y = y0 + rr;
+          keep = rr >= nms_lo && rr <= hi && rr >= 1 && rr < r_last && xl >= 4u && xl < 252u && x >= kEdge &&
                  x < L.w - kEdge;
-          keep = keep && c > q[-1] && c > q[1] && c > q[-257] && c > q[-256] && c > q[-255] && c > q[255] &&
-                 c > q[256] && c > q[257];
+          keep = keep && c > qc[-1] && c > qc[1] && c > qu[-1] && c > qu[0] && c > qu[1] && c > qd[-1] && c > qd[0] &&
+                 c > qd[1];
           key = ((uint32_t)y << 16) | (uint32_t)x;
         }
         emit(keep, key, c);
@@ -897,20 +912,24 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
     } else {
       for (int rr = nms_lo; rr <= hi; rr++) {
         if (rr < 1 || rr >= r_last) continue;
-        const int w = ((((rr + 3) & (RK - 1)) + 1) << 6) + lane;
+        const int row = (rr + 3) & (RK - 1);
+        const int w = (row << 6) + lane, wu = (((row + RK - 1) & (RK - 1)) << 6) + lane, wd = (((row + 1) & (RK - 1)) << 6) + lane;
         const uint32_t C = scw[w];
         if (__ballot(C != 0u) == 0ull) continue;
-        const uint32_t Cl = scw[w - 1], Cr = scw[w + 1];
-        const uint32_t U = scw[w - 64], Ul = scw[w - 65], Ur = scw[w - 63];
-        const uint32_t D = scw[w + 64], Dl = scw[w + 63], Dr = scw[w + 65];
-        uint32_t keep = __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(C, Cl, 3), 0);
-        keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(Cr, C, 1), 0);
+        // left / right dwords by DPP: the halo lanes' own neighbours are never output (om = 0 there)
+        const uint32_t U = scw[wu], D = scw[wd];
+#define SHR1(v_) __builtin_amdgcn_update_dpp(0u, (v_), 0x138, 0xf, 0xf, true)
+#define SHL1(v_) __builtin_amdgcn_update_dpp(0u, (v_), 0x130, 0xf, 0xf, true)
+        uint32_t keep = __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(C, SHR1(C), 3), 0);
+        keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(SHL1(C), C, 1), 0);
         keep &= __builtin_amdgcn_lerp(C, ~U, 0);
-        keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(U, Ul, 3), 0);
-        keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(Ur, U, 1), 0);
+        keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(U, SHR1(U), 3), 0);
+        keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(SHL1(U), U, 1), 0);
         keep &= __builtin_amdgcn_lerp(C, ~D, 0);
-        keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(D, Dl, 3), 0);
-        keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(Dr, D, 1), 0);
+        keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(D, SHR1(D), 3), 0);
+        keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(SHL1(D), D, 1), 0);
+#undef SHR1
+#undef SHL1
         keep &= om;
         const uint32_t ykey = (uint32_t)(y0 + rr) << 16;
 #pragma unroll
@@ -920,52 +939,23 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
     // the list restarts with the scored corners of row s (their NMS needs row s + 1)
     nH = 0;
     {
-      const uint32_t rowaddr = (((uint32_t)(s + 3) & (RK - 1)) + 1u) << 8;
-      const uint32_t C = scw[(rowaddr >> 2) + lane];
+      const uint32_t row = (uint32_t)(s + 3) & (RK - 1);
+      const uint32_t C = scw[(row << 6) + lane];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const bool hit = ((C >> (8 * j)) & 255u) != 0u;
         const unsigned long long bal = __ballot(hit);
         if (bal) {
-          if (hit) sm.h[nH + mbcnt64(bal)] = (rowaddr + 4u * lane + j) | ((uint32_t)s << 16);
-          nH += (uint32_t)__popcll(bal);
+          const uint32_t cnt = (uint32_t)__popcll(bal);
+          // a row holds at most 256 corners; the list keeps what fits and the next flush falls back to the dense NMS
+          if (hit && nH + mbcnt64(bal) < (uint32_t)kSHCap) sm.h[nH + mbcnt64(bal)] = (4u * lane + j) | (row << 8) | ((uint32_t)s << 16);
+          nH += cnt;
         }
       }
     }
     MSF_WAVE_SYNC();
     nms_lo = s;
     last_flush = s;
-  };
-
-  // prefilter of rel row s (ring index s + 3): rows s, s + 3, s + 6 of the ring
-  auto step = [&](int s) {
-    if (s > r_last || ablate == 1) return;
-    const uint32_t U = pxw[(((s) & (RK - 1)) + 3) * 64 + lane];
-    const uint32_t C = pxw[(((s + 3) & (RK - 1)) + 3) * 64 + lane];
-    const uint32_t D = pxw[(((s + 6) & (RK - 1)) + 3) * 64 + lane];
-    const uint32_t Lf = __builtin_amdgcn_update_dpp(0u, C, 0x138, 0xf, 0xf, true);   // wave_shr:1: lane i <- lane i - 1
-    const uint32_t Rt = __builtin_amdgcn_update_dpp(0u, C, 0x130, 0xf, 0xf, true);   // wave_shl:1: lane i <- lane i + 1
-    const uint32_t W3 = __builtin_amdgcn_alignbyte(C, Lf, 1);
-    const uint32_t E3 = __builtin_amdgcn_alignbyte(Rt, C, 3);
-    const uint32_t nC = ~C;
-    const uint32_t l0 = __builtin_amdgcn_lerp(D, nC, 0), l4 = __builtin_amdgcn_lerp(E3, nC, 0);
-    const uint32_t l8 = __builtin_amdgcn_lerp(U, nC, 0), l12 = __builtin_amdgcn_lerp(W3, nC, 0);
-    const uint32_t b0 = __builtin_amdgcn_lerp(l0, lerp_bright, 0), b4 = __builtin_amdgcn_lerp(l4, lerp_bright, 0);
-    const uint32_t b8 = __builtin_amdgcn_lerp(l8, lerp_bright, 0), b12 = __builtin_amdgcn_lerp(l12, lerp_bright, 0);
-    const uint32_t n0 = __builtin_amdgcn_lerp(l0, lerp_not_dark, 0), n4 = __builtin_amdgcn_lerp(l4, lerp_not_dark, 0);
-    const uint32_t n8 = __builtin_amdgcn_lerp(l8, lerp_not_dark, 0), n12 = __builtin_amdgcn_lerp(l12, lerp_not_dark, 0);
-    const uint32_t cb = ((b0 | b8) & (b4 | b12)) & vm;
-    const uint32_t cd = ~((n0 & n8) | (n4 & n12)) & vm;
-    const bool has = (cb | cd) != 0u;
-    const unsigned long long bal = __ballot(has);
-    if (bal) {
-      if (has) sm.g[nG + mbcnt64(bal)] = make_uint2((uint32_t)lane | ((uint32_t)s << 8), cb | (cd >> 1));
-      nG += (uint32_t)__popcll(bal);
-    }
-    if (nG > (uint32_t)(kSGCap - 64) || s - last_flush >= kFlushRows || s == r_last) {
-      MSF_WAVE_SYNC();
-      flush(s);
-    }
   };
 
   // warm-up: pixel rows y0 - 3 .. y0 + 2 (ring indices 0 .. 5), then the queue holds rows y0 + 3 .. y0 + 6
@@ -977,13 +967,53 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
     for (int k = 0; k < 6; k++) PUT_ROW(k, v[k]);
   }
   uint32_t q0 = LOAD_ROW(y0 + 3), q1 = LOAD_ROW(y0 + 4), q2 = LOAD_ROW(y0 + 5), q3 = LOAD_ROW(y0 + 6);
-  // the scored domain's rows: all of [y0, y0 + r_last] lie in [30, h - 30)
+  // One step = rel row s_: its row + 3 leaves the queue for the ring (and the queue slot is refilled four rows ahead),
+  // then the cardinal prefilter of the row (ring indices s_, s_ + 3, s_ + 6; see fast_tile for the SWAR form).
+  // Four steps are written out so that each queue register is named statically: a rotating queue would make every
+  // step wait for the load issued in the step before.
+#define STREAM_STEP(q_, s_)                                                                                            \
+  do {                                                                                                                 \
+    const int ss_ = (s_);                                                                                              \
+    const uint32_t D_ = (q_);                                                                                          \
+    PUT_ROW(ss_ + 6, D_);                                                                                              \
+    (q_) = LOAD_ROW(y0 + ss_ + 7);                                                                                     \
+    if (ss_ <= r_last && ablate != 1) {                                                                                \
+      const uint32_t U_ = pxw[((ss_) & (RK - 1)) * 64 + lane];                                                         \
+      const uint32_t C_ = pxw[((ss_ + 3) & (RK - 1)) * 64 + lane];                                                     \
+      const uint32_t Lf_ = __builtin_amdgcn_update_dpp(0u, C_, 0x138, 0xf, 0xf, true); /* wave_shr:1: lane i <- i-1 */ \
+      const uint32_t Rt_ = __builtin_amdgcn_update_dpp(0u, C_, 0x130, 0xf, 0xf, true); /* wave_shl:1: lane i <- i+1 */ \
+      const uint32_t W3_ = __builtin_amdgcn_alignbyte(C_, Lf_, 1);                                                     \
+      const uint32_t E3_ = __builtin_amdgcn_alignbyte(Rt_, C_, 3);                                                     \
+      const uint32_t nC_ = ~C_;                                                                                        \
+      const uint32_t l0_ = __builtin_amdgcn_lerp(D_, nC_, 0), l4_ = __builtin_amdgcn_lerp(E3_, nC_, 0);                \
+      const uint32_t l8_ = __builtin_amdgcn_lerp(U_, nC_, 0), l12_ = __builtin_amdgcn_lerp(W3_, nC_, 0);               \
+      const uint32_t b0_ = __builtin_amdgcn_lerp(l0_, lerp_bright, 0), b4_ = __builtin_amdgcn_lerp(l4_, lerp_bright, 0);   \
+      const uint32_t b8_ = __builtin_amdgcn_lerp(l8_, lerp_bright, 0), b12_ = __builtin_amdgcn_lerp(l12_, lerp_bright, 0); \
+      const uint32_t n0_ = __builtin_amdgcn_lerp(l0_, lerp_not_dark, 0), n4_ = __builtin_amdgcn_lerp(l4_, lerp_not_dark, 0);   \
+      const uint32_t n8_ = __builtin_amdgcn_lerp(l8_, lerp_not_dark, 0), n12_ = __builtin_amdgcn_lerp(l12_, lerp_not_dark, 0); \
+      const uint32_t cb_ = ((b0_ | b8_) & (b4_ | b12_)) & vm;                                                          \
+      const uint32_t cd_ = ~((n0_ & n8_) | (n4_ & n12_)) & vm;                                                         \
+      const bool has_ = (cb_ | cd_) != 0u;                                                                             \
+      const unsigned long long bal_ = __ballot(has_);                                                                  \
+      if (bal_) {                                                                                                      \
+        if (has_) sm.g[nG + mbcnt64(bal_)] = make_uint2((uint32_t)lane | ((uint32_t)ss_ << 8), cb_ | (cd_ >> 1));      \
+        nG += (uint32_t)__popcll(bal_);                                                                                \
+      }                                                                                                                \
+    }                                                                                                                  \
+  } while (0)
   for (int s = 0; s <= r_last; s += 4) {
-    PUT_ROW(s + 6, q0); q0 = LOAD_ROW(y0 + s + 7); MSF_WAVE_SYNC(); step(s);
-    PUT_ROW(s + 7, q1); q1 = LOAD_ROW(y0 + s + 8); MSF_WAVE_SYNC(); step(s + 1);
-    PUT_ROW(s + 8, q2); q2 = LOAD_ROW(y0 + s + 9); MSF_WAVE_SYNC(); step(s + 2);
-    PUT_ROW(s + 9, q3); q3 = LOAD_ROW(y0 + s + 10); MSF_WAVE_SYNC(); step(s + 3);
+    STREAM_STEP(q0, s);
+    STREAM_STEP(q1, s + 1);
+    STREAM_STEP(q2, s + 2);
+    STREAM_STEP(q3, s + 3);
+    const int sl = min(s + 3, r_last);
+    // flushes happen between groups of four steps: at most 64 + 4 x 64 records wait (kSGCap), at most 8 rows
+    if (ablate != 1 && (nG > 64u || sl - last_flush >= kFlushRows || sl == r_last)) {
+      MSF_WAVE_SYNC();
+      flush(sl);
+    }
   }
+#undef STREAM_STEP
   flush_out();
 #undef LOAD_ROW
 #undef PUT_ROW
