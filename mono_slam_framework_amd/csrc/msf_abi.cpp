@@ -85,10 +85,14 @@ int run_device(msf_handle* h, int n_pairs, const uint8_t* d_a, const uint8_t* d_
   if (frame_stride < row_stride * (long long)h->cfg.image_height)
     return fail(h, MSF_ERR_INVALID_ARG, "frame_stride < row_stride * image_height (frames would overlap)");
   if (h->cfg.kind == MSF_KIND_ORB) {
-    msf::FrameSrc src{d_a, d_b, n_pairs, 0, frame_stride, (int)row_stride};
+    // the stateless MatchFrames path works in its own feature slots [2P, 4P): slots [0, 2P) are the per-frame cache of
+    // msf_extract_device / msf_store_frame, which a MatchFrames call on the same handle must not disturb
+    // (KeyFrameMatchDatabase and Tracking share one matcher, src/main.cpp:77-81)
+    const int scratch0 = 2 * h->cfg.max_batch_pairs;
+    msf::FrameSrc src{d_a, d_b, n_pairs, scratch0, frame_stride, (int)row_stride};
     hipError_t e = h->orb.extract(src, 2 * n_pairs, st);
     if (e != hipSuccess) return hip_fail(h, "orb extract", e);
-    e = h->orb.match(n_pairs, nullptr, nullptr, h->cfg.threshold, d_out, cap, d_n_out, st);
+    e = h->orb.match(n_pairs, nullptr, nullptr, h->cfg.threshold, d_out, cap, d_n_out, st, scratch0);
     if (e != hipSuccess) return hip_fail(h, "orb match", e);
     return MSF_OK;
   }
@@ -166,7 +170,7 @@ int msf_create(const msf_config* cfg, msf_handle** out) {
   std::string err;
   const bool profile = (cfg->flags & MSF_FLAG_PROFILE) != 0;
   if (cfg->kind == MSF_KIND_ORB) {
-    err = h->orb.init(cfg->image_width, cfg->image_height, 2 * cfg->max_batch_pairs,
+    err = h->orb.init(cfg->image_width, cfg->image_height, 4 * cfg->max_batch_pairs,
                       (cfg->flags & MSF_FLAG_BLUR_TIE_HALF_UP) != 0, profile, (cfg->flags & MSF_FLAG_FAST_DENSE) != 0);
   } else {
     if (cfg->image_width != 640 || cfg->image_height != 480) {
@@ -314,7 +318,7 @@ int msf_extract_device(msf_handle* h, int32_t n_frames, const uint8_t* d_frames,
   std::lock_guard<std::mutex> lk(h->mu);
   const bool is_orb = h->cfg.kind == MSF_KIND_ORB;
   if (n_frames < 0 || !d_frames || first_slot < 0 ||
-      first_slot + n_frames > (is_orb ? h->orb.max_slots() : h->loftr.max_slots()))
+      first_slot + n_frames > (is_orb ? 2 * h->cfg.max_batch_pairs : h->loftr.max_slots()))
     return fail(h, MSF_ERR_INVALID_ARG, "msf_extract_device: slot range outside [0, 2*max_batch_pairs)");
   if (((uintptr_t)d_frames | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 15)
     return fail(h, MSF_ERR_INVALID_ARG, "device frames must be 16-byte aligned with strides multiple of 16");

@@ -440,248 +440,6 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
   fast_tile(g, src, pyr, fi, l, bt - g.lv[l].tile_base, kFastT, cand_cnt, cand_key, cand_sc, sm);
 }
 
-// ---- the same tile for a threshold tau well above fastThreshold, where pixels that pass the prefilter are rare
-// (a few per cent) but almost every wave still meets one: the dense kernel's per-wave scan + append, its two scoring
-// loops and the dense NMS passes would run for nearly every wave.  Here the prefilter only drops one packed record per
-// 4-px group with a survivor (one LDS atomic by the lanes concerned), and the records are expanded, scored and
-// non-maximum-suppressed as lists.  28-row tiles: 34 x 30 prefilter tasks = two full passes of the 512 threads.
-constexpr int STH = 28, SSH = STH + 2, SPH2 = STH + 2 * HY;
-constexpr int kGCap = GPR * SSH;            // one record per prefilter task: cannot overflow
-constexpr int kPxChunk = kFastThreads;      // records expanded per round, one per thread
-constexpr int kPCap = 4 * kPxChunk;         // pixel entries of a round (brighter from the front, darker from the back)
-constexpr int kHitCap = 512;                // scored corners (score >= tau) handled by the list NMS; more -> dense NMS
-constexpr int kTileCandCapS = TW * STH / 4;
-static_assert(kGCap <= 2 * kFastThreads, "sparse prefilter is two passes");
-
-struct FastSparseSmem {
-  __attribute__((aligned(16))) uint8_t px[PW2 * SPH2];
-  __attribute__((aligned(16))) uint8_t sc[PW2 * SPH2 + 2 * SCO];
-  uint2 glist[kGCap];               // (dword index of the group in the tile, brighter flags | darker flags >> 1)
-  uint16_t plist[kPCap];
-  uint16_t hlist[kHitCap];
-  uint32_t okey[kTileCandCapS];
-  uint8_t osc[kTileCandCapS];
-  uint32_t wtot[kFastThreads / 64];
-  uint32_t n1, nh, lcount, gbase;
-};
-
-__device__ __forceinline__ void fast_tile_sparse(const OrbGeometry& g, const FrameSrc& src, const uint8_t* pyr, int fi,
-                                                 int l, int t, int tau, uint32_t* cand_cnt, uint32_t* cand_key,
-                                                 uint8_t* cand_sc, FastSparseSmem& S_, int ablate) {
-  uint8_t* px = S_.px;
-  uint8_t* sc = S_.sc;
-  const int slot = src.slot0 + fi;
-  const OrbLevelInfo L = g.lv[l];
-  const int x0 = kTileX0 + (t % L.tiles_x) * TW, y0 = kTileY0 + (t / L.tiles_x) * STH;
-  int pitch;
-  const uint8_t* img = level_ptr(g, src, pyr, fi, l, &pitch);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) { S_.n1 = 0; S_.nh = 0; S_.lcount = 0; }
-  const uint32_t lerp_bright = 0x01010101u * (uint32_t)(128 - tau / 2);
-  const uint32_t lerp_not_dark = 0x01010101u * (uint32_t)(255 - (254 - tau) / 2);
-
-  for (int i = tid; i < (PW2 / 16) * SPH2; i += kFastThreads) {
-    const int r = i / (PW2 / 16), c = i % (PW2 / 16);
-    const int gx = x0 - HX + 16 * c, gy = y0 - HY + r;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (gx >= 0 && gx + 16 <= pitch && gy >= 0 && gy < L.h)
-      v = *reinterpret_cast<const uint4*>(img + (long long)gy * pitch + gx);
-    reinterpret_cast<uint4*>(px)[i] = v;
-  }
-  for (int i = tid; i < (PW2 * SPH2 + 2 * SCO) / 4; i += kFastThreads) reinterpret_cast<uint32_t*>(sc)[i] = 0;
-  __syncthreads();
-  if (ablate == 1) { if (px[tid] == 77 && sc[tid] == 3) cand_cnt[0] = 1; return; }
-
-  // phase 1: cardinal prefilter at tau, 4 px per lane (see fast_tile); survivors leave one record per group
-  const uint32_t* T = reinterpret_cast<const uint32_t*>(px);
-  constexpr int kLo = kEdge - 1;
-  const int txlo = max(-1, kLo - x0), txhi = min(TW, L.w - kLo - 1 - x0);
-  const bool inner1 = txlo == -1 && txhi == TW && y0 - 1 >= kLo && y0 + STH < L.h - kLo;
-#pragma unroll
-  for (int pass = 0; pass < 2; pass++) {
-    const int i = pass * kFastThreads + tid;
-    const int ic = i < kGCap ? i : kGCap - 1;
-    const int sr = ic / GPR, gq = ic % GPR;
-    const int ty = sr - 1, tx0 = 4 * gq - 4;
-    const int b = ((ty + HY) * PW2 + tx0 + HX) >> 2;
-    const uint32_t C = T[b], Lf = T[b - 1], Rt = T[b + 1];
-    const uint32_t U = T[b - 3 * (PW2 / 4)], D = T[b + 3 * (PW2 / 4)];
-    const uint32_t W3 = __builtin_amdgcn_alignbyte(C, Lf, 1);
-    const uint32_t E3 = __builtin_amdgcn_alignbyte(Rt, C, 3);
-    const uint32_t nC = ~C;
-    const uint32_t l0 = __builtin_amdgcn_lerp(D, nC, 0), l4 = __builtin_amdgcn_lerp(E3, nC, 0);
-    const uint32_t l8 = __builtin_amdgcn_lerp(U, nC, 0), l12 = __builtin_amdgcn_lerp(W3, nC, 0);
-    const uint32_t b0 = __builtin_amdgcn_lerp(l0, lerp_bright, 0), b4 = __builtin_amdgcn_lerp(l4, lerp_bright, 0);
-    const uint32_t b8 = __builtin_amdgcn_lerp(l8, lerp_bright, 0), b12 = __builtin_amdgcn_lerp(l12, lerp_bright, 0);
-    const uint32_t n0 = __builtin_amdgcn_lerp(l0, lerp_not_dark, 0), n4 = __builtin_amdgcn_lerp(l4, lerp_not_dark, 0);
-    const uint32_t n8 = __builtin_amdgcn_lerp(l8, lerp_not_dark, 0), n12 = __builtin_amdgcn_lerp(l12, lerp_not_dark, 0);
-    uint32_t vm = 0;
-    if (inner1) {
-      vm = gq == 0 ? 0x80000000u : gq == GPR - 1 ? 0x00000080u : 0x80808080u;
-      vm = i < kGCap ? vm : 0u;
-    } else {
-      const int gy = y0 + ty;
-      int first = txlo - tx0, last = txhi - tx0;
-      first = first < 0 ? 0 : first;
-      last = last > 3 ? 3 : last;
-      if (i < kGCap && gy >= kLo && gy < L.h - kLo && first <= last)
-        vm = (0x80808080u << (8 * first)) & (0x80808080u >> (8 * (3 - last)));
-    }
-    const uint32_t cb = ((b0 | b8) & (b4 | b12)) & vm;
-    const uint32_t cd = ~((n0 & n8) | (n4 & n12)) & vm;
-    if (cb | cd) S_.glist[atomicAdd(&S_.n1, 1u)] = make_uint2((uint32_t)b, cb | (cd >> 1));
-  }
-  __syncthreads();
-
-  // phase 2: expand the records into per-pixel entries (one polarity from each end of plist) and score them exactly
-  const uint32_t n1 = S_.n1;
-  if (ablate == 2) { if (n1 == 77777) cand_cnt[0] = 1; return; }
-  for (uint32_t c0 = 0; c0 < n1; c0 += kPxChunk) {   // uniform; one round unless the tile is crowded
-    uint32_t e0 = 0, mb = 0, md = 0;
-    if (c0 + tid < n1) {
-      const uint2 rec = S_.glist[c0 + tid];
-      e0 = rec.x << 2;
-      mb = rec.y & 0x80808080u;
-      md = (rec.y << 1) & 0x80808080u;
-    }
-    const uint32_t mine = __popc(mb) | (__popc(md) << 16);
-    const uint32_t incl = wave_incl_scan(mine);
-    if (lane == 63) S_.wtot[wave] = incl;
-    __syncthreads();
-    uint32_t base = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < kFastThreads / 64; w++) {
-      const uint32_t v = S_.wtot[w];
-      base += w < wave ? v : 0u;
-      total += v;
-    }
-    const uint32_t slots = base + incl - mine;
-    uint32_t k = slots & 0xFFFFu;
-    if (mb & 0x80u) S_.plist[k++] = (uint16_t)e0;
-    if (mb & 0x8000u) S_.plist[k++] = (uint16_t)(e0 + 1);
-    if (mb & 0x800000u) S_.plist[k++] = (uint16_t)(e0 + 2);
-    if (mb & 0x80000000u) S_.plist[k++] = (uint16_t)(e0 + 3);
-    k = kPCap - 1 - (slots >> 16);
-    if (md & 0x80u) S_.plist[k--] = (uint16_t)e0;
-    if (md & 0x8000u) S_.plist[k--] = (uint16_t)(e0 + 1);
-    if (md & 0x800000u) S_.plist[k--] = (uint16_t)(e0 + 2);
-    if (md & 0x80000000u) S_.plist[k--] = (uint16_t)(e0 + 3);
-    __syncthreads();
-    const uint32_t nb = total & 0xFFFFu, nd = total >> 16;
-    for (uint32_t i = tid; i < nb; i += kFastThreads) {
-      const int e = S_.plist[i];
-      const int s = fast_score_pol<true>(&px[e], tau);
-      if (s) {
-        sc[SCO + e] = (uint8_t)s;
-        const uint32_t hh = atomicAdd(&S_.nh, 1u);
-        if (hh < (uint32_t)kHitCap) S_.hlist[hh] = (uint16_t)e;
-      }
-    }
-    for (uint32_t i = tid; i < nd; i += kFastThreads) {
-      const int e = S_.plist[kPCap - 1 - i];
-      const int s = fast_score_pol<false>(&px[e], tau);
-      if (s) {
-        sc[SCO + e] = (uint8_t)s;
-        const uint32_t hh = atomicAdd(&S_.nh, 1u);
-        if (hh < (uint32_t)kHitCap) S_.hlist[hh] = (uint16_t)e;
-      }
-    }
-    __syncthreads();
-  }
-
-  // phase 3: strict 3x3 NMS + runByImageBorder(31) over the scored corners
-  const uint32_t nh = S_.nh;
-  if (ablate == 3) { if (nh == 77777) cand_cnt[0] = 1; return; }
-  if (nh == 0) return;   // uniform
-  if (nh <= (uint32_t)kHitCap) {
-    for (uint32_t i = tid; i < nh; i += kFastThreads) {
-      const int e = S_.hlist[i];
-      const uint8_t* q = sc + SCO + e;
-      const int c = q[0];
-      const int ry = e / PW2, tx = e - ry * PW2 - HX, ty = ry - HY;
-      const int gx = x0 + tx, gy = y0 + ty;
-      bool keep = tx >= 0 && tx < TW && ty >= 0 && ty < STH && gx >= kEdge && gx < L.w - kEdge && gy >= kEdge &&
-                  gy < L.h - kEdge;
-      keep = keep && c > q[-1] && c > q[1] && c > q[-PW2 - 1] && c > q[-PW2] && c > q[-PW2 + 1] && c > q[PW2 - 1] &&
-             c > q[PW2] && c > q[PW2 + 1];
-      if (keep) {
-        const uint32_t k = atomicAdd(&S_.lcount, 1u);
-        S_.okey[k] = ((uint32_t)gy << 16) | (uint32_t)gx;
-        S_.osc[k] = (uint8_t)c;
-      }
-    }
-  } else {
-    const uint32_t* S = reinterpret_cast<const uint32_t*>(sc) + SCO / 4;
-    constexpr int SPD = PW2 / 4;
-    const int txlo3 = max(0, kEdge - x0), txhi3 = min(TW - 1, L.w - kEdge - 1 - x0);
-    for (int i = tid; i < (TW / 4) * STH; i += kFastThreads) {
-      const int ty = i / (TW / 4), j = i % (TW / 4);
-      const int w = (ty + HY) * SPD + HX / 4 + j;
-      const uint32_t C = S[w];
-      const int gy = y0 + ty;
-      if (C == 0 || gy < kEdge || gy >= L.h - kEdge) continue;
-      const uint32_t Cl = S[w - 1], Cr = S[w + 1];
-      const uint32_t U = S[w - SPD], Ul = S[w - SPD - 1], Ur = S[w - SPD + 1];
-      const uint32_t D = S[w + SPD], Dl = S[w + SPD - 1], Dr = S[w + SPD + 1];
-      uint32_t keep = __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(C, Cl, 3), 0);
-      keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(Cr, C, 1), 0);
-      keep &= __builtin_amdgcn_lerp(C, ~U, 0);
-      keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(U, Ul, 3), 0);
-      keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(Ur, U, 1), 0);
-      keep &= __builtin_amdgcn_lerp(C, ~D, 0);
-      keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(D, Dl, 3), 0);
-      keep &= __builtin_amdgcn_lerp(C, ~__builtin_amdgcn_alignbyte(Dr, D, 1), 0);
-      int first = txlo3 - 4 * j, last = txhi3 - 4 * j;
-      first = first < 0 ? 0 : first;
-      last = last > 3 ? 3 : last;
-      keep &= first <= last ? (0x80808080u << (8 * first)) & (0x80808080u >> (8 * (3 - last))) : 0u;
-      if (keep == 0u) continue;
-      uint32_t k = atomicAdd(&S_.lcount, (uint32_t)__popc(keep));
-      const uint32_t key = ((uint32_t)gy << 16) | (uint32_t)(x0 + 4 * j);
-      if (keep & 0x80u) { S_.okey[k] = key; S_.osc[k++] = (uint8_t)(C & 0xFFu); }
-      if (keep & 0x8000u) { S_.okey[k] = key + 1; S_.osc[k++] = (uint8_t)((C >> 8) & 0xFFu); }
-      if (keep & 0x800000u) { S_.okey[k] = key + 2; S_.osc[k++] = (uint8_t)((C >> 16) & 0xFFu); }
-      if (keep & 0x80000000u) { S_.okey[k] = key + 3; S_.osc[k++] = (uint8_t)(C >> 24); }
-    }
-  }
-  __syncthreads();
-  const uint32_t n = S_.lcount;
-  if (n == 0) return;   // uniform
-  if (tid == 0) S_.gbase = atomicAdd(&cand_cnt[slot * kOrbLevels + l], n);
-  __syncthreads();
-  const uint32_t base = S_.gbase;
-  uint32_t* outk = cand_key + (long long)slot * g.cand_total + L.cand_off;
-  uint8_t* outs = cand_sc + (long long)slot * g.cand_total + L.cand_off;
-  for (uint32_t i = tid; i < n; i += kFastThreads)
-    if (base + i < (uint32_t)L.cand_cap) {
-      outk[base + i] = S_.okey[i];
-      outs[base + i] = S_.osc[i];
-    }
-}
-
-// First pass over the 28-row tiling: (frame, level)s whose threshold is above fastThreshold; the others are already in
-// the dense queue (k_fast_tau put them there).
-__global__ __launch_bounds__(kFastThreads) void k_fast_sparse(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
-                                                              const uint32_t* __restrict__ tau, uint32_t* cand_cnt,
-                                                              uint32_t* cand_key, uint8_t* cand_sc, int ablate) {
-  __shared__ FastSparseSmem sm;
-  int G;
-  {
-    const uint32_t total = gridDim.x, lin = blockIdx.x;
-    const uint32_t xcd = lin & 7u, q = total >> 3, r = total & 7u;
-    G = (int)(xcd * q + (xcd < r ? xcd : r) + (lin >> 3));
-  }
-  const int fi = G / g.total_tiles_s, bt = G - fi * g.total_tiles_s;
-  int l = 0;
-#pragma unroll
-  for (int i = 1; i < kOrbLevels; i++)
-    if (i < g.nlevels && bt >= g.lv[i].tile_base_s) l = i;
-  const int tv = (int)tau[(src.slot0 + fi) * kOrbLevels + l];
-  if (tv <= kFastT) return;   // uniform
-  if (ablate == 4) return;
-  fast_tile_sparse(g, src, pyr, fi, l, bt - g.lv[l].tile_base_s, tv, cand_cnt, cand_key, cand_sc, sm, ablate);
-}
-
 // ------------------------------------------------------------------ K3+K4, streaming form for tau well above fastThreshold
 // The tile kernels above are bound by workgroup dispatch and by their barriers once the scoring work is gone (measured:
 // 1.9 ms to dispatch the 10^6 tiles of a 1024-pair batch, 6 ms of phase latency).  Here ONE WAVE walks a column strip
@@ -695,6 +453,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_sparse(OrbGeometry g, Fra
 //    runByImageBorder run over the hits whose three score rows are final; kept corners are buffered and appended to
 //    the level's candidate list with one global atomic per buffer flush.
 // Emits exactly the maxima with score >= tau of the strip's pixels, like fast_tile(tau).
+constexpr int kTauBins = 64;             // score histogram bins of width 4 (k_fast_tau's sample, the emitted corners)
 constexpr int SR = 64;                   // output rows per strip
 constexpr int RK = 16;                   // ring rows (power of two)
 constexpr int SPX = 248;                 // output px per strip
@@ -741,7 +500,7 @@ __device__ __forceinline__ int stream_score(const uint8_t* ring, uint32_t r0, ui
 
 __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
                                                     const uint32_t* __restrict__ tau, uint32_t* cand_cnt,
-                                                    uint32_t* cand_key, uint8_t* cand_sc, int ablate) {
+                                                    uint32_t* cand_key, uint8_t* cand_sc) {
   __shared__ StreamSmem sm;
   int G;
   {
@@ -765,6 +524,11 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
   const uint8_t* img = level_ptr(g, src, pyr, fi, l, &pitch);
   const uint32_t lerp_bright = 0x01010101u * (uint32_t)(128 - tv / 2);
   const uint32_t lerp_not_dark = 0x01010101u * (uint32_t)(255 - (254 - tv) / 2);
+  uint32_t* const out_cnt = cand_cnt + slot * kOrbLevels + l;
+  uint32_t* const outk = cand_key + (long long)slot * g.cand_total + L.cand_off;
+  uint8_t* const outs = cand_sc + (long long)slot * g.cand_total + L.cand_off;
+  const uint32_t out_cap = (uint32_t)L.cand_cap;
+  const int lw = L.w;
 
   const int xs = kSX0 + SPX * sx;                 // x of lane 0's first px
   const int xb = xs + 4 * lane;
@@ -805,12 +569,10 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
   auto flush_out = [&]() {
     if (nO == 0) return;
     uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&cand_cnt[slot * kOrbLevels + l], nO);
+    if (lane == 0) base = atomicAdd(out_cnt, nO);
     base = __builtin_amdgcn_readfirstlane(base);
-    uint32_t* outk = cand_key + (long long)slot * g.cand_total + L.cand_off;
-    uint8_t* outs = cand_sc + (long long)slot * g.cand_total + L.cand_off;
     for (uint32_t i = lane; i < nO; i += 64)
-      if (base + i < (uint32_t)L.cand_cap) {
+      if (base + i < out_cap) {
         outk[base + i] = sm.okey[i];
         outs[base + i] = sm.osc[i];
       }
@@ -837,7 +599,6 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
     // the hit list was rebuilt from one row's scores at the end of the last flush: if that row held more corners than
     // the list, this NMS is the dense one
     bool overflow = nH > (uint32_t)kSHCap;
-    if (ablate == 2) { nG = 0; last_flush = s; return; }
     // 32 records per round: at most 32 x 8 pixel entries (a pixel can pass both polarity prefilters)
     for (uint32_t c0 = 0; c0 < nG; c0 += 32) {
       uint32_t e0 = 0, mb = 0, md = 0;
@@ -884,7 +645,6 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
       MSF_WAVE_SYNC();
     }
     nG = 0;
-    if (ablate == 3) { nH = 0; last_flush = s; return; }
     // ---- NMS of rel rows [nms_lo, s - 1]: all their neighbours' scores are final
     const int hi = s - 1;
     if (!overflow) {
@@ -902,7 +662,7 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
           c = qc[0];
           const int x = xs + (int)xl, y = y0 + rr;
           keep = rr >= nms_lo && rr <= hi && rr >= 1 && rr < r_last && xl >= 4u && xl < 252u && x >= kEdge &&
-                 x < L.w - kEdge;
+                 x < lw - kEdge;
           keep = keep && c > qc[-1] && c > qc[1] && c > qu[-1] && c > qu[0] && c > qu[1] && c > qd[-1] && c > qd[0] &&
                  c > qd[1];
           key = ((uint32_t)y << 16) | (uint32_t)x;
@@ -977,7 +737,7 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
     const uint32_t D_ = (q_);                                                                                          \
     PUT_ROW(ss_ + 6, D_);                                                                                              \
     (q_) = LOAD_ROW(y0 + ss_ + 7);                                                                                     \
-    if (ss_ <= r_last && ablate != 1) {                                                                                \
+    if (ss_ <= r_last) {                                                                                \
       const uint32_t U_ = pxw[((ss_) & (RK - 1)) * 64 + lane];                                                         \
       const uint32_t C_ = pxw[((ss_ + 3) & (RK - 1)) * 64 + lane];                                                     \
       const uint32_t Lf_ = __builtin_amdgcn_update_dpp(0u, C_, 0x138, 0xf, 0xf, true); /* wave_shr:1: lane i <- i-1 */ \
@@ -1008,7 +768,7 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
     STREAM_STEP(q3, s + 3);
     const int sl = min(s + 3, r_last);
     // flushes happen between groups of four steps: at most 64 + 4 x 64 records wait (kSGCap), at most 8 rows
-    if (ablate != 1 && (nG > 64u || sl - last_flush >= kFlushRows || sl == r_last)) {
+    if (nG > 64u || sl - last_flush >= kFlushRows || sl == r_last) {
       MSF_WAVE_SYNC();
       flush(sl);
     }
@@ -1026,9 +786,9 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
 // below tau was ever needed.  k_fast_tau picks tau per (frame, level) from exact scores on a sparse sample of the
 // level, k_fast_check verifies the count afterwards and queues the (frame, level)s that fell short for a dense
 // (tau = fastThreshold) second pass by k_fast_redo.  Whatever tau is picked, the result is the dense one bit for bit.
-constexpr int kTauBins = 64;          // score histogram bins of width 4
-constexpr int kTauMinHits = 32;       // sample hits the estimate must rest on
-constexpr int kTauOversample = 24;    // estimated pixels with score >= tau per key point to keep (clusters, NMS, ties)
+constexpr int kTauMinHits = 24;       // sample hits the estimate must rest on
+constexpr int kTauOversample = 10;    // estimated pixels with score >= tau per key point to keep: a strict maximum stands
+                                      // for 4-5 pixels of its cluster at these scores, so about twice the 2N needed
 
 __device__ __forceinline__ int fast_score_px(const uint8_t* p, int pitch) {
   const int off[16][2] = {{0, 3}, {1, 3}, {2, 2}, {3, 1}, {3, 0}, {3, -1}, {2, -2}, {1, -3},
@@ -1058,13 +818,20 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
   return x;
 }
 
-// One workgroup per (level, frame): exact scores at sampled pixels (rows samp_sy apart with a hashed jitter, columns
-// samp_sx apart -- odd, hashed phase per row, so a periodic texture is not aliased), histogram in LDS, tau = the
-// largest multiple of 4 with enough sample hits above it.
+// One workgroup per (level, frame).  Sampled pixels: rows samp_sy apart with a hashed jitter, columns samp_sx apart --
+// odd, hashed phase per row, so a periodic texture is not aliased.  Only the upper tail of the score distribution
+// matters, so a sample first takes the cardinal test at kTauPre (5 byte loads; every pixel with score >= kTauPre passes
+// it) and only the survivors, compacted in LDS, get the exact score: the histogram is exact from kTauPre upwards.
+// tau = the largest multiple of 4 with enough sample hits at or above it, fastThreshold (dense) if there is none.
+constexpr int kTauPre = 40;
+constexpr int kTauListCap = 2048;     // prefilter survivors kept per (frame, level); the rest are dropped (fewer hits: a
+                                      // lower, still valid, tau)
 __global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, const uint8_t* pyr, int force_tau,
                                                   uint32_t* tau, uint32_t* tau_first, uint32_t* redo_cnt,
                                                   uint32_t* redo_list) {
   __shared__ uint32_t hist[kTauBins];
+  __shared__ uint32_t list[kTauListCap];
+  __shared__ uint32_t nlist;
   const int l = blockIdx.x, fi = blockIdx.y, slot = src.slot0 + fi, tid = threadIdx.x;
   const OrbLevelInfo L = g.lv[l];
   int tv = kFastT;
@@ -1072,20 +839,47 @@ __global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, c
     tv = force_tau;
   } else if (L.samp_rows > 0) {
     if (tid < kTauBins) hist[tid] = 0;
+    if (tid == 0) nlist = 0;
     __syncthreads();
     int pitch;
     const uint8_t* img = level_ptr(g, src, pyr, fi, l, &pitch);
     const int rw = L.w - 2 * kEdge, rh = L.h - 2 * kEdge;
-    const int total = L.samp_rows * L.samp_cols;
-    for (int s = tid; s < total; s += 256) {
-      const int j = s / L.samp_cols, k = s - j * L.samp_cols;
-      const uint32_t hj = hash_u32((uint32_t)(l * 4099 + j) * 2654435761u + 12345u);
-      int y = j * L.samp_sy + (int)(hj % (uint32_t)L.samp_sy);
-      int x = k * L.samp_sx + (int)((hj >> 16) % (uint32_t)L.samp_sx);
-      y = y < rh ? y : rh - 1;
-      x = x < rw ? x : rw - 1;
-      const int sc = fast_score_px(img + (long long)(kEdge + y) * pitch + kEdge + x, pitch);
-      if (sc) atomicAdd(&hist[sc >> 2], 1u);
+    // four sampled rows per iteration: their 20 byte loads are in flight together
+    for (int j0 = 0; j0 < L.samp_rows; j0 += 4) {
+      for (int k = tid; k < L.samp_cols; k += 256) {
+        int cv[4], nv[4], sv[4], ev[4], wv[4];
+        uint32_t pos[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int j = min(j0 + u, L.samp_rows - 1);
+          const uint32_t hj = hash_u32((uint32_t)(l * 4099 + j) * 2654435761u + 12345u);
+          int y = j * L.samp_sy + (int)(hj % (uint32_t)L.samp_sy);
+          y = kEdge + (y < rh ? y : rh - 1);
+          int x = k * L.samp_sx + (int)((hj >> 16) % (uint32_t)L.samp_sx);
+          x = kEdge + (x < rw ? x : rw - 1);
+          const uint8_t* p = img + (long long)y * pitch + x;
+          cv[u] = p[0]; nv[u] = p[-3 * pitch]; sv[u] = p[3 * pitch]; ev[u] = p[3]; wv[u] = p[-3];
+          pos[u] = ((uint32_t)y << 16) | (uint32_t)x;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int hi = cv[u] + kTauPre, lo = cv[u] - kTauPre;
+          const bool pass = j0 + u < L.samp_rows &&
+                            (((nv[u] > hi || sv[u] > hi) && (ev[u] > hi || wv[u] > hi)) ||
+                             ((nv[u] < lo || sv[u] < lo) && (ev[u] < lo || wv[u] < lo)));
+          if (pass) {
+            const uint32_t idx = atomicAdd(&nlist, 1u);
+            if (idx < (uint32_t)kTauListCap) list[idx] = pos[u];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t n = min(nlist, (uint32_t)kTauListCap);
+    for (uint32_t i = tid; i < n; i += 256) {
+      const uint32_t e = list[i];
+      const int sc = fast_score_px(img + (long long)(e >> 16) * pitch + (e & 0xFFFFu), pitch);
+      if (sc >= kTauPre) atomicAdd(&hist[sc >> 2], 1u);
     }
     __syncthreads();
     if (tid < 64) {
@@ -1099,10 +893,9 @@ __global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, c
       const uint32_t factor = (uint32_t)(L.samp_sx * L.samp_sy);
       uint32_t need = ((uint32_t)kTauOversample * 2u * (uint32_t)L.quota + factor - 1u) / factor;
       need = need < (uint32_t)kTauMinHits ? (uint32_t)kTauMinHits : need;
-      const unsigned long long ok = __ballot(c >= need);
+      const unsigned long long ok = __ballot(c >= need && 4 * tid >= kTauPre);
       const int top = ok ? 63 - __builtin_clzll(ok) : 0;     // largest qualifying bin
-      tv = 4 * top;
-      if (tv < kFastT + 8) tv = kFastT;                      // nothing to gain: dense
+      tv = ok ? 4 * top : kFastT;                            // too few strong corners: dense
     }
   }
   if (tid == 0) {
@@ -1568,14 +1361,16 @@ constexpr int kTrainChunk = 1024;  // train descriptors staged per LDS pass (32 
 __global__ __launch_bounds__(256) void k_match(int n_pairs, const int32_t* slot_a, const int32_t* slot_b,
                                                const msf_keypoint* kp, const uint32_t* kp_cnt, const uint8_t* desc,
                                                const uint32_t* status, float ratio, msf_match* out, int cap,
-                                               int32_t* n_out, int chunk) {
+                                               int32_t* n_out, int chunk, int slot_base, int max_slots) {
   __shared__ __attribute__((aligned(16))) unsigned long long train[kTrainChunk * 4];
   __shared__ uint32_t wave_cnt[4];
   __shared__ uint32_t running;
   const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int sa = slot_a ? slot_a[pair] : pair;
-  const int sb = slot_b ? slot_b[pair] : n_pairs + pair;
-  if ((status[sa] | status[sb]) & kStatusOverflow) {
+  // slot arrays come from the caller's device memory and cannot be checked on the host: a slot outside the handle's
+  // range gives n_out = -1 for that pair instead of an out-of-bounds read
+  const int sa = slot_a ? slot_a[pair] : slot_base + pair;
+  const int sb = slot_b ? slot_b[pair] : slot_base + n_pairs + pair;
+  if (sa < 0 || sa >= max_slots || sb < 0 || sb >= max_slots || ((status[sa] | status[sb]) & kStatusOverflow)) {
     if (tid == 0) n_out[pair] = -1;
     return;
   }
@@ -1648,15 +1443,16 @@ __global__ __launch_bounds__(256) void k_match_split(int n_pairs, const int32_t*
                                                      const msf_keypoint* kp, const uint32_t* kp_cnt,
                                                      const uint8_t* desc, const uint32_t* status, float ratio,
                                                      msf_match* out, int cap, int32_t* n_out, int chunk,
-                                                     uint32_t* qres, uint32_t* done) {
+                                                     uint32_t* qres, uint32_t* done, int slot_base, int max_slots) {
   __shared__ __attribute__((aligned(16))) unsigned long long train[kTrainChunk * 4];
   __shared__ int part[3][4][64];
   __shared__ uint32_t wave_cnt[4];
   __shared__ uint32_t running, last_s;
   const int pair = blockIdx.y, qb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int sa = slot_a ? slot_a[pair] : pair;
-  const int sb = slot_b ? slot_b[pair] : n_pairs + pair;
-  if ((status[sa] | status[sb]) & kStatusOverflow) {   // uniform over the pair's workgroups: nobody takes a ticket
+  const int sa = slot_a ? slot_a[pair] : slot_base + pair;
+  const int sb = slot_b ? slot_b[pair] : slot_base + n_pairs + pair;
+  // uniform over the pair's workgroups: nobody takes a ticket (bad slots: see k_match)
+  if (sa < 0 || sa >= max_slots || sb < 0 || sb >= max_slots || ((status[sa] | status[sb]) & kStatusOverflow)) {
     if (qb == 0 && tid == 0) n_out[pair] = -1;
     return;
   }
@@ -1832,7 +1628,7 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     for (int v = 0; v < 16; v++) g.umax[v] = umax[v];
   }
   long long pix = 0;
-  int cand = 0, tiles = 0, tiles_s = 0, strips = 0, tab = 0, s1 = 0;
+  int cand = 0, tiles = 0, strips = 0, tab = 0, s1 = 0;
   g.max_level_tiles = 0;
   for (int l = 0; l < g.nlevels; l++) {
     OrbLevelInfo& L = g.lv[l];
@@ -1860,9 +1656,6 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     if (L.tiles_x == 0 || L.tiles_y == 0) L.tiles_x = L.tiles_y = 0;
     L.tile_base = tiles;
     tiles += L.tiles_x * L.tiles_y;
-    L.tiles_y_s = L.tiles_x > 0 ? (L.h - 2 * kEdge + STH - 1) / STH : 0;
-    L.tile_base_s = tiles_s;
-    tiles_s += L.tiles_x * L.tiles_y_s;
     // strips: lane 1 of strip 0 holds px 28..31; 248 output px per strip over [31, w - 31), 64 output rows
     L.strips_x = L.tiles_x > 0 ? (L.w - kEdge - (kSX0 + 4) + SPX - 1) / SPX : 0;
     L.strips_y = L.tiles_x > 0 ? (L.h - 2 * kEdge + SR - 1) / SR : 0;
@@ -1892,7 +1685,6 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   g.cand_total = cand;
   g.s1_total = s1;
   g.total_tiles = tiles;
-  g.total_tiles_s = tiles_s;
   g.total_strips = strips;
 
   std::vector<uint32_t> htab(tab > 0 ? tab : 1, 0u);
@@ -1989,13 +1781,8 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
       hipLaunchKernelGGL(k_fast, dim3((unsigned)g.total_tiles * (unsigned)n), dim3(kFastThreads), 0, st, g, src, d_pyr_,
                          d_cand_cnt_, d_cand_, d_cand_sc_);
     } else {
-      if (getenv("MSF_ORB_TILE_SPARSE"))
-      hipLaunchKernelGGL(k_fast_sparse, dim3((unsigned)g.total_tiles_s * (unsigned)n), dim3(kFastThreads), 0, st, g, src,
-                         d_pyr_, tau, d_cand_cnt_, d_cand_, d_cand_sc_, getenv("MSF_ORB_ABLATE") ? atoi(getenv("MSF_ORB_ABLATE")) : 0);
-      else
       hipLaunchKernelGGL(k_fast_stream, dim3((unsigned)g.total_strips * (unsigned)n), dim3(64), 0, st, g, src, d_pyr_, tau,
-                         d_cand_cnt_, d_cand_, d_cand_sc_, getenv("MSF_ORB_ABLATE") ? atoi(getenv("MSF_ORB_ABLATE")) : 0);
-      if (!getenv("MSF_ORB_ABLATE"))
+                         d_cand_cnt_, d_cand_, d_cand_sc_);
       hipLaunchKernelGGL(k_fast_check, dim3((n * kOrbLevels + 255) / 256), dim3(256), 0, st, g, src.slot0, n, tau, d_cand_cnt_,
                          d_redo_, d_redo_ + 1);
       // fixed grid (a multiple of 8: see the XCD-contiguous unit order), sized to what the batch could need
@@ -2025,7 +1812,7 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
 }
 
 hipError_t OrbPipeline::match(int n_pairs, const int32_t* d_slot_a, const int32_t* d_slot_b, float ratio,
-                              msf_match* d_out, int cap, int32_t* d_n_out, hipStream_t st) {
+                              msf_match* d_out, int cap, int32_t* d_n_out, hipStream_t st, int slot_base) {
   if (n_pairs <= 0) return hipSuccess;
   // train descriptors go through LDS in chunks of kTrainChunk; MSF_ORB_TRAIN_CHUNK shrinks the chunk so tests can
   // exercise the multi-chunk path with ordinary keypoint counts
@@ -2036,10 +1823,10 @@ hipError_t OrbPipeline::match(int n_pairs, const int32_t* d_slot_a, const int32_
   }();
   if (n_pairs <= kSplitMaxPairs && d_qres_)
     hipLaunchKernelGGL(k_match_split, dim3(kSplitBlocks, n_pairs), dim3(256), 0, st, n_pairs, d_slot_a, d_slot_b, d_kp_,
-                       d_kp_cnt_, d_desc_, d_status_, ratio, d_out, cap, d_n_out, chunk, d_qres_, d_done_);
+                       d_kp_cnt_, d_desc_, d_status_, ratio, d_out, cap, d_n_out, chunk, d_qres_, d_done_, slot_base, max_slots_);
   else
     hipLaunchKernelGGL(k_match, dim3(n_pairs), dim3(256), 0, st, n_pairs, d_slot_a, d_slot_b, d_kp_, d_kp_cnt_,
-                       d_desc_, d_status_, ratio, d_out, cap, d_n_out, chunk);
+                       d_desc_, d_status_, ratio, d_out, cap, d_n_out, chunk, slot_base, max_slots_);
   if (ev_ok_) {
     hipEventRecord(ev_[5], st);
     ev_recorded_ = true;

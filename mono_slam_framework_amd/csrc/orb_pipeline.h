@@ -28,7 +28,6 @@ struct OrbLevelInfo {
   int cand_off;        // offset (entries) of this level inside a slot's candidate array
   int s1_off;          // offset (entries) of this level inside a slot's stage-1 array
   int tiles_x, tiles_y, tile_base;  // FAST tiling (128 x 32 tiles, dense kernel)
-  int tiles_y_s, tile_base_s;       // 128 x 28 tiling of the output-sensitive first pass
   int strips_x, strips_y, strip_base;   // 248 x 64 column strips of the streaming first pass (one wave each)
   int tab_off;         // offset (entries) of this level's resize tables
   int samp_sx, samp_sy, samp_rows, samp_cols;   // k_fast_tau's sample lattice over [31, w-31) x [31, h-31); rows 0 = none
@@ -39,7 +38,6 @@ struct OrbGeometry {
   int nlevels;
   int w0, h0;
   int total_tiles;
-  int total_tiles_s;
   int total_strips;
   int max_level_tiles;     // largest tile count of one level
   int cand_total;          // candidate entries per slot
@@ -69,9 +67,9 @@ class OrbPipeline {
 
   // extract features of n frames into slots [src.slot0, src.slot0 + n)
   hipError_t extract(const FrameSrc& src, int n_frames, hipStream_t st);
-  // match slot pairs; d_slot_a/d_slot_b may be null => pair i = (i, n_pairs + i)
+  // match slot pairs; d_slot_a/d_slot_b may be null => pair i = (slot_base + i, slot_base + n_pairs + i)
   hipError_t match(int n_pairs, const int32_t* d_slot_a, const int32_t* d_slot_b, float ratio,
-                   msf_match* d_out, int cap_per_pair, int32_t* d_n_out, hipStream_t st);
+                   msf_match* d_out, int cap_per_pair, int32_t* d_n_out, hipStream_t st, int slot_base = 0);
 
   const OrbGeometry& geom() const { return g_; }
   int max_slots() const { return max_slots_; }

@@ -207,25 +207,32 @@ class FeatureMatcher(_Matcher):
     def level_sizes(self):
         return self._debug(_lib.DBG_LEVEL_SIZES, 0, 0, np.int32, 8 * 4 * 4).reshape(8, 4)
 
-    def level_pixels(self, slot, level):
+    # Introspection of the feature slots.  `slot` counts from the scratch slots of the last MatchFrames / match_batch
+    # call (frame A of pair i = i, frame B = n_pairs + i); cache=True addresses the per-frame cache slots of
+    # extract_device / store_frame instead (the two ranges are disjoint: [2P, 4P) and [0, 2P), P = max_batch_pairs).
+    def _slot(self, slot, cache):
+        return slot if cache else 2 * self.max_batch_pairs + slot
+
+    def level_pixels(self, slot, level, cache=False):
         w, h, pitch, _ = self.level_sizes()[level]
-        return self._debug(_lib.DBG_LEVEL_PIXELS, slot, level, np.uint8, int(pitch) * int(h)).reshape(h, pitch)[:, :w]
+        return self._debug(_lib.DBG_LEVEL_PIXELS, self._slot(slot, cache), level, np.uint8,
+                           int(pitch) * int(h)).reshape(h, pitch)[:, :w]
 
-    def fast_candidates(self, slot, level):
-        return self._debug(_lib.DBG_FAST_CANDS, slot, level, np.int32, 1 << 20).reshape(-1, 3)
+    def fast_candidates(self, slot, level, cache=False):
+        return self._debug(_lib.DBG_FAST_CANDS, self._slot(slot, cache), level, np.int32, 1 << 20).reshape(-1, 3)
 
-    def fast_tau(self, slot):
+    def fast_tau(self, slot, cache=False):
         """int32 [8, 2]: per level the FAST score threshold the candidate list was built with, and its first estimate."""
-        return self._debug(_lib.DBG_FAST_TAU, slot, 0, np.int32, 64).reshape(-1, 2)
+        return self._debug(_lib.DBG_FAST_TAU, self._slot(slot, cache), 0, np.int32, 64).reshape(-1, 2)
 
-    def stage1(self, slot, level):
-        return self._debug(_lib.DBG_STAGE1, slot, level, _lib.KP_DTYPE, 1 << 18)
+    def stage1(self, slot, level, cache=False):
+        return self._debug(_lib.DBG_STAGE1, self._slot(slot, cache), level, _lib.KP_DTYPE, 1 << 18)
 
-    def keypoints(self, slot):
-        return self._debug(_lib.DBG_KEYPOINTS, slot, 0, _lib.KP_DTYPE, 2048 * 32)
+    def keypoints(self, slot, cache=False):
+        return self._debug(_lib.DBG_KEYPOINTS, self._slot(slot, cache), 0, _lib.KP_DTYPE, 2048 * 32)
 
-    def descriptors(self, slot):
-        return self._debug(_lib.DBG_DESCRIPTORS, slot, 0, np.uint8, 2048 * 32).reshape(-1, 32)
+    def descriptors(self, slot, cache=False):
+        return self._debug(_lib.DBG_DESCRIPTORS, self._slot(slot, cache), 0, np.uint8, 2048 * 32).reshape(-1, 32)
 
 
 class DNNFeatureMatcher(_Matcher):

@@ -106,6 +106,67 @@ def test_orb_database_matches_reference_logic():
     assert db.DetectLoopCandidate(gpu_kfs[0], 0) is None and db.DetectRelocalizationCandidates(gpu_kfs[0]) == []
 
 
+def test_matchframes_between_database_calls_keeps_the_keyframe_cache():
+    """One matcher handle serves Tracking's MatchFrames and the database (src/main.cpp:77-81).  The stateless calls work
+    in their own feature slots, so the resident key frames must give the same answers before and after them."""
+    from mono_slam_framework_amd.keyframe_db import KeyFrame, KeyFrameMatchDatabase
+    from mono_slam_framework_amd.matcher import FeatureMatcher
+    views = _views()[:8]
+    images = [v[2] for v in views]
+    orc = oracle_orb.FeatureMatcherOracle(0.6)
+    orb = oracle_orb.OrbOracle(W, H)
+    keys = [_keypoint_keys(orb, im, 0.6, 70 + i) for i, im in enumerate(images)]
+    gpu_kfs, cpu_kfs = _make_graph(images, keys, 5)
+    fm = FeatureMatcher(0.6, W, H, max_batch_pairs=8)
+    db = KeyFrameMatchDatabase(fm)
+    for kf in gpu_kfs:
+        db.add(kf)
+
+    def mf(a, b):
+        return orc.MatchFrames(a, b)
+
+    # unrelated MatchFrames traffic on the same handle: single pairs and a full batch (2 x 8 frames of scratch)
+    x, y = synth.synth_pair(4242, W, H)
+    np.testing.assert_array_equal(fm.MatchFrames(x, y), orc.MatchFrames(x, y))
+    A, B = synth.synth_batch(4300, 8, W, H)
+    for g_, (a_, b_) in zip(fm.match_batch(list(A), list(B)), zip(A, B)):
+        np.testing.assert_array_equal(g_, orc.MatchFrames(a_, b_))
+
+    q_img = synth.synth_pair(901, W, H, shift=(30, 14))[1]
+    got = db.DetectRelocalizationCandidates(KeyFrame(500, q_img))
+    exp, exp_num = oracle_db.detect_relocalization_candidates(cpu_kfs, mf, KeyFrame(500, q_img))
+    np.testing.assert_array_equal(db.last_num_matches, exp_num)
+    assert [k.id() for k in got] == [k.id() for k in exp]
+    np.testing.assert_array_equal(fm.MatchFrames(y, x), orc.MatchFrames(y, x))
+    got = db.DetectLoopCandidate(gpu_kfs[5], 3)
+    exp, exp_num, exp_mp = oracle_db.detect_loop_candidate(cpu_kfs, mf, cpu_kfs[5], 3)
+    np.testing.assert_array_equal(db.last_num_matches, exp_num)
+    np.testing.assert_array_equal(db.last_num_mp, exp_mp)
+    assert (got.id() if got else None) == (exp.id() if exp else None)
+
+
+def test_bad_device_slot_indices_are_reported_not_read():
+    """msf_match_slots_device takes DEVICE index arrays, which the host cannot validate: an index outside the handle's
+    slots gives n_out = -1 for that pair (no out-of-bounds read), the other pairs are unaffected."""
+    from mono_slam_framework_amd.matcher import FeatureMatcher
+    fm = FeatureMatcher(0.8, W, H, max_batch_pairs=2)
+    A, B = synth.synth_batch(300, 2, W, H)
+    d = torch.from_numpy(np.concatenate([A, B], 0)).cuda()
+    fm.extract_device(d, first_slot=0)
+    sa = torch.tensor([0, 1, 0, -3], dtype=torch.int32, device="cuda")
+    sb = torch.tensor([2, 3, 1 << 20, 2], dtype=torch.int32, device="cuda")
+    out = torch.zeros((4, 1024, 4), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros((4,), dtype=torch.int32, device="cuda")
+    fm.match_slots_device(sa, sb, out, cnt)
+    c = cnt.cpu().numpy()
+    orc = oracle_orb.FeatureMatcherOracle(0.8)
+    for i in range(2):
+        e = orc.MatchFrames(A[i], B[i])
+        assert c[i] == len(e)
+        np.testing.assert_array_equal(out[i, :len(e)].cpu().numpy(), e)
+    assert c[2] == -1 and c[3] == -1
+
+
 def test_count_kernel_edge_cases():
     """msf_count_mappoint_matches_device on hand-made match lists: out-of-image endpoints have no map point
     (KeyPointMap.cc:59-62), counts beyond the capacity and negative (failed) counts are clamped."""

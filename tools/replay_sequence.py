@@ -118,7 +118,6 @@ def replay(n_frames=1000, width=640, height=480, ratio=0.6, max_local=8, kf_ever
                 ref = fm.MatchFrames(cur, frames[f])
                 assert ref.shape == m.shape and np.array_equal(ref, m), "cached path differs from MatchFrames at frame %d" % i
                 stats["cache_checks"] += 1
-            fm.extract_device(torch.from_numpy(cur[None]).to(dev), first_slot=0)   # MatchFrames reused slots 0/1
         # new key frame: DetectLoopCandidate + SearchInNeighbors = new KF against every KF in the DB
         if i % kf_every == 0:
             slot = 2 + (len(kfs) % 64)
