@@ -76,17 +76,194 @@ def cpu_baseline_loftr(args, A, B, gpu_lists):
             "match_list_mismatches_vs_gpu": mism}
 
 
+def opencv_probe(args, A, B, gpu_lists):
+    """SURVEY.md H1 / BASELINE.md 3.2: if a real OpenCV happens to be importable on this box, run the literal reference
+    sequence (cv::ORB::create() defaults, detectAndCompute x2, BFMatcher(NORM_HAMMING).knnMatch(k=2), ratio test,
+    int truncation: src/featurematcher.cpp:3-45) on the same pairs and record how the GPU lists compare with it.
+    Never required: absent -> {"opencv": "absent"}."""
+    try:
+        import cv2
+    except Exception:
+        return {"opencv": "absent"}
+    import numpy as np
+    n = min(len(A), 16)
+    orb = cv2.ORB_create()
+    bf = cv2.BFMatcher(cv2.NORM_HAMMING)
+    t0 = time.perf_counter()
+    same_list = same_set = 0
+    jacc = []
+    for i in range(n):
+        k1, d1 = orb.detectAndCompute(A[i], np.full(A[i].shape, 255, np.uint8))
+        k2, d2 = orb.detectAndCompute(B[i], np.full(B[i].shape, 255, np.uint8))
+        m = []
+        if d1 is not None and d2 is not None and len(k2) >= 2:
+            for pr in bf.knnMatch(d1, d2, k=2):
+                if len(pr) == 2 and pr[0].distance < args.ratio * pr[1].distance:
+                    p1, p2 = k1[pr[0].queryIdx].pt, k2[pr[0].trainIdx].pt
+                    m.append((int(p1[0]), int(p1[1]), int(p2[0]), int(p2[1])))
+        g = [tuple(r) for r in gpu_lists[i].tolist()]
+        same_list += int(g == m)
+        same_set += int(set(g) == set(m))
+        u = len(set(g) | set(m))
+        jacc.append(len(set(g) & set(m)) / u if u else 1.0)
+    dt = time.perf_counter() - t0
+    return {"opencv": cv2.__version__, "pairs": n, "pairs_per_sec_1thread": round(n / dt, 3),
+            "identical_ordered_lists": same_list, "identical_match_sets": same_set,
+            "mean_match_set_jaccard": round(float(np.mean(jacc)), 4)}
+
+
+def run_workload(args, matcher, W, H, P, ratio_or_thr, rank, world, local_rank, dev, cdev, with_cpu):
+    """One metric configuration: P synthetic pairs per GPU resident in HBM, `warmup` untimed + `steps` timed steps on a
+    stream of its own.  Returns the result fields of one JSON line (rank 0) or None."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from mono_slam_framework_amd import _lib, synth
+    from mono_slam_framework_amd.gather import MatchListGather
+    from mono_slam_framework_amd.matcher import DNNFeatureMatcher, FeatureMatcher
+
+    mode = args.synth_mode if args.synth_mode is not None else (1 if matcher == "loftr" else 0)
+    first = synth_first_pair(rank, world, P)
+    A, B = synth.synth_batch(first, P, W, H, mode=mode, threads=min(16, os.cpu_count() or 1))
+    dA, dB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+    if matcher == "orb":
+        fm = FeatureMatcher(ratio_or_thr, W, H, device=local_rank, max_batch_pairs=P, flags=_lib.MSF_FLAG_PROFILE)
+    else:
+        fm = DNNFeatureMatcher(threshold=ratio_or_thr, device=local_rank, max_batch_pairs=P, flags=_lib.MSF_FLAG_PROFILE)
+    out = torch.zeros((P, args.cap, 4), dtype=torch.int32, device=dev)
+    cnt = torch.zeros((P,), dtype=torch.int32, device=dev)
+    packed = torch.zeros((P * args.cap, 4), dtype=torch.int32, device=dev)
+    offs = torch.zeros((P + 1,), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    # the whole step is enqueued on ONE stream of its own (the *_device entry points are asynchronous on the stream
+    # they are given; one stream in flight per handle: include/msf_abi.h)
+    side = torch.cuda.Stream(device=dev)
+    stream = side.cuda_stream
+    gather = MatchListGather(P, cdev) if world > 1 else None
+    stage_acc = {}
+    gathered = [0]
+
+    def step(timed):
+        with torch.cuda.stream(side):
+            fm.match_batch_device(dA, dB, out, cnt, stream=stream)
+            fm.pack_matches_device(out, cnt, packed, offs, stream=stream)
+            if gather is not None:
+                # gather of variable-length match lists to rank 0 (all-gather of offsets, then exact-size
+                # ncclSend/ncclRecv over xGMI); no all-reduce in the data path
+                res = gather(packed.to(cdev), offs.to(cdev))
+                if res is not None:
+                    gathered[0] = sum(int(r[0].shape[0]) for r in res)
+        if timed:
+            for k, v in fm.stage_times().items():   # HIP events recorded on the launch stream
+                stage_acc[k] = stage_acc.get(k, 0.0) + v
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)   # timing only, outside the timed region
+        dt = float(tmax.item())
+    res = None
+    if rank == 0:
+        cnt_h = cnt.cpu().numpy()
+        out_h = out.cpu().numpy()
+        lists = [out_h[i, :max(cnt_h[i], 0)] for i in range(P)]
+        ms_per_step = dt / args.steps * 1e3
+        value = world * P * args.steps / dt
+        bpp = algorithmic_bytes_per_pair(W, H)
+        stages = {k: v / args.steps for k, v in stage_acc.items()}
+        dom = max(stages, key=stages.get) if stages else None
+        roofline = None
+        traffic = traffic_record(matcher, dom, P, W, H)
+        if dom and matcher == "loftr":
+            # dominant "kernel" = the 22-launch convolution stack (k_conv<...>) of one call
+            flops = P * (LOFTR_CONV_FLOPS_PER_PAIR if dom == "backbone_convs" else LOFTR_FLOPS_PER_PAIR)
+            achieved = flops / (stages[dom] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 5), "traffic": traffic,
+                        "avg_launch_ms": round(stages[dom], 4), "algorithmic_flops_per_launch": flops,
+                        "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+                        "pipeline_frac": round(value / world * LOFTR_FLOPS_PER_PAIR / 1e12 / MFMA_F32_PEAK_TFLOPS, 5)}
+        elif dom:
+            achieved = P * bpp / (stages[dom] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom,
+                        "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "avg_launch_ms": round(stages[dom], 4),
+                        "algorithmic_bytes_per_launch": P * bpp,
+                        "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+                        "pipeline_frac": round(value / world * bpp / 1e9 / HBM_PEAK_GBS, 5)}
+        if world > 1:
+            assert gathered[0] > 0, "rank 0 gathered no match records"
+        res = {
+            "value": round(value, 2), "ms_per_step": round(ms_per_step, 4),
+            "dtype": "u8" if matcher == "orb" else "f32",
+            "config": {"workload": "%s extract+match, %dx%d pairs, %d pairs/GPU/step resident in HBM, %s"
+                                   % (matcher.upper(), W, H, P,
+                                      "ratio %.2f" % ratio_or_thr if matcher == "orb" else "conf threshold %.2f" % ratio_or_thr),
+                       "pairs_per_gpu": P, "width": W, "height": H, "synth_mode": mode,
+                       "matches_per_pair_mean": round(float(np.mean([len(l) for l in lists])), 2),
+                       "overflow_pairs": int((cnt_h < 0).sum()),
+                       "gathered_match_records_per_step": gathered[0] if world > 1 else int(offs[P].item()),
+                       "shard": "pair p of a step -> rank p // pairs_per_gpu (contiguous blocks)",
+                       "collective_backend": args.backend if world > 1 else None},
+            "roofline": roofline,
+        }
+        if with_cpu:
+            cargs = argparse.Namespace(**vars(args))
+            cargs.width, cargs.height, cargs.ratio, cargs.threshold = W, H, ratio_or_thr, ratio_or_thr
+            res["cpu_baseline"] = (cpu_baseline if matcher == "orb" else cpu_baseline_loftr)(cargs, A, B, lists)
+            if matcher == "orb":
+                res["cpu_baseline"]["reference_lib"] = opencv_probe(cargs, A, B, lists)
+    fm.close()
+    del dA, dB, out, cnt, packed, offs
+    torch.cuda.empty_cache()
+    return res
+
+
+def synth_first_pair(rank, world, P):
+    # contiguous blocks: rank r owns pairs r*P .. r*P + P - 1 of every step (DESIGN.md section 6, gather.shard_pairs)
+    return rank * P
+
+
+def traffic_record(matcher, dom, P, W, H):
+    """HBM bytes per launch of the dominant stage from the committed PMC passes (profiles/traffic_*.json, collected by
+    tools/collect_profiles.sh: separate --pmc runs, FETCH_SIZE x 2 + WRITE_SIZE).  Not measured inside this run: the
+    record names its source and the kernel versions it was taken at, and is dropped when the batch differs."""
+    tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % matcher)
+    try:
+        tj = json.load(open(tfile))
+    except Exception:
+        return None
+    if tj.get("_pairs_per_gpu") != P or tj.get("_width", W) != W or dom not in tj:
+        return None
+    return {"bytes": tj[dom], "source": "profiles/traffic_%s.json" % matcher, "measured_at": tj.get("_commit")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=1024, help="pairs per GPU per step (resident in HBM)")
+    ap.add_argument("--pairs", type=int, default=None, help="pairs per GPU per step (resident in HBM); default 1024 (ORB 720p), 4096 (ORB VGA), 256 (LoFTR)")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--ratio", type=float, default=0.6, help="Lowe ratio (the app uses 0.6, src/main.cpp:66)")
     ap.add_argument("--cap", type=int, default=1024, help="match-list capacity per pair")
-    ap.add_argument("--matcher", default="orb", choices=["orb", "loftr"])
+    ap.add_argument("--matcher", default=None, choices=["orb", "loftr"],
+                    help="one workload only; default: the headline (ORB 1280x720) plus, on one GPU, the two other metric "
+                         "configurations (ORB 640x480, LoFTR 640x480) as `secondary`")
     ap.add_argument("--synth-mode", type=int, default=None,
                     help="synthetic texture: 0 blocky x8 (SURVEY 8d, ORB default), 1 smooth blobs (LoFTR default), 2 blocky x16")
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -94,12 +271,12 @@ def main():
     ap.add_argument("--cpu-loftr-pairs", type=int, default=8)
     ap.add_argument("--threshold", type=float, default=0.15, help="LoFTR confidence threshold (dnnfeaturematcher.h:11)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured configuration); gloo = rehearsal of the N > 1 code path "
                          "on a box with fewer GPUs than ranks (all ranks share cuda:0, results staged through host)")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -122,128 +299,30 @@ def main():
             dist.init_process_group("gloo")
     cdev = dev if args.backend == "nccl" else torch.device("cpu")   # where the collective's tensors live
 
-    from mono_slam_framework_amd import _lib, synth
-    from mono_slam_framework_amd.matcher import DNNFeatureMatcher, FeatureMatcher
-
+    with_cpu = not args.no_cpu_baseline and world == 1     # the CPU leg is timed on rank 0 of the 1-GPU run only
     if args.matcher == "loftr":
-        args.width, args.height = 640, 480
-        if args.pairs == 1024:
-            args.pairs = 256
-    W, H, P = args.width, args.height, args.pairs
-    # synthetic pairs of this rank (pair index = rank * P + i), resident in HBM before timing
-    mode = args.synth_mode if args.synth_mode is not None else (1 if args.matcher == "loftr" else 0)
-    A, B = synth.synth_batch(rank * P, P, W, H, mode=mode,
-                             threads=min(16, os.cpu_count() or 1))
-    dA, dB = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
-    if args.matcher == "orb":
-        fm = FeatureMatcher(args.ratio, W, H, device=local_rank, max_batch_pairs=P, flags=_lib.MSF_FLAG_PROFILE)
+        head = ("loftr", 640, 480, args.pairs or 256, args.threshold)
     else:
-        fm = DNNFeatureMatcher(threshold=args.threshold, device=local_rank, max_batch_pairs=P,
-                               flags=_lib.MSF_FLAG_PROFILE)
-    out = torch.zeros((P, args.cap, 4), dtype=torch.int32, device=dev)
-    cnt = torch.zeros((P,), dtype=torch.int32, device=dev)
-    packed = torch.zeros((P * args.cap, 4), dtype=torch.int32, device=dev)
-    offs = torch.zeros((P + 1,), dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    from mono_slam_framework_amd.gather import MatchListGather
-    gather = MatchListGather(P, cdev) if world > 1 else None
-    stage_acc = {}
-    gathered = [0]
-
-    def step(timed):
-        fm.match_batch_device(dA, dB, out, cnt, stream=stream)
-        fm.pack_matches_device(out, cnt, packed, offs, stream=stream)
-        if gather is not None:
-            # gather of variable-length match lists to rank 0 (all-gather of offsets, then exact-size
-            # ncclSend/ncclRecv over xGMI); no all-reduce in the data path
-            res = gather(packed.to(cdev), offs.to(cdev))
-            if res is not None:
-                gathered[0] = sum(int(r[0].shape[0]) for r in res)
-        if timed:
-            for k, v in fm.stage_times().items():   # HIP events recorded on the launch stream
-                stage_acc[k] = stage_acc.get(k, 0.0) + v
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)   # timing only, outside the timed region
-        dt = float(tmax.item())
-
+        vga = (args.width, args.height) == (640, 480)
+        head = ("orb", args.width, args.height, args.pairs or (4096 if vga else 1024), args.ratio)
+    extra = []
+    if args.matcher is None and world == 1 and not args.no_secondary and (args.width, args.height) == (1280, 720) \
+            and args.pairs is None:
+        extra = [("orb", 640, 480, 4096, args.ratio), ("loftr", 640, 480, 256, args.threshold)]
+    r = run_workload(args, *head, rank, world, local_rank, dev, cdev, with_cpu)
+    secondary = [run_workload(args, *w, rank, world, local_rank, dev, cdev, with_cpu) for w in extra]
     if rank == 0:
-        cnt_h = cnt.cpu().numpy()
-        out_h = out.cpu().numpy()
-        lists = [out_h[i, :max(cnt_h[i], 0)] for i in range(P)]
-        ms_per_step = dt / args.steps * 1e3
-        value = world * P * args.steps / dt
-        bpp = algorithmic_bytes_per_pair(W, H)
-        stages = {k: v / args.steps for k, v in stage_acc.items()}
-        dom = max(stages, key=stages.get) if stages else None
-        roofline = None
-        if dom and args.matcher == "loftr":
-            # dominant "kernel" = the 22-launch convolution stack (k_conv<...>) of one call
-            flops = P * (LOFTR_CONV_FLOPS_PER_PAIR if dom == "backbone_convs" else LOFTR_FLOPS_PER_PAIR)
-            achieved = flops / (stages[dom] * 1e-3) / 1e12
-            traffic = None
-            tfile = os.path.join(ROOT, "profiles", "traffic_loftr.json")
-            if os.path.exists(tfile):
-                try:
-                    tj = json.load(open(tfile))
-                    traffic = tj.get(dom) if tj.get("_pairs_per_gpu") == P else None
-                except Exception:
-                    traffic = None
-            roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 5), "traffic": traffic,
-                        "avg_launch_ms": round(stages[dom], 4), "algorithmic_flops_per_launch": flops,
-                        "stage_ms": {k: round(v, 4) for k, v in stages.items()},
-                        "pipeline_frac": round(value / world * LOFTR_FLOPS_PER_PAIR / 1e12 / MFMA_F32_PEAK_TFLOPS, 5)}
-        elif dom:
-            achieved = P * bpp / (stages[dom] * 1e-3) / 1e9
-            traffic = None
-            tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.matcher)
-            if os.path.exists(tfile):
-                try:
-                    tj = json.load(open(tfile))
-                    traffic = tj.get(dom) if tj.get("_pairs_per_gpu") == P else None   # measured at the same batch only
-                except Exception:
-                    traffic = None
-            roofline = {"bound": "hbm" if args.matcher == "orb" else "mfma", "kernel": dom,
-                        "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                        "avg_launch_ms": round(stages[dom], 4),
-                        "algorithmic_bytes_per_launch": P * bpp,
-                        "stage_ms": {k: round(v, 4) for k, v in stages.items()},
-                        "pipeline_frac": round(value / world * bpp / 1e9 / HBM_PEAK_GBS, 5)}
-        if world > 1:
-            assert gathered[0] > 0, "rank 0 gathered no match records"
-        line = {
-            "metric": "frame-pairs/sec (extract+match)", "value": round(value, 2), "unit": "frame-pairs/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8" if args.matcher == "orb" else "f32", "data": "synthetic",
-            "config": {"workload": "%s extract+match, %dx%d pairs, %d pairs/GPU/step resident in HBM, %s"
-                                   % (args.matcher.upper(), W, H, P,
-                                      "ratio %.2f" % args.ratio if args.matcher == "orb" else "conf threshold %.2f" % args.threshold),
-                       "pairs_per_gpu": P, "width": W, "height": H, "synth_mode": mode,
-                       "matches_per_pair_mean": round(float(np.mean([len(l) for l in lists])), 2),
-                       "overflow_pairs": int((cnt_h < 0).sum()),
-                       "gathered_match_records_per_step": gathered[0] if world > 1 else int(offs[P].item()),
-                       "collective_backend": args.backend if world > 1 else None},
-            "roofline": roofline,
-        }
-        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed on rank 0 of the 1-GPU run only
-            line["cpu_baseline"] = (cpu_baseline if args.matcher == "orb" else cpu_baseline_loftr)(args, A, B, lists)
+        line = {"metric": "frame-pairs/sec (extract+match)", "value": r["value"], "unit": "frame-pairs/sec",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": r["dtype"],
+                "data": "synthetic", "config": r["config"], "roofline": r["roofline"]}
+        if "cpu_baseline" in r:
+            line["cpu_baseline"] = r["cpu_baseline"]
+        if secondary:
+            # the two other configurations of BASELINE.json's metric, each run like the headline: same steps / warmup
+            line["secondary"] = [dict(workload=x["config"]["workload"], unit="frame-pairs/sec", steps=args.steps,
+                                      warmup=args.warmup, **{k: v for k, v in x.items() if k != "config"},
+                                      config=x["config"]) for x in secondary]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

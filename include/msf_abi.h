@@ -21,6 +21,16 @@
  * different std::async thread per frame (src/main.cpp:131-139).  Every entry
  * point therefore selects the handle's device itself and serialises on a
  * per-handle mutex.
+ *
+ * Streams: the *_device entry points enqueue on the hipStream_t they are given
+ * and return without waiting.  A handle's device workspaces are shared by all
+ * its calls, so ONE stream may be in flight per handle: enqueue a handle's
+ * calls on one stream (or synchronise between streams).  stream = NULL means
+ * the handle's own stream, which is created with hipStreamDefault flags -- it
+ * is ordered against the legacy null stream in both directions, so buffers a
+ * caller prepared on the null stream (torch's default stream) are seen -- and
+ * which is synchronised before the call returns.  Host-pointer entry points
+ * always use the handle's stream and return when the results are in host memory.
  */
 #ifndef MSF_ABI_H
 #define MSF_ABI_H
@@ -54,6 +64,7 @@ typedef enum msf_kind {
 #define MSF_FLAG_BLUR_TIE_HALF_UP 1u /* ORB 7x7 blur: (sum+32768)>>16 instead of round-half-even */
 #define MSF_FLAG_PROFILE 2u          /* record per-stage HIP events on the launch stream (msf_stage_times) */
 #define MSF_FLAG_KEEP_DEBUG 4u       /* LoFTR: keep pair 0's confidence matrix and coarse features for msf_debug_get */
+#define MSF_FLAG_NO_FRAME_CACHE 16u  /* msf_match_pair: extract both frames on every call (no transparent per-frame cache) */
 #define MSF_FLAG_FAST_DENSE 8u       /* ORB: score every pixel at fastThreshold (no output-sensitive first pass); same results */
 
 typedef struct msf_config {
@@ -66,7 +77,10 @@ typedef struct msf_config {
   int32_t image_height;
   int32_t max_batch_pairs;   /* device workspace is sized for this many pairs per call */
   uint32_t flags;
-  const char* weights_path;  /* LoFTR weights blob; NULL = <library dir>/weights/loftr_teacher.bin */
+  const char* weights_path;  /* LoFTR: the model file, as DNNFeatureMatcher's model_file_path (dnnfeaturematcher.cpp:11-21):
+                                the reference's model/LoFTR_teacher.onnx is read directly (its initializers and constants);
+                                an MSFLTR01 blob made by msf_convert_weights loads the same tensors faster.
+                                NULL = <library dir>/weights/loftr_teacher.bin */
 } msf_config;
 
 /* FrameBase::imGray as the matchers read it (slam_pipeline/include/FrameBase.h:45):
@@ -95,6 +109,13 @@ typedef struct msf_keypoint {
 int msf_abi_version(void);
 void msf_default_config(msf_config* cfg, int kind);
 
+/* The LoFTR model file on the host, no GPU involved (what Ort::Session's constructor does with the path,
+ * dnnfeaturematcher.cpp:18-21): msf_weights_info reads `path` -- ONNX model or MSFLTR01 blob -- and reports the tensor
+ * count, the f32 count and a digest of names, shapes and values (equal digests <=> identical weights);
+ * msf_convert_weights writes them as a blob.  Errors: MSF_ERR_IO with msf_last_error(NULL). */
+int msf_weights_info(const char* path, uint64_t* digest, int32_t* n_tensors, int64_t* n_floats);
+int msf_convert_weights(const char* src_path, const char* dst_blob_path);
+
 /* FeatureMatcher::FeatureMatcher(threshold) / DNNFeatureMatcher::DNNFeatureMatcher(path, threshold, w, h, res)
  * (featurematcher.cpp:3-6, dnnfeaturematcher.cpp:11-40) */
 int msf_create(const msf_config* cfg, msf_handle** out);
@@ -105,9 +126,16 @@ int msf_set_threshold(msf_handle* h, float value);
 const char* msf_last_error(const msf_handle* h); /* h may be NULL: error of the last failed msf_create */
 
 /* FeatureMatcher::MatchFrames(pF1, pF2) (featurematcher.cpp:10-45, dnnfeaturematcher.cpp:44-102):
- * host images in, host match list out.  Writes min(n, cap) matches, *n_out = n. */
+ * host images in, host match list out.  Writes min(n, cap) matches, *n_out = n.
+ * The reference extracts both frames on every call, and its callers loop MatchFrames(X, KF_i) with X fixed
+ * (Tracking.cc:595-632, LocalMapping.cc:176,329, KeyFrameDatabase.cc:32,64).  msf_match_pair keeps the per-frame part
+ * (ORB key points + descriptors / LoFTR backbone tokens) of the last frames it saw -- 64 by default, env
+ * MSF_FRAME_CACHE_SLOTS, least recently used replaced -- keyed by a 64-bit content hash and confirmed by comparing the
+ * frame's bytes with a host copy, so a hash collision is a miss, never a wrong result.  Results are identical with the
+ * cache on or off (MSF_FLAG_NO_FRAME_CACHE); msf_frame_cache_stats counts hits and misses (a miss = one extraction). */
 int msf_match_pair(msf_handle* h, const msf_image* a, const msf_image* b,
                    msf_match* out, int32_t cap, int32_t* n_out);
+int msf_frame_cache_stats(msf_handle* h, uint64_t* hits, uint64_t* misses, int32_t* capacity);
 /* n_pairs independent MatchFrames calls in one launch sequence; out is [n_pairs][cap_per_pair] */
 int msf_match_batch(msf_handle* h, int32_t n_pairs, const msf_image* a, const msf_image* b,
                     msf_match* out, int32_t cap_per_pair, int32_t* n_out);
@@ -122,8 +150,10 @@ int msf_match_batch_device(msf_handle* h, int32_t n_pairs, const uint8_t* d_a, c
 
 /* "next" row 1 of SURVEY.md 8f: extract once per frame, match many.  The per-frame part -- ORB key points and
  * descriptors, or the LoFTR backbone tokens ([1200][32] f32; the backbone sees one image at a time, only the attention
- * blocks and the correlation see the pair) -- stays in the handle's device slots [0, 2*max_batch_pairs).
- * msf_match_slots_device pairs slots (DEVICE index arrays); LoFTR: n_pairs <= max_batch_pairs. */
+ * blocks and the correlation see the pair) -- stays in the handle's device slots [0, 2*max_batch_pairs).  MatchFrames
+ * calls on the same handle (msf_match_pair/_batch/_batch_device) work in separate slots and leave these untouched.
+ * msf_match_slots_device pairs slots (DEVICE index arrays; an index outside [0, 2*max_batch_pairs) gives n_out = -1
+ * for that pair); LoFTR: n_pairs <= max_batch_pairs. */
 int msf_extract_device(msf_handle* h, int32_t n_frames, const uint8_t* d_frames, int64_t frame_stride,
                        int64_t row_stride, int32_t first_slot, void* stream);
 int msf_match_slots_device(msf_handle* h, int32_t n_pairs, const int32_t* d_slot_a, const int32_t* d_slot_b,
@@ -131,7 +161,8 @@ int msf_match_slots_device(msf_handle* h, int32_t n_pairs, const int32_t* d_slot
 
 /* "next" row 3 of SURVEY.md 8f: KeyFrameMatchDatabase scoring (slam_pipeline/src/KeyFrameDatabase.cc:23-53).
  * msf_set_mappoints replaces the content of map slot [0, 2*max_batch_pairs) with a frame's KeyPointMap occupancy:
- * `keys` (HOST pointer) are the pixel keys y*cols + x that hold a map point (KeyPointMap.cc:36-52).
+ * `keys` (HOST pointer) are the pixel keys y*cols + x that hold a map point (KeyPointMap.cc:36-52); keys outside the
+ * image are ignored, as KeyPointMap::SetMapPoint ignores such points (KeyPointMap.cc:38-39).
  * msf_count_mappoint_matches_device: d_num_mp[i] = number of the first min(d_n_matches[i], cap_per_pair) matches of
  * pair i whose endpoint 1 is set in map slot d_map_a[i] and endpoint 2 in map slot d_map_b[i]
  * (MatchFramesResult::GetMapPoint1/2 both non-null, FeatureMatcher.h:23-29, KeyFrameDatabase.cc:37-44). */

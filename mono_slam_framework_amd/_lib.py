@@ -20,6 +20,7 @@ MSF_FLAG_BLUR_TIE_HALF_UP = 1
 MSF_FLAG_PROFILE = 2
 MSF_FLAG_KEEP_DEBUG = 4
 MSF_FLAG_FAST_DENSE = 8
+MSF_FLAG_NO_FRAME_CACHE = 16
 
 (DBG_LEVEL_SIZES, DBG_LEVEL_PIXELS, DBG_FAST_CANDS, DBG_KEYPOINTS, DBG_DESCRIPTORS, DBG_STAGE1,
  DBG_LOFTR_CONF, DBG_LOFTR_FEAT, DBG_FAST_TAU) = range(9)
@@ -30,7 +31,8 @@ ABI_SYMBOLS = ["msf_abi_version", "msf_default_config", "msf_create", "msf_destr
                "msf_extract_device", "msf_match_slots_device", "msf_pack_matches_device", "msf_debug_get",
                "msf_stage_times", "msf_set_mappoints", "msf_count_mappoint_matches_device",
                "msf_store_frame", "msf_match_one_to_many", "msf_check_hypotheses",
-               "msf_render_match_image"]
+               "msf_render_match_image", "msf_weights_info", "msf_convert_weights",
+               "msf_frame_cache_stats"]
 
 
 class Config(C.Structure):
@@ -84,6 +86,9 @@ def load():
     L.msf_match_one_to_many.argtypes = [vp, i32, i32, vp, vp, vp, vp, i32]
     L.msf_check_hypotheses.argtypes = [vp, i32, i32, vp, vp, i32, vp, f32, vp, C.POINTER(i32), vp]
     L.msf_render_match_image.argtypes = [vp, C.POINTER(Image), C.POINTER(Image), vp, i32, vp, vp, vp, i64]
+    L.msf_weights_info.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(i32), C.POINTER(i64)]
+    L.msf_convert_weights.argtypes = [C.c_char_p, C.c_char_p]
+    L.msf_frame_cache_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(i32)]
     L.msf_stage_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(f32), i32]
     _lib = L
     return L

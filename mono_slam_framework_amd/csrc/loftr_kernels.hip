@@ -9,6 +9,7 @@
 //
 // Activations are NCHW f32 (the graph's own layout) so MFMA results store as float4 runs along W.
 #include "loftr_pipeline.h"
+#include "weights_io.h"
 
 #include <dlfcn.h>
 #include <math.h>
@@ -772,7 +773,8 @@ struct LoftrPipeline::Impl {
   // workspace (per chunk of pairs)
   float *bufA = nullptr, *bufB = nullptr, *bufC = nullptr, *bufD = nullptr;
   float *tok[4] = {nullptr, nullptr, nullptr, nullptr};  // f0 f1 t0 t1, each [max_pairs][1200][32]
-  float* tok_cache = nullptr;  // [2*max_pairs][1200][32] backbone tokens per frame slot (extract / match_slots)
+  float* tok_cache = nullptr;  // [n_slots][1200][32] backbone tokens per frame slot (extract / match_slots)
+  int n_slots = 0;             // 2 * max_pairs caller-visible slots + the handle's transparent frame cache
   float* fsc = nullptr;      // [2][max_pairs][1200][32] features / sqrt(32)
   float* kv = nullptr;       // [max_pairs][1056]
   float* rstats = nullptr;   // [max_pairs][2][1200]
@@ -803,36 +805,6 @@ void LoftrPipeline::destroy() {
 
 namespace {
 
-struct Blob {
-  std::map<std::string, std::pair<std::vector<uint32_t>, std::vector<float>>> t;
-};
-
-std::string load_blob(const std::string& path, Blob* b) {
-  FILE* f = fopen(path.c_str(), "rb");
-  if (!f) return "io: cannot open weights file " + path;
-  char magic[8];
-  uint32_t n = 0;
-  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "MSFLTR01", 8) != 0 || fread(&n, 4, 1, f) != 1 || n > 4096) {
-    fclose(f);
-    return "io: bad weights header in " + path;
-  }
-  struct Rec { char name[32]; uint32_t ndim, dims[4], off, count; };
-  static_assert(sizeof(Rec) == 60, "record layout");
-  std::vector<Rec> recs(n);
-  if (fread(recs.data(), sizeof(Rec), n, f) != n) { fclose(f); return "io: truncated weights table"; }
-  size_t total = 0;
-  for (auto& r : recs) total = std::max(total, (size_t)r.off + r.count);
-  std::vector<float> data(total);
-  if (fread(data.data(), 4, total, f) != total) { fclose(f); return "io: truncated weights payload"; }
-  fclose(f);
-  for (auto& r : recs) {
-    std::string name(r.name, strnlen(r.name, 32));
-    std::vector<uint32_t> dims(r.dims, r.dims + r.ndim);
-    b->t[name] = {dims, std::vector<float>(data.begin() + r.off, data.begin() + r.off + r.count)};
-  }
-  return "";
-}
-
 std::string default_weights() {
   Dl_info info;
   std::string dir = ".";
@@ -852,11 +824,13 @@ std::string default_weights() {
     if (e_ != hipSuccess) return std::string(#expr) + ": " + hipGetErrorString(e_);      \
   } while (0)
 
-std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool profile, bool keep_debug) {
+std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool profile, bool keep_debug,
+                                int extra_slots) {
   destroy();
   p_ = new Impl();
   Impl& P = *p_;
   P.max_pairs = max_pairs;
+  P.n_slots = 2 * max_pairs + (extra_slots > 0 ? extra_slots : 0);
   {
     if (const char* d = getenv("MSF_LOFTR_DENSE_HEAD")) P.dense_head = atoi(d) != 0;   // tests: force the dense head
     const char* e = getenv("MSF_LOFTR_CHUNK");   // pairs per backbone pass (activation working set)
@@ -865,13 +839,14 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
   }
   P.profile = profile;
   P.keep_debug = keep_debug;
-  Blob blob;
-  std::string err = load_blob(weights_path && weights_path[0] ? weights_path : default_weights(), &blob);
+  // the model file the caller names (the reference's .onnx, dnnfeaturematcher.cpp:11-21) or the packed blob
+  WeightMap blob;
+  std::string err = load_weights(weights_path && weights_path[0] ? weights_path : default_weights(), &blob);
   if (!err.empty()) return err;
   auto need = [&](const std::string& n, size_t count) -> const std::vector<float>* {
-    auto it = blob.t.find(n);
-    if (it == blob.t.end() || it->second.second.size() != count) return nullptr;
-    return &it->second.second;
+    auto it = blob.find(n);
+    if (it == blob.end() || it->second.data.size() != count) return nullptr;
+    return &it->second.data;
   };
   auto upload = [&](const std::vector<float>& h, float** d) -> hipError_t {
     hipError_t e = hipMalloc(d, h.size() * sizeof(float));
@@ -987,7 +962,7 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
   LF_TRY(dalloc(&P.bufC, big));
   LF_TRY(dalloc(&P.bufD, big / 2));
   for (int i = 0; i < 4; i++) LF_TRY(dalloc(&P.tok[i], (size_t)max_pairs * NTOK * DM));
-  LF_TRY(dalloc(&P.tok_cache, (size_t)2 * max_pairs * NTOK * DM));
+  LF_TRY(dalloc(&P.tok_cache, (size_t)P.n_slots * NTOK * DM));
   LF_TRY(dalloc(&P.fsc, (size_t)2 * max_pairs * NTOK * DM));
   LF_TRY(dalloc(&P.kv, (size_t)max_pairs * (DM * DM + DM)));
   LF_TRY(dalloc(&P.rstats, (size_t)max_pairs * 2 * NTOK));
@@ -1074,7 +1049,7 @@ hipError_t LoftrPipeline::extract(int n_frames, const uint8_t* d_frames, long lo
                                   int first_slot, hipStream_t st) {
   if (!p_) return hipErrorNotInitialized;
   Impl& P = *p_;
-  if (n_frames < 0 || first_slot < 0 || first_slot + n_frames > 2 * P.max_pairs) return hipErrorInvalidValue;
+  if (n_frames < 0 || first_slot < 0 || first_slot + n_frames > P.n_slots) return hipErrorInvalidValue;
   const long long ts = (long long)NTOK * DM;
   for (int f0 = 0; f0 < n_frames; f0 += 2 * P.chunk) {
     const int n = std::min(2 * P.chunk, n_frames - f0);
@@ -1093,12 +1068,12 @@ hipError_t LoftrPipeline::match_slots(int n_pairs, const int32_t* d_slot_a, cons
   hipEvent_t* ev = P.ev_ok ? P.ev.data() : nullptr;
   if (ev) hipEventRecord(ev[0], st);
   hipLaunchKernelGGL(k_gather_tokens, dim3(NTOK * DM / 4 / 256 + 1, n_pairs, 2), dim3(256), 0, st, P.tok_cache,
-                     d_slot_a, d_slot_b, 2 * P.max_pairs, P.tok[0], P.tok[1]);
+                     d_slot_a, d_slot_b, P.n_slots, P.tok[0], P.tok[1]);
   if (ev) hipEventRecord(ev[1], st);
   return transformer_and_head(n_pairs, threshold, d_out, cap, d_n_out, st);
 }
 
-int LoftrPipeline::max_slots() const { return p_ ? 2 * p_->max_pairs : 0; }
+int LoftrPipeline::max_slots() const { return p_ ? p_->n_slots : 0; }
 
 namespace {
 

@@ -17,7 +17,8 @@ class LoftrPipeline {
   LoftrPipeline() = default;
   ~LoftrPipeline();
   // returns empty string on success; "io: ..." for weight-file problems
-  std::string init(const char* weights_path, int max_pairs, bool profile, bool keep_debug);
+  // extra_slots: token slots beyond the 2 * max_pairs caller-visible ones (the handle's transparent frame cache)
+  std::string init(const char* weights_path, int max_pairs, bool profile, bool keep_debug, int extra_slots = 0);
   void destroy();
   hipError_t match(int n_pairs, const uint8_t* d_a, const uint8_t* d_b, long long frame_stride, int row_stride,
                    float threshold, msf_match* d_out, int cap_per_pair, int32_t* d_n_out, hipStream_t st);

@@ -1807,7 +1807,10 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
     hipLaunchKernelGGL(k_describe, dim3(bx, n), dim3(256), 0, st, g, src, d_pyr_, d_kp_, d_kp_cnt_, d_desc_,
                        half_up_ ? 1 : 0);
   }
-  if (ev_ok_) hipEventRecord(ev_[4], st);
+  if (ev_ok_) {
+    hipEventRecord(ev_[4], st);
+    ev_extract_pending_ = true;
+  }
   return hipGetLastError();
 }
 
@@ -1816,6 +1819,7 @@ hipError_t OrbPipeline::match(int n_pairs, const int32_t* d_slot_a, const int32_
   if (n_pairs <= 0) return hipSuccess;
   // train descriptors go through LDS in chunks of kTrainChunk; MSF_ORB_TRAIN_CHUNK shrinks the chunk so tests can
   // exercise the multi-chunk path with ordinary keypoint counts
+  if (ev_ok_ && !ev_extract_pending_) hipEventRecord(ev_[4], st);
   static const int chunk = [] {
     const char* e = getenv("MSF_ORB_TRAIN_CHUNK");
     const int v = e ? atoi(e) : kTrainChunk;
@@ -1830,6 +1834,8 @@ hipError_t OrbPipeline::match(int n_pairs, const int32_t* d_slot_a, const int32_
   if (ev_ok_) {
     hipEventRecord(ev_[5], st);
     ev_recorded_ = true;
+    ev_match_only_ = !ev_extract_pending_;   // a slot-pair match on its own: only the last interval is of this call
+    ev_extract_pending_ = false;
   }
   return hipGetLastError();
 }
@@ -1839,7 +1845,7 @@ int OrbPipeline::stage_times(const char** names, float* ms, int cap) {
   if (!ev_ok_ || !ev_recorded_) return 0;
   if (hipEventSynchronize(ev_[5]) != hipSuccess) return 0;
   int n = 0;
-  for (int i = 0; i < 5 && n < cap; i++, n++) {
+  for (int i = ev_match_only_ ? 4 : 0; i < 5 && n < cap; i++, n++) {
     names[n] = kNames[i];
     if (hipEventElapsedTime(&ms[n], ev_[i], ev_[i + 1]) != hipSuccess) ms[n] = -1.f;
   }

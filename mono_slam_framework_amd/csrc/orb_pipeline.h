@@ -98,7 +98,7 @@ class OrbPipeline {
   uint32_t* d_qres_ = nullptr;     // [kSplitMaxPairs][kKpCap] per-query results of the small-batch matcher
   uint32_t* d_done_ = nullptr;     // [kSplitMaxPairs] ticket counters (left at 0)
   hipEvent_t ev_[kOrbStages + 2] = {};
-  bool ev_ok_ = false, ev_recorded_ = false;
+  bool ev_ok_ = false, ev_recorded_ = false, ev_extract_pending_ = false, ev_match_only_ = false;
   FrameSrc last_src_{};
 };
 

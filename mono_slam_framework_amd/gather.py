@@ -6,8 +6,11 @@ import torch.distributed as dist
 
 
 def shard_pairs(n_pairs_total, rank, world):
-    """Static, deterministic partition: pair p belongs to rank p % world."""
-    return list(range(rank, n_pairs_total, world))
+    """Static, deterministic partition into contiguous blocks (what bench.py and DESIGN.md section 6 use: a rank's
+    frames are one resident array, and rank 0's gathered lists come out in pair order): rank r owns pairs
+    [r * ceil(n / world), min(n, (r + 1) * ceil(n / world)))."""
+    per = -(-n_pairs_total // world)
+    return list(range(min(n_pairs_total, rank * per), min(n_pairs_total, (rank + 1) * per)))
 
 
 class MatchListGather:

@@ -83,6 +83,12 @@ class _Matcher:
         m = min(n.value, cap)
         return out[:m].view(np.int32).reshape(m, 4).copy()
 
+    def frame_cache_stats(self):
+        """(hits, misses, capacity) of the transparent per-frame cache behind MatchFrames (a miss = one extraction)."""
+        hits, miss, cap = C.c_uint64(0), C.c_uint64(0), C.c_int32(0)
+        self._check(self._L.msf_frame_cache_stats(self._h, C.byref(hits), C.byref(miss), C.byref(cap)))
+        return hits.value, miss.value, cap.value
+
     # --- batched forms -------------------------------------------------------------------------
     def match_batch(self, frames1, frames2, cap=4096):
         n = len(frames1)

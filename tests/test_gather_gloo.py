@@ -65,5 +65,6 @@ def test_gather_with_empty_rank():
 
 def test_shard_is_a_partition():
     parts = [shard_pairs(37, r, 4) for r in range(4)]
-    assert sorted(sum(parts, [])) == list(range(37))
-    assert all(p[0] == r for r, p in enumerate(parts))
+    assert sum(parts, []) == list(range(37))                      # contiguous blocks in rank order
+    assert [len(p) for p in parts] == [10, 10, 10, 7]
+    assert shard_pairs(3, 3, 4) == [] and shard_pairs(3, 0, 4) == [0]

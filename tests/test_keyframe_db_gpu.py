@@ -193,8 +193,11 @@ def test_count_kernel_edge_cases():
     fm.count_mappoint_matches_device(d_m, d_c, d_a, d_b, d_n)
     # pair 0: rows 0,1,2 hit; row 3 misses in b; rows 4,5 are outside the image
     assert d_n.cpu().tolist() == [3, 3, 0, 0]
-    with pytest.raises(Exception):
-        fm.set_mappoints(0, [W * H])
+    # keys outside the image are ignored, like KeyPointMap::SetMapPoint ignores such points (KeyPointMap.cc:38-39)
+    fm.set_mappoints(0, keys_a + [W * H, -5, 1 << 30])
+    d_n.fill_(-1)
+    fm.count_mappoint_matches_device(d_m, d_c, d_a, d_b, d_n)
+    assert d_n.cpu().tolist() == [3, 3, 0, 0]
     with pytest.raises(Exception):
         fm.set_mappoints(8, [0])
 

@@ -18,7 +18,8 @@ CONF_TOL = 1e-3   # north_star: "LoFTR match confidences within 1e-3"
 def _dm(thr=0.15, pairs=1):
     from mono_slam_framework_amd.matcher import DNNFeatureMatcher
     from mono_slam_framework_amd import _lib
-    return DNNFeatureMatcher(threshold=thr, max_batch_pairs=pairs, flags=_lib.MSF_FLAG_KEEP_DEBUG)
+    return DNNFeatureMatcher(threshold=thr, max_batch_pairs=pairs,
+                             flags=_lib.MSF_FLAG_KEEP_DEBUG | _lib.MSF_FLAG_NO_FRAME_CACHE)
 
 
 def _check_lists(got, conf_ref, thr):
@@ -175,3 +176,25 @@ def test_sparse_head_equals_dense_head(monkeypatch):
     sparse.SetThreshold(0.02)       # below the sparse path's validity: the handle switches to the dense head itself
     dense.SetThreshold(0.02)
     np.testing.assert_array_equal(sparse.MatchFrames(*pairs[6], cap=8192), dense.MatchFrames(*pairs[6], cap=8192))
+
+
+def test_model_file_may_be_an_onnx_file(tmp_path):
+    """DNNFeatureMatcher(model_file_path, ...) opens the model file its caller names
+    (/root/reference/src/dnnfeaturematcher.cpp:11-21).  The reference's file cannot travel to the GPU box, so an ONNX
+    file with the same topology is written from the blob's tensors (tests/onnx_writer.py): constructed from it, the
+    matcher gives the confidences and the match list it gives from the blob, bit for bit."""
+    from mono_slam_framework_amd import _lib
+    from mono_slam_framework_amd.matcher import DNNFeatureMatcher, MsfError
+    from tests import onnx_writer
+    p = str(tmp_path / "LoFTR_teacher.onnx")
+    onnx_writer.write_onnx(p, onnx_writer.read_blob(_lib.default_weights_path()))
+    a, b = G["img0_ii"], G["img1_ii"]
+    ref = _dm(0.15)
+    exp = ref.MatchFrames(a, b, cap=8192)
+    dm = DNNFeatureMatcher(p, threshold=0.15, flags=_lib.MSF_FLAG_KEEP_DEBUG | _lib.MSF_FLAG_NO_FRAME_CACHE)
+    np.testing.assert_array_equal(dm.MatchFrames(a, b, cap=8192), exp)
+    np.testing.assert_array_equal(dm.conf_matrix().view(np.uint32), ref.conf_matrix().view(np.uint32))
+    np.testing.assert_array_equal(exp, G["matches_ii_015"])
+    with pytest.raises(MsfError) as e:
+        DNNFeatureMatcher(str(tmp_path / "absent.onnx"), threshold=0.15)
+    assert e.value.code == _lib.MSF_ERR_IO

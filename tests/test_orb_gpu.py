@@ -13,8 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _matcher(w, h, thr=0.8, pairs=1, flags=0):
+    # stateless MatchFrames: the stage-level getters below read the scratch slots of the last call
+    # (the transparent frame cache has its own tests: tests/test_frame_cache_gpu.py)
+    from mono_slam_framework_amd import _lib
     from mono_slam_framework_amd.matcher import FeatureMatcher
-    return FeatureMatcher(thr, w, h, max_batch_pairs=pairs, flags=flags)
+    return FeatureMatcher(thr, w, h, max_batch_pairs=pairs, flags=flags | _lib.MSF_FLAG_NO_FRAME_CACHE)
 
 
 def _noise_image(w, h, seed):

@@ -14,7 +14,7 @@ from oracle import loftr as oracle_loftr                          # noqa: E402
 
 TOL = 1e-3
 thr = 0.15
-dm = DNNFeatureMatcher(None, thr, 640, 480, flags=4)   # MSF_FLAG_KEEP_DEBUG
+dm = DNNFeatureMatcher(None, thr, 640, 480, flags=4 | 16)   # MSF_FLAG_KEEP_DEBUG | MSF_FLAG_NO_FRAME_CACHE
 orc = oracle_loftr.DNNFeatureMatcherOracle(thr)
 worst = 0.0
 bad_lists = 0
