@@ -64,6 +64,7 @@ typedef enum msf_kind {
 #define MSF_FLAG_BLUR_TIE_HALF_UP 1u /* ORB 7x7 blur: (sum+32768)>>16 instead of round-half-even */
 #define MSF_FLAG_PROFILE 2u          /* record per-stage HIP events on the launch stream (msf_stage_times) */
 #define MSF_FLAG_KEEP_DEBUG 4u       /* LoFTR: keep pair 0's confidence matrix and coarse features for msf_debug_get */
+#define MSF_FLAG_LEVEL_SIZE_MUL_INV 32u /* ORB pyramid level size cvRound(W * (1.f / scale)) instead of cvRound(W / scale) */
 #define MSF_FLAG_NO_FRAME_CACHE 16u  /* msf_match_pair: extract both frames on every call (no transparent per-frame cache) */
 #define MSF_FLAG_FAST_DENSE 8u       /* ORB: score every pixel at fastThreshold (no output-sensitive first pass); same results */
 

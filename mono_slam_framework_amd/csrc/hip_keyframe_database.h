@@ -5,8 +5,9 @@
 // The reference calls MatchFrames(query, KF_i) once per stored keyframe (re-extracting both frames every time) and
 // counts on the host.  Here a keyframe is uploaded once in add() (msf_store_frame: image resident in HBM, ORB features
 // extracted once), its KeyPointMap occupancy is a device bitmap (msf_set_mappoints), and a query is one
-// msf_match_one_to_many call that returns two int32 per keyframe.  The selection logic after the counts is the
-// reference's, line for line, with the same size_t / float conversions.
+// msf_match_one_to_many call that returns two int32 per keyframe.  The selection rules applied to those counts are
+// stated at the two Detect* functions; tests/cpp/test_keyframe_db.cpp and tests/test_keyframe_db_gpu.py hold them
+// against the reference's behaviour (including its integer / f32 conversions).
 //
 // Two layers, like hip_feature_matcher.h:
 //  (1) msf::HipKeyFrameMatchDatabase<KF, Frame, Traits>: OpenCV-free; Traits says how to read a keyframe
@@ -72,70 +73,68 @@ class HipKeyFrameMatchDatabase {
     mFrames.clear();
   }
 
-  KeyFramePtr DetectLoopCandidate(KF& pKF, size_t minNumMPMatches) {   // KeyFrameDatabase.cc:23-53
-    KeyFramePtr loopCandidate;
-    if (!MatchAll(Traits::Image(pKF), &pKF)) return loopCandidate;
-    size_t maxNumMP = 0;
+  // Place recognition for loop closing (replaces KeyFrameMatchDatabase::DetectLoopCandidate, KeyFrameDatabase.cc:23-53).
+  // One batched query gives, per stored key frame, the match count and the number of matches that carry a map point at
+  // both ends.  A key frame can be the loop candidate when it matched at all, was not already handed out for this query
+  // (its LoopQuery stamp) and is not a covisibility neighbour of the query; among those the one sharing the most map
+  // points wins, provided it shares more than `min_shared`.  Earlier key frames win ties.
+  KeyFramePtr DetectLoopCandidate(KF& query, size_t min_shared) {
+    if (!MatchAll(Traits::Image(query), &query)) return KeyFramePtr();
+    const unsigned long qid = Traits::Id(query);
+    int best = -1;
+    size_t best_shared = min_shared;
     for (size_t i = 0; i < mFrames.size(); i++) {
-      const KeyFramePtr& pKFi = mFrames[i];
-      const size_t numMatches = num_[i];
-      if (numMatches != 0 && Traits::LoopQuery(*pKFi) != Traits::Id(pKF)) {
-        if (!Traits::IsConnected(pKF, pKFi)) {
-          const size_t numMP = (size_t)num_mp_[i];
-          if (numMP > minNumMPMatches && numMP > maxNumMP) {
-            loopCandidate = pKFi;
-            maxNumMP = numMP;
-          }
-        }
+      const bool usable = num_[i] != 0 && Traits::LoopQuery(*mFrames[i]) != qid && !Traits::IsConnected(query, mFrames[i]);
+      const size_t shared = (size_t)num_mp_[i];
+      if (usable && shared > best_shared) {
+        best = (int)i;
+        best_shared = shared;
       }
     }
-    return loopCandidate;
+    return best < 0 ? KeyFramePtr() : mFrames[best];
   }
 
-  std::vector<KeyFramePtr> DetectRelocalizationCandidates(Frame& pF) {   // KeyFrameDatabase.cc:55-117
-    std::vector<KeyFramePtr> vpRelocCandidates;
-    if (!MatchAll(Traits::Image(pF), nullptr)) return vpRelocCandidates;
-    std::vector<std::pair<KeyFramePtr, size_t>> frameMatchCounts;
-    frameMatchCounts.reserve(mFrames.size());
-    size_t maxNumMatches = 0;
+  // Relocalisation (replaces KeyFrameMatchDatabase::DetectRelocalizationCandidates, KeyFrameDatabase.cc:55-117), in
+  // three passes over the counts of one batched query:
+  //  1. every stored key frame is stamped with the query's id and its match count (the stamp is how pass 2 knows
+  //     which covisible key frames took part in THIS query);
+  //  2. each key frame with at least 80 % of the best count (the product is truncated to an integer, as the reference
+  //     does) forms a group with those of its ten best covisible key frames that carry the stamp: the group's weight is
+  //     the f32 sum of the members' counts (own count first, then covisibility order), its representative the member
+  //     with the largest count (the key frame itself on ties);
+  //  3. the representatives of groups heavier than 75 % of the heaviest group are returned, each once, in group order.
+  std::vector<KeyFramePtr> DetectRelocalizationCandidates(Frame& query) {
+    std::vector<KeyFramePtr> result;
+    if (!MatchAll(Traits::Image(query), nullptr)) return result;
+    const unsigned long qid = Traits::Id(query);
+    int top = 0;
     for (size_t i = 0; i < mFrames.size(); i++) {
-      const KeyFramePtr& pKFi = mFrames[i];
-      const int numMatches = num_[i];
-      Traits::RelocQuery(*pKFi) = Traits::Id(pF);
-      Traits::RelocScore(*pKFi) = static_cast<float>(numMatches);
-      frameMatchCounts.emplace_back(pKFi, numMatches);
-      if ((size_t)numMatches > maxNumMatches) maxNumMatches = numMatches;
+      Traits::RelocQuery(*mFrames[i]) = qid;
+      Traits::RelocScore(*mFrames[i]) = (float)num_[i];
+      top = std::max(top, (int)num_[i]);
     }
-    const auto minNumMatches = static_cast<size_t>(maxNumMatches * 0.8f);
+    const size_t cutoff = (size_t)((float)(size_t)top * 0.8f);
 
-    float bestAccNumMatches = 0;
-    std::vector<std::pair<KeyFramePtr, float>> accNumMatchFrames;
-    for (auto& kfItem : frameMatchCounts) {
-      if (kfItem.second >= minNumMatches) {
-        KeyFramePtr pKFi = kfItem.first;
-        float bestNumMatches = static_cast<float>(kfItem.second);
-        float accNumMatches = bestNumMatches;
-        KeyFramePtr pBestKF = pKFi;
-        for (auto& pKF2 : Traits::BestCovisibility(*pKFi, 10)) {
-          if (Traits::RelocQuery(*pKF2) != Traits::Id(pF)) continue;
-          accNumMatches += Traits::RelocScore(*pKF2);
-          if (Traits::RelocScore(*pKF2) > bestNumMatches) {
-            pBestKF = pKF2;
-            bestNumMatches = Traits::RelocScore(*pKF2);
-          }
-        }
-        accNumMatchFrames.emplace_back(pBestKF, accNumMatches);
-        if (accNumMatches > bestAccNumMatches) bestAccNumMatches = accNumMatches;
+    struct Group { KeyFramePtr rep; float weight; };
+    std::vector<Group> groups;
+    float heaviest = 0.f;
+    for (size_t i = 0; i < mFrames.size(); i++) {
+      if ((size_t)num_[i] < cutoff) continue;
+      Group g{mFrames[i], (float)num_[i]};
+      float rep_score = g.weight;
+      for (const KeyFramePtr& nb : Traits::BestCovisibility(*mFrames[i], 10)) {
+        if (Traits::RelocQuery(*nb) != qid) continue;      // did not take part in this query
+        const float s = Traits::RelocScore(*nb);
+        g.weight += s;
+        if (s > rep_score) { g.rep = nb; rep_score = s; }
       }
+      heaviest = std::max(heaviest, g.weight);
+      groups.push_back(g);
     }
-
-    const float minNumMatchesToRetain = 0.75f * bestAccNumMatches;
-    for (auto& kfItem : accNumMatchFrames) {
-      if (kfItem.second > minNumMatchesToRetain &&
-          std::find(vpRelocCandidates.begin(), vpRelocCandidates.end(), kfItem.first) == vpRelocCandidates.end())
-        vpRelocCandidates.push_back(kfItem.first);
-    }
-    return vpRelocCandidates;
+    const float keep_above = 0.75f * heaviest;
+    for (const Group& g : groups)
+      if (g.weight > keep_above && std::find(result.begin(), result.end(), g.rep) == result.end()) result.push_back(g.rep);
+    return result;
   }
 
   // per-keyframe counts of the last query, in mFrames order (diagnostics and tests)

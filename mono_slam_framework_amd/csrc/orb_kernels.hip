@@ -1582,7 +1582,8 @@ void OrbPipeline::destroy() {
     if (e_ != hipSuccess) return std::string(#expr) + ": " + hipGetErrorString(e_);       \
   } while (0)
 
-std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_half_up, bool profile, bool dense_fast) {
+std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_half_up, bool profile, bool dense_fast,
+                              bool level_size_mul_inv) {
   if (width < 64 || height < 64 || width > 8192 || height > 8192) return "arg: ORB image size must be in [64, 8192] x [64, 8192]";
   if (max_slots < 2) return "arg: ORB max_slots < 2";
   max_slots_ = max_slots;
@@ -1635,8 +1636,11 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     const float s = (float)pow(scale_factor, (double)l);
     const float inv = 1.0f / s;
     L.scale = s;
-    L.w = cv_round_f((float)width * inv);
-    L.h = cv_round_f((float)height * inv);
+    // ORB_Impl::detectAndCompute (OpenCV 3.x / 4.x): Size sz(cvRound(image.cols/scale), cvRound(image.rows/scale));
+    // MSF_FLAG_LEVEL_SIZE_MUL_INV selects the 2.4-era cvRound(cols * (1.f / scale)) instead (they differ for a few odd
+    // sizes, e.g. width 69 -> 57 vs 58 at level 1; never for 640 / 480 / 1280 / 720 / 1920 / 1080)
+    L.w = level_size_mul_inv ? cv_round_f((float)width * inv) : cv_round_f((float)width / s);
+    L.h = level_size_mul_inv ? cv_round_f((float)height * inv) : cv_round_f((float)height / s);
     L.pitch = (L.w + 15) & ~15;
     L.pix_off = pix;
     if (l > 0) pix += (long long)L.pitch * L.h;

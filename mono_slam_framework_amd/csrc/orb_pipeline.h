@@ -62,7 +62,8 @@ class OrbPipeline {
   OrbPipeline() = default;
   ~OrbPipeline();
   // returns empty string on success
-  std::string init(int width, int height, int max_slots, bool blur_half_up, bool profile, bool dense_fast = false);
+  std::string init(int width, int height, int max_slots, bool blur_half_up, bool profile, bool dense_fast = false,
+                   bool level_size_mul_inv = false);
   void destroy();
 
   // extract features of n frames into slots [src.slot0, src.slot0 + n)

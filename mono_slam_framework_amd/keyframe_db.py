@@ -105,55 +105,46 @@ class KeyFrameMatchDatabase:
         self.last_num_matches, self.last_num_mp = num, num_mp
         return num, num_mp
 
-    # --- KeyFrameDatabase.cc:23-53 -------------------------------------------------------------------------------
-    def DetectLoopCandidate(self, pKF, minNumMPMatches):
-        spConnectedKeyFrames = pKF.GetConnectedKeyFrames()
-        num, num_mp = self._match_all(pKF, True)
-        loopCandidate, maxNumMP = None, 0
-        for i, pKFi in enumerate(self.mFrames):
-            if num[i] != 0 and pKFi.mnLoopQuery != pKF.id():
-                if pKFi not in spConnectedKeyFrames:
-                    numMP = int(num_mp[i])
-                    if numMP > minNumMPMatches and numMP > maxNumMP:
-                        loopCandidate, maxNumMP = pKFi, numMP
-        return loopCandidate
+    # --- the two queries (replace KeyFrameMatchDatabase::DetectLoopCandidate / DetectRelocalizationCandidates,
+    # --- slam_pipeline/src/KeyFrameDatabase.cc:23-53, 55-117); rules as in csrc/hip_keyframe_database.h ---------------
+    def DetectLoopCandidate(self, query, min_shared):
+        """The stored key frame sharing the most map points with `query` (more than min_shared), among those that
+        matched at all, were not already handed out for this query and are not its covisibility neighbours."""
+        counts, shared = self._match_all(query, True)
+        neighbours = query.GetConnectedKeyFrames()
+        best, best_shared = None, min_shared
+        for kf, n, mp in zip(self.mFrames, counts, shared):
+            usable = n != 0 and kf.mnLoopQuery != query.id() and kf not in neighbours
+            if usable and int(mp) > best_shared:
+                best, best_shared = kf, int(mp)
+        return best
 
-    # --- KeyFrameDatabase.cc:55-117 ------------------------------------------------------------------------------
-    def DetectRelocalizationCandidates(self, pF):
-        num, _ = self._match_all(pF, False)
+    def DetectRelocalizationCandidates(self, query):
+        """Representatives of the covisibility groups whose summed match count exceeds 75 % of the heaviest group's."""
+        counts, _ = self._match_all(query, False)
         f32 = np.float32
-        frameMatchCounts = []
-        maxNumMatches = 0
-        for i, pKFi in enumerate(self.mFrames):
-            numMatches = int(num[i])
-            pKFi.mnRelocQuery = pF.id()
-            pKFi.mRelocScore = f32(numMatches)
-            frameMatchCounts.append((pKFi, numMatches))
-            if numMatches > maxNumMatches:
-                maxNumMatches = numMatches
-        minNumMatches = int(f32(maxNumMatches) * f32(0.8))            # static_cast<size_t>(size_t * 0.8f)
-
-        bestAccNumMatches = f32(0)
-        accNumMatchFrames = []
-        for pKFi, cnt in frameMatchCounts:
-            if cnt >= minNumMatches:
-                bestNumMatches = f32(cnt)
-                accNumMatches = bestNumMatches
-                pBestKF = pKFi
-                for pKF2 in pKFi.GetBestCovisibilityKeyFrames(10):
-                    if pKF2.mnRelocQuery != pF.id():
-                        continue
-                    accNumMatches = f32(accNumMatches + f32(pKF2.mRelocScore))
-                    if pKF2.mRelocScore > bestNumMatches:
-                        pBestKF = pKF2
-                        bestNumMatches = f32(pKF2.mRelocScore)
-                accNumMatchFrames.append((pBestKF, accNumMatches))
-                if accNumMatches > bestAccNumMatches:
-                    bestAccNumMatches = accNumMatches
-
-        minNumMatchesToRetain = f32(0.75) * bestAccNumMatches
-        vpRelocCandidates = []
-        for pKFi, acc in accNumMatchFrames:
-            if acc > minNumMatchesToRetain and not any(pKFi is k for k in vpRelocCandidates):
-                vpRelocCandidates.append(pKFi)
-        return vpRelocCandidates
+        qid = query.id()
+        for kf, n in zip(self.mFrames, counts):          # pass 1: stamp every key frame of this query with its count
+            kf.mnRelocQuery = qid
+            kf.mRelocScore = f32(int(n))
+        top = int(counts.max()) if len(counts) else 0
+        cutoff = int(f32(top) * f32(0.8))                 # the reference truncates the f32 product to an integer
+        groups = []                                       # pass 2: (representative, f32 weight) per strong key frame
+        for kf, n in zip(self.mFrames, counts):
+            if int(n) < cutoff:
+                continue
+            weight = rep_score = f32(int(n))
+            rep = kf
+            for nb in kf.GetBestCovisibilityKeyFrames(10):
+                if nb.mnRelocQuery != qid:                # did not take part in this query
+                    continue
+                weight = f32(weight + f32(nb.mRelocScore))
+                if nb.mRelocScore > rep_score:
+                    rep, rep_score = nb, f32(nb.mRelocScore)
+            groups.append((rep, weight))
+        keep_above = f32(0.75) * max([w for _, w in groups], default=f32(0))
+        result = []                                       # pass 3: each representative once, in group order
+        for rep, weight in groups:
+            if weight > keep_above and not any(rep is r for r in result):
+                result.append(rep)
+        return result

@@ -19,7 +19,8 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<f4"), ("angle", 
 
 class Opts(C.Structure):
     _fields_ = [("nfeatures", C.c_int32), ("nlevels", C.c_int32), ("fast_threshold", C.c_int32),
-                ("edge_threshold", C.c_int32), ("blur_tie_even", C.c_int32)]
+                ("edge_threshold", C.c_int32), ("blur_tie_even", C.c_int32),
+                ("level_size_mul_inv", C.c_int32)]
 
 
 def build(force=False):
@@ -79,9 +80,9 @@ class OrbOracle:
     """cv::ORB::create() defaults, as the reference constructs it (featurematcher.cpp:4)."""
 
     def __init__(self, width, height, nfeatures=500, nlevels=8, fast_threshold=20, edge_threshold=31,
-                 blur_tie_even=1):
+                 blur_tie_even=1, level_size_mul_inv=0):
         self.L = lib()
-        o = Opts(nfeatures, nlevels, fast_threshold, edge_threshold, blur_tie_even)
+        o = Opts(nfeatures, nlevels, fast_threshold, edge_threshold, blur_tie_even, level_size_mul_inv)
         self.nlevels = nlevels
         self.w, self.h = width, height
         self.ctx = self.L.orb_oracle_create(width, height, C.byref(o))

@@ -83,6 +83,7 @@ void orb_oracle_default_opts(orb_oracle_opts* o) {
   o->fast_threshold = 20;
   o->edge_threshold = 31;
   o->blur_tie_even = 1;
+  o->level_size_mul_inv = 0;
 }
 
 /* Deterministic sin/cos for t in [0, ~2*pi]: Cody-Waite reduction by pi/2 and
@@ -198,8 +199,13 @@ orb_oracle_ctx* orb_oracle_create(int width, int height, const orb_oracle_opts* 
     float s = (float)pow(scale_factor, (double)l);
     float inv = 1.0f / s;
     c->scale[l] = s;
-    c->lw[l] = cv_round_f((float)width * inv);
-    c->lh[l] = cv_round_f((float)height * inv);
+    if (c->o.level_size_mul_inv) {
+      c->lw[l] = cv_round_f((float)width * inv);
+      c->lh[l] = cv_round_f((float)height * inv);
+    } else {                                     /* Size sz(cvRound(image.cols/scale), cvRound(image.rows/scale)) */
+      c->lw[l] = cv_round_f((float)width / s);
+      c->lh[l] = cv_round_f((float)height / s);
+    }
   }
   /* computeKeyPoints: nfeaturesPerLevel */
   {

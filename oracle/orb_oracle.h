@@ -32,6 +32,10 @@ typedef struct orb_oracle_opts {
   int32_t edge_threshold;  /* 31 */
   int32_t blur_tie_even;   /* 1: column pass rounds ties to even (OpenCV SIMD f32 column
                               filter); 0: (sum + 32768) >> 16 (scalar FixedPtCastEx) */
+  int32_t level_size_mul_inv; /* 0: level size = cvRound(W / scale_l) (ORB_Impl::detectAndCompute of OpenCV 3.x / 4.x:
+                              `Size sz(cvRound(image.cols/scale), cvRound(image.rows/scale))`);
+                              1: cvRound(W * (1.f / scale_l)) (the 2.4-era computeImagePyramid).  The two differ for
+                              139 widths in [64, 4096] (69 is the smallest), for none of 640/480/1280/720/1920/1080 */
 } orb_oracle_opts;
 
 /* one keypoint, 32 bytes */
