@@ -823,7 +823,7 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
 // matters, so a sample first takes the cardinal test at kTauPre (5 byte loads; every pixel with score >= kTauPre passes
 // it) and only the survivors, compacted in LDS, get the exact score: the histogram is exact from kTauPre upwards.
 // tau = the largest multiple of 4 with enough sample hits at or above it, fastThreshold (dense) if there is none.
-constexpr int kTauPre = 40;
+constexpr int kTauPre = 40, kTauPreHigh = 64;
 constexpr int kTauListCap = 2048;     // prefilter survivors kept per (frame, level); the rest are dropped (fewer hits: a
                                       // lower, still valid, tau)
 __global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, const uint8_t* pyr, int force_tau,
@@ -834,7 +834,7 @@ __global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, c
   __shared__ uint32_t nlist;
   const int l = blockIdx.x, fi = blockIdx.y, slot = src.slot0 + fi, tid = threadIdx.x;
   const OrbLevelInfo L = g.lv[l];
-  int tv = kFastT;
+  int tv = kFastT, pre_used = kTauPre;
   if (force_tau > 0) {
     tv = force_tau;
   } else if (L.samp_rows > 0) {
@@ -844,42 +844,79 @@ __global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, c
     int pitch;
     const uint8_t* img = level_ptr(g, src, pyr, fi, l, &pitch);
     const int rw = L.w - 2 * kEdge, rh = L.h - 2 * kEdge;
-    // four sampled rows per iteration: their 20 byte loads are in flight together
+    // A sample site is a run of 4 adjacent pixels (one aligned dword): the cardinal test then works on 4 px at once
+    // from 5 dword loads (the SWAR form of fast_tile's prefilter at kTauPre), a quarter of the loads per pixel.
+    // Four sampled rows per iteration, so that their 20 loads are in flight together.
+    // The test runs at kTauPreHigh first; textures without enough strong corners (few survivors: the estimate would
+    // end below kTauPreHigh anyway) are sampled again at kTauPre.
+    const uint32_t factor_px = (uint32_t)(L.samp_sx * L.samp_sy);
+    uint32_t need_hits = ((uint32_t)kTauOversample * 2u * (uint32_t)L.quota + factor_px - 1u) / factor_px;
+    need_hits = need_hits < (uint32_t)kTauMinHits ? (uint32_t)kTauMinHits : need_hits;
+    int pre = kTauPreHigh;
+    for (int attempt = 0; attempt < 2; attempt++) {
+    const uint32_t lb = 0x01010101u * (uint32_t)(128 - pre / 2), lnd = 0x01010101u * (uint32_t)(255 - (254 - pre) / 2);
+    const int x_first = (kEdge + 3) & ~3;                                  // first dword fully inside [31, w - 31)
+    const int n_dw = (L.w - kEdge - x_first) >> 2;                         // dwords fully inside
     for (int j0 = 0; j0 < L.samp_rows; j0 += 4) {
       for (int k = tid; k < L.samp_cols; k += 256) {
-        int cv[4], nv[4], sv[4], ev[4], wv[4];
-        uint32_t pos[4];
+        uint32_t Cv[4], Lv[4], Rv[4], Uv[4], Dv[4], pos[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const int j = min(j0 + u, L.samp_rows - 1);
           const uint32_t hj = hash_u32((uint32_t)(l * 4099 + j) * 2654435761u + 12345u);
           int y = j * L.samp_sy + (int)(hj % (uint32_t)L.samp_sy);
           y = kEdge + (y < rh ? y : rh - 1);
-          int x = k * L.samp_sx + (int)((hj >> 16) % (uint32_t)L.samp_sx);
-          x = kEdge + (x < rw ? x : rw - 1);
+          int d = k * L.samp_sx + (int)((hj >> 16) % (uint32_t)L.samp_sx);   // dword index of the run
+          d = d < n_dw ? d : n_dw - 1;
+          const int x = x_first + 4 * d;
           const uint8_t* p = img + (long long)y * pitch + x;
-          cv[u] = p[0]; nv[u] = p[-3 * pitch]; sv[u] = p[3 * pitch]; ev[u] = p[3]; wv[u] = p[-3];
+          Cv[u] = *reinterpret_cast<const uint32_t*>(p);
+          Lv[u] = *reinterpret_cast<const uint32_t*>(p - 4);
+          Rv[u] = *reinterpret_cast<const uint32_t*>(p + 4);
+          Uv[u] = *reinterpret_cast<const uint32_t*>(p - 3 * pitch);
+          Dv[u] = *reinterpret_cast<const uint32_t*>(p + 3 * pitch);
           pos[u] = ((uint32_t)y << 16) | (uint32_t)x;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          const int hi = cv[u] + kTauPre, lo = cv[u] - kTauPre;
-          const bool pass = j0 + u < L.samp_rows &&
-                            (((nv[u] > hi || sv[u] > hi) && (ev[u] > hi || wv[u] > hi)) ||
-                             ((nv[u] < lo || sv[u] < lo) && (ev[u] < lo || wv[u] < lo)));
-          if (pass) {
-            const uint32_t idx = atomicAdd(&nlist, 1u);
-            if (idx < (uint32_t)kTauListCap) list[idx] = pos[u];
+          const uint32_t W3 = __builtin_amdgcn_alignbyte(Cv[u], Lv[u], 1), E3 = __builtin_amdgcn_alignbyte(Rv[u], Cv[u], 3);
+          const uint32_t nC = ~Cv[u];
+          const uint32_t l0 = __builtin_amdgcn_lerp(Dv[u], nC, 0), l4 = __builtin_amdgcn_lerp(E3, nC, 0);
+          const uint32_t l8 = __builtin_amdgcn_lerp(Uv[u], nC, 0), l12 = __builtin_amdgcn_lerp(W3, nC, 0);
+          const uint32_t cb = (__builtin_amdgcn_lerp(l0, lb, 0) | __builtin_amdgcn_lerp(l8, lb, 0)) &
+                              (__builtin_amdgcn_lerp(l4, lb, 0) | __builtin_amdgcn_lerp(l12, lb, 0));
+          const uint32_t cd = ~((__builtin_amdgcn_lerp(l0, lnd, 0) & __builtin_amdgcn_lerp(l8, lnd, 0)) |
+                                (__builtin_amdgcn_lerp(l4, lnd, 0) & __builtin_amdgcn_lerp(l12, lnd, 0)));
+          uint32_t m = (cb | cd) & 0x80808080u;
+          if (j0 + u >= L.samp_rows) m = 0u;
+          if (m) {
+            const uint32_t idx = atomicAdd(&nlist, (uint32_t)__popc(m));
+            uint32_t q = idx;
+#pragma unroll
+            for (int b4 = 0; b4 < 4; b4++)
+              if ((m >> (8 * b4 + 7)) & 1u) {
+                if (q < (uint32_t)kTauListCap) list[q] = pos[u] + (uint32_t)b4;
+                q++;
+              }
           }
         }
       }
     }
     __syncthreads();
+    // about one survivor of the cardinal test in four or five scores above the test's threshold
+    if (attempt == 1 || nlist >= 6u * need_hits) break;   // uniform
+    __syncthreads();
+    if (tid == 0) nlist = 0;
+    pre = kTauPre;
+    __syncthreads();
+    }
+    pre_used = pre;
+    __syncthreads();
     const uint32_t n = min(nlist, (uint32_t)kTauListCap);
     for (uint32_t i = tid; i < n; i += 256) {
       const uint32_t e = list[i];
       const int sc = fast_score_px(img + (long long)(e >> 16) * pitch + (e & 0xFFFFu), pitch);
-      if (sc >= kTauPre) atomicAdd(&hist[sc >> 2], 1u);
+      if (sc >= pre_used) atomicAdd(&hist[sc >> 2], 1u);
     }
     __syncthreads();
     if (tid < 64) {
@@ -893,7 +930,7 @@ __global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, c
       const uint32_t factor = (uint32_t)(L.samp_sx * L.samp_sy);
       uint32_t need = ((uint32_t)kTauOversample * 2u * (uint32_t)L.quota + factor - 1u) / factor;
       need = need < (uint32_t)kTauMinHits ? (uint32_t)kTauMinHits : need;
-      const unsigned long long ok = __ballot(c >= need && 4 * tid >= kTauPre);
+      const unsigned long long ok = __ballot(c >= need && 4 * tid >= pre_used);
       const int top = ok ? 63 - __builtin_clzll(ok) : 0;     // largest qualifying bin
       tv = ok ? 4 * top : kFastT;                            // too few strong corners: dense
     }
@@ -1024,19 +1061,27 @@ __global__ __launch_bounds__(256) void k_thr_harris(OrbGeometry g, FrameSrc src,
       if (i + b < n) atomicAdd(&hist[(w[b >> 2] >> (8 * (b & 3))) & 255u], 1u);
   }
   __syncthreads();
-  if (tid == 0) {
-    // KeyPointsFilter::retainBest(keypoints, 2 * featuresNum): keep all >= the (2N)-th largest score
+  if (tid < 64) {
+    // KeyPointsFilter::retainBest(keypoints, 2 * featuresNum): keep all >= the (2N)-th largest score = the largest
+    // score b with (number of candidates scoring >= b) >= 2N.  One wave: lane i owns bins 4i .. 4i+3.
     const uint32_t keep = 2u * (uint32_t)L.quota;
-    uint32_t thr = 0;
-    if (n > keep) {
-      thr = 256;  // keep == 0: drop all
-      uint32_t cum = 0;
-      for (int b = 255; b >= 0 && keep > 0; b--) {
-        cum += hist[b];
-        if (cum >= keep) { thr = b; break; }
-      }
+    const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+    uint32_t above = h0 + h1 + h2 + h3;              // -> candidates in the bins of lanes > tid
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_down(above, o);
+      if (tid + o < 64) above += up;
     }
-    thr_s = thr;
+    above -= h0 + h1 + h2 + h3;
+    const uint32_t c3 = above + h3, c2 = c3 + h2, c1 = c2 + h1, c0 = c1 + h0;   // candidates scoring >= 4i+3 .. 4i
+    const int mine = c3 >= keep ? 4 * tid + 3 : c2 >= keep ? 4 * tid + 2 : c1 >= keep ? 4 * tid + 1 : c0 >= keep ? 4 * tid : -1;
+    const unsigned long long ok = __ballot(mine >= 0);
+    uint32_t thr = 0;                                  // n <= 2N: keep everything
+    if (n > keep) {
+      thr = 256;                                       // keep == 0: drop all
+      if (keep > 0 && ok) thr = (uint32_t)__shfl(mine, 63 - __builtin_clzll(ok));
+    }
+    if (tid == 0) thr_s = thr;
   }
   __syncthreads();
   const uint32_t thr = thr_s;
@@ -1666,21 +1711,24 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     L.strip_base = strips;
     strips += L.strips_x * L.strips_y;
     if (L.tiles_x * L.tiles_y > g.max_level_tiles) g.max_level_tiles = L.tiles_x * L.tiles_y;
-    // sample lattice of k_fast_tau: about 4096 pixels of the kept region, rows sparser than columns (a sampled pixel
-    // touches 7 rows), column step odd so that block textures with power-of-two periods are not aliased
+    // sample lattice of k_fast_tau: about 4096 pixels of the kept region in runs of 4 (one dword), rows sparser than
+    // columns (a sampled pixel touches 7 rows); samp_sx counts dwords and is odd, so that block textures with
+    // power-of-two periods are not aliased
     L.samp_sx = L.samp_sy = 1;
     L.samp_rows = L.samp_cols = 0;
     if (L.tiles_x > 0) {
       const int rw = L.w - 2 * kEdge, rh = L.h - 2 * kEdge;
-      const double s2 = (double)rw * rh / 4096.0;
-      int sx = (int)(sqrt(s2 > 1.0 ? s2 : 1.0) / 2.0);
+      const int n_dw = (L.w - kEdge - ((kEdge + 3) & ~3)) >> 2;          // aligned dwords fully inside [31, w - 31)
+      const double s2 = (double)n_dw * rh / 1024.0;                      // (dword, row) sites per sampled run
+      int sx = (int)(sqrt(s2 > 1.0 ? s2 : 1.0) / 4.0);
       sx = (sx < 1 ? 1 : sx) | 1;
       int sy = (int)(s2 / sx + 0.5);
       sy = sy < 1 ? 1 : sy;
       L.samp_sx = sx;
       L.samp_sy = sy;
       L.samp_rows = (rh + sy - 1) / sy;
-      L.samp_cols = (rw + sx - 1) / sx;
+      L.samp_cols = n_dw > 0 ? (n_dw + sx - 1) / sx : 0;
+      if (L.samp_cols == 0) L.samp_rows = 0;
     }
     L.tab_off = tab;
     if (l > 0) tab += ((L.w + 3) & ~3) + ((L.h + 3) & ~3);
