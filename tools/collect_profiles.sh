@@ -5,11 +5,11 @@
 # Outputs land under gpurun_out/prof_<tag>/ ; tools/pmc_summary.py + tools/make_traffic_json.py digest them.
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
-ORB="--steps 5 --warmup 1 --no-cpu-baseline"
+ORB="--steps 5 --warmup 1 --no-cpu-baseline --no-secondary"
 LOF="--matcher loftr --steps 5 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/orb_stats -- python3 $R/bench.py $ORB > $OUT/orb_stats.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/loftr_stats -- python3 $R/bench.py $LOF > $OUT/loftr_stats.log 2>&1 || exit 1

@@ -12,7 +12,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STAGE = {"k_resize": "pyramid", "k_fast": "fast_nms", "k_thr_harris": "select_harris", "k_select": "select_harris",
+STAGE = {"k_resize": "pyramid", "k_fast": "fast_nms", "k_fast_tau": "fast_nms", "k_fast_stream": "fast_nms",
+         "k_fast_check": "fast_nms", "k_fast_redo": "fast_nms", "k_thr_harris": "select_harris", "k_select": "select_harris",
          "k_describe": "orient_describe", "k_match": "match", "k_conv": "backbone_convs", "k_tokens": "backbone_convs",
          "k_attn_kv": "transformer", "k_attn_update": "transformer", "k_scale_feats": "match_head",
          "k_sim_stats": "match_head", "k_conf_mask": "match_head", "k_decode": "match_head"}
@@ -28,7 +29,7 @@ def load(d, steps):
     return acc
 
 
-def main(tag="r01", steps=6):
+def main(tag="r02", steps=6):
     base = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     for which in ("orb", "loftr"):
         fetch, write = load(os.path.join(base, which + "_fetch"), steps), load(os.path.join(base, which + "_write"), steps)
@@ -44,6 +45,12 @@ def main(tag="r01", steps=6):
         out = {s: int((2 * v["fetch_kb_raw"] + v["write_kb"]) * 1024) for s, v in stages.items()}
         out["_raw"] = {s: {"FETCH_SIZE_KB": v["fetch_kb_raw"], "WRITE_SIZE_KB": v["write_kb"]} for s, v in stages.items()}
         out["_pairs_per_gpu"] = 1024 if which == "orb" else 256   # the bench defaults the passes were run with
+        out["_width"] = 1280 if which == "orb" else 640
+        try:
+            import subprocess
+            out["_commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+        except Exception:
+            out["_commit"] = None
         out["_note"] = "HBM bytes per bench step (launch of the stage): 2 * FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, " + tag
         json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_%s.json" % which), "w"), indent=1)
 
