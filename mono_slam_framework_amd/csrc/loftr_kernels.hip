@@ -273,6 +273,177 @@ __global__ __launch_bounds__(64 * kConvWaves) void k_conv(const void* __restrict
 #undef MSF_CONV_ISSUE
 }
 
+// ------------------------------------------------------------------ fused BasicBlock, 8 channels, stride 1 (layer1 @ 240 x 320)
+// y = relu(conv2(relu(conv1(x) + b1)) + b2 + x) in ONE kernel: the intermediate t never goes to HBM.  Unfused, a block of
+// this stage moves five activation-sized transfers (x read, t written, t read, x read as residual, y written) and runs at
+// its HBM time; fused it moves x (+ halo rows) and y.  Same MFMA form as k_conv with RP = 2 (two output rows in the 16
+// MFMA columns), the same k order in both convolutions: results are bit-identical to the two-kernel path.
+//  * a workgroup (4 waves) owns a band of R = 8 output rows and walks its x tiles of 64 columns left to right;
+//  * conv1 of tile k produces t rows oy0-1 .. oy0+8 (5 row pairs: wave w takes M tile w of every pair) into LDS, columns
+//    64k .. 64k+63, in segment k % 2 of the t rows;
+//  * conv2 of tile k-1 runs right after it: it needs t columns 64(k-1)-1 .. 64(k-1)+64, i.e. its own segment, the first
+//    column of the segment just written, and the last column of tile k-2, which was copied to a halo column before its
+//    segment was overwritten (two halo columns alternate) -- no t column is computed twice, only the two halo ROWS per
+//    band are (10 rows for 8);
+//  * zero padding of conv2 applies to t: t rows outside the image are stored as 0, columns -1 and W read a zero column.
+namespace blk8 {
+constexpr int R = 8, TW = 64;
+constexpr int XH = R + 4;                          // x rows oy0-2 .. oy0+9
+constexpr int XO = 3;                              // staged rows start at the float4-aligned column 64k - 4; window starts at 64k - 1
+constexpr int XW4 = (TW + 2 + XO + 3) / 4;         // 18 float4 per staged row
+constexpr int XPITCH = 4 * XW4;                    // 72
+constexpr int XPLANE = ((XH * XPITCH + 15) / 32) * 32 + 16;   // == 16 (mod 32): conflict-free fragment reads (see ConvCfg)
+constexpr int TROWS = R + 2;                       // t rows oy0-1 .. oy0+8
+constexpr int TPITCH = 132;                        // two 64-column segments, left-halo column (128), zero column (129), pad
+constexpr int TPLANE = ((TROWS * TPITCH + 15) / 32) * 32 + 16;
+constexpr int KSTEPS = 24;                         // (3 + 1) rows x 3 columns x 8 channels / 4
+constexpr int LDS_FLOATS = 8 * XPLANE + 8 * TPLANE;
+static_assert(XPLANE % 32 == 16 && TPLANE % 32 == 16, "plane strides");
+}  // namespace blk8
+
+__global__ __launch_bounds__(256) void k_block8(const float* __restrict__ in, const float* __restrict__ w1,
+                                                const float* __restrict__ b1, const float* __restrict__ w2,
+                                                const float* __restrict__ b2, float* __restrict__ out, int H, int W,
+                                                int n_bands) {
+  using namespace blk8;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xT = lds;
+  float* tT = lds + 8 * XPLANE;
+  const int nwg = gridDim.x, per = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7;
+  const int unit = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);     // XCD-contiguous (image, band) order
+  const int img = unit / n_bands;
+  const int oy0 = (unit - img * n_bands) * R;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int m = wave;                              // this wave's M tile (16 columns) of every row pair
+  const int rowsel = i >> 3, co = i & 7;           // MFMA column -> (row of the pair, output channel)
+  const float* inf = in + (long long)img * 8 * H * W;
+  float* outf = out + (long long)img * 8 * H * W;
+
+  // both convolutions' weight fragments stay in registers for the whole band (row-packed [k][16], 24 k steps each)
+  float bw1[KSTEPS], bw2[KSTEPS];
+#pragma unroll
+  for (int j = 0; j < KSTEPS; j++) {
+    bw1[j] = w1[(j * 4 + kq) * 16 + i];
+    bw2[j] = w2[(j * 4 + kq) * 16 + i];
+  }
+  const float bias1 = b1[co], bias2 = b2[co];
+  // halo column (left of tile 0 = padding) and the zero column
+  for (int idx = tid; idx < 8 * TROWS; idx += 256) {
+    const int c = idx / TROWS, r = idx - c * TROWS;
+    *reinterpret_cast<f32x4*>(&tT[c * TPLANE + r * TPITCH + 128]) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // x tile staging (as in k_conv): 16-byte global loads of tile k+1 are in flight while tile k is computed
+  constexpr int TOTAL = 8 * XH * XW4;
+  constexpr int NLD = (TOTAL + 255) / 256;
+  f32x4 pre[NLD];
+  int loff[NLD], x4v[NLD];
+  long long grow[NLD];
+#pragma unroll
+  for (int u = 0; u < NLD; u++) {
+    const int idx = tid + 256 * u;
+    const int c = idx / (XH * XW4);
+    const int rm = idx - c * (XH * XW4);
+    const int r = rm / XW4;
+    x4v[u] = rm - r * XW4;
+    loff[u] = idx < TOTAL ? c * XPLANE + r * XPITCH + 4 * x4v[u] : -1;
+    const int gy = oy0 - 2 + r;
+    grow[u] = (idx < TOTAL && gy >= 0 && gy < H) ? ((long long)c * H + gy) * W : -1;
+  }
+#define MSF_BLK_ISSUE(k_)                                                                       \
+  {                                                                                             \
+    const int gx0_ = TW * (k_) - 4;                                                             \
+    _Pragma("unroll") for (int u = 0; u < NLD; u++) {                                           \
+      const int gx = gx0_ + 4 * x4v[u];                                                         \
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                      \
+      if (grow[u] >= 0 && gx >= 0 && gx + 4 <= W) v = *reinterpret_cast<const f32x4*>(inf + grow[u] + gx); \
+      pre[u] = v;                                                                               \
+    }                                                                                           \
+  }
+  const int ntx = W / TW;
+  MSF_BLK_ISSUE(0)
+#pragma unroll
+  for (int u = 0; u < NLD; u++)
+    if (loff[u] >= 0) *reinterpret_cast<f32x4*>(&xT[loff[u]]) = pre[u];
+  // Iteration k: conv1 of tile k, barrier, then conv2 of tile k-1 together with the hand-over to iteration k+1 (x tile
+  // k+1 into LDS, last column of tile k-1 into the halo column conv2 of tile k will read), barrier: two barriers per
+  // tile.  The two halo columns (128, 130) alternate so the one conv2(k-1) reads is not the one being written.
+  for (int k = 0; k <= ntx; k++) {
+    __syncthreads();
+    if (k + 1 < ntx) MSF_BLK_ISSUE(k + 1)
+    if (k < ntx) {
+      // ---- conv1 of tile k: t rows 2u, 2u+1 (u = 0..4), columns 16m .. 16m+15 of the tile
+      f32x4 acc[5];
+#pragma unroll
+      for (int u = 0; u < 5; u++) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int step = 0; step < KSTEPS; step++) {
+        const int kk = (step * 4) / 8, c = (step * 4) % 8 + kq;
+        const int ky = kk / 3, kx = kk - ky * 3;
+        const float* ap = &xT[c * XPLANE + ky * XPITCH + kx + XO + 16 * m + i];
+#pragma unroll
+        for (int u = 0; u < 5; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[2 * u * XPITCH], bw1[step], acc[u], 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 5; u++) {
+        const int tr = 2 * u + rowsel, gy = oy0 - 1 + tr;
+        f32x4 v = acc[u] + f32x4{bias1, bias1, bias1, bias1};
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        if (gy < 0 || gy >= H) v = f32x4{0.f, 0.f, 0.f, 0.f};        // conv2 pads t with zeros
+        *reinterpret_cast<f32x4*>(&tT[co * TPLANE + tr * TPITCH + (k & 1) * 64 + 16 * m + 4 * kq]) = v;
+      }
+    }
+    __syncthreads();                       // t of tile k is complete; nobody reads the x tile any more
+    if (k + 1 < ntx) {
+#pragma unroll
+      for (int u = 0; u < NLD; u++)
+        if (loff[u] >= 0) *reinterpret_cast<f32x4*>(&xT[loff[u]]) = pre[u];
+    }
+    if (k >= 1 && k < ntx) {               // last column of tile k-1 -> the halo column conv2 of tile k reads (next iteration)
+      for (int idx = tid; idx < 8 * TROWS; idx += 256) {
+        const int c = idx / TROWS, r = idx - c * TROWS;
+        float* row = &tT[c * TPLANE + r * TPITCH];
+        row[128 + 2 * (k & 1)] = row[((k - 1) & 1) * 64 + 63];
+      }
+    }
+    if (k >= 1) {
+      // ---- conv2 of tile j = k-1: output rows oy0 + 2u, +1 (u = 0..3), columns 64j + 16m .. +15
+      const int j = k - 1;
+      f32x4 rv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++)     // residual = x, requested before the MFMA loop
+        rv[u] = *reinterpret_cast<const f32x4*>(inf + ((long long)co * H + (oy0 + 2 * u + rowsel)) * W + TW * j + 16 * m + 4 * kq);
+      int colterm[3];
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++) {
+        const int cr = 16 * m + i + kx - 1;                               // column inside the tile, -1 .. 64
+        colterm[kx] = cr < 0 ? 128 + 2 * (j & 1) : cr >= TW ? (k < ntx ? (k & 1) * 64 : 129) : (j & 1) * 64 + cr;
+      }
+      f32x4 acc[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int step = 0; step < KSTEPS; step++) {
+        const int kk = (step * 4) / 8, c = (step * 4) % 8 + kq;
+        const int ky = kk / 3, kx = kk - ky * 3;
+        const float* ap = &tT[c * TPLANE + ky * TPITCH + colterm[kx]];
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[2 * u * TPITCH], bw2[step], acc[u], 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int oy = oy0 + 2 * u + rowsel;
+        f32x4 v = acc[u] + f32x4{bias2, bias2, bias2, bias2};
+        v += rv[u];
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        *reinterpret_cast<f32x4*>(outf + ((long long)co * H + oy) * W + TW * j + 16 * m + 4 * kq) = v;
+      }
+    }
+  }
+#undef MSF_BLK_ISSUE
+}
+
 // ------------------------------------------------------------------ tokens: + positional encoding, n c h w -> n (h w) c
 __global__ __launch_bounds__(256) void k_tokens(const float* __restrict__ bb, const float* __restrict__ pe,
                                                 float* __restrict__ tok, int n_img) {
@@ -784,6 +955,7 @@ struct LoftrPipeline::Impl {
   SimCand* cand = nullptr;   // [max_pairs][kCandCap]
   uint32_t* cand_cnt = nullptr;
   bool dense_head = false;
+  bool fuse_blocks = true;   // MSF_LOFTR_UNFUSED=1: one kernel per convolution (tests: bit-identical results)
   bool keep_debug = false;   // MSF_FLAG_KEEP_DEBUG: pair 0's confidence matrix + features for the parity tests
   float* conf_dbg = nullptr; // [1200][1200]
   float* feat_dbg = nullptr; // [2][1200][32]
@@ -833,6 +1005,7 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
   P.n_slots = 2 * max_pairs + (extra_slots > 0 ? extra_slots : 0);
   {
     if (const char* d = getenv("MSF_LOFTR_DENSE_HEAD")) P.dense_head = atoi(d) != 0;   // tests: force the dense head
+    if (const char* d = getenv("MSF_LOFTR_UNFUSED")) P.fuse_blocks = atoi(d) == 0;
     const char* e = getenv("MSF_LOFTR_CHUNK");   // pairs per backbone pass (activation working set)
     const int want = e ? atoi(e) : 64;
     P.chunk = max_pairs < want ? max_pairs : (want > 0 ? want : 64);
@@ -1013,6 +1186,19 @@ void launch_conv(const ConvDesc& c, const void* in, long long in_img_stride, int
                      sc ? sc->d_b : nullptr, out_sc, n_bands);
 }
 
+// y = relu(conv_b(relu(conv_a(x))) + x) for an 8-channel, stride-1 BasicBlock at 240 x 320 (k_block8)
+void launch_block8(const ConvDesc& ca, const ConvDesc& cb, const float* in, float* out, int n_img, hipStream_t st) {
+  const size_t lds = (size_t)blk8::LDS_FLOATS * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_block8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const int n_bands = ca.hout / blk8::R;      // 240 / 8
+  hipLaunchKernelGGL(k_block8, dim3(n_bands * n_img), dim3(256), lds, st, in, ca.d_w2, ca.d_b, cb.d_w2, cb.d_b, out, ca.hout,
+                     ca.wout, n_bands);
+}
+
 }  // namespace
 
 namespace {
@@ -1087,10 +1273,15 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
   if (nA) launch_conv<1, 8, 7, 2, 64, true, false, true, 2>(c[0], srcA, frame_stride, row_stride, nullptr, a, nA, st);
   if (nB) launch_conv<1, 8, 7, 2, 64, true, false, true, 2>(c[0], srcB, frame_stride, row_stride, nullptr, a + (long long)nA * s8, nB, st);
   // layer1 @240x320, 8 ch
-  launch_conv<8, 8, 3, 1, 64, true, false, false, 2>(c[1], a, s8, 0, nullptr, b, ni, st);
-  launch_conv<8, 8, 3, 1, 64, true, true, false, 2>(c[2], b, s8, 0, a, cc, ni, st);
-  launch_conv<8, 8, 3, 1, 64, true, false, false, 2>(c[3], cc, s8, 0, nullptr, b, ni, st);
-  launch_conv<8, 8, 3, 1, 64, true, true, false, 2>(c[4], b, s8, 0, cc, a, ni, st);                 // a = 196
+  if (P.fuse_blocks) {   // each BasicBlock in one kernel: the intermediate activation stays in LDS
+    launch_block8(c[1], c[2], a, cc, ni, st);
+    launch_block8(c[3], c[4], cc, a, ni, st);                                                        // a = 196
+  } else {
+    launch_conv<8, 8, 3, 1, 64, true, false, false, 2>(c[1], a, s8, 0, nullptr, b, ni, st);
+    launch_conv<8, 8, 3, 1, 64, true, true, false, 2>(c[2], b, s8, 0, a, cc, ni, st);
+    launch_conv<8, 8, 3, 1, 64, true, false, false, 2>(c[3], cc, s8, 0, nullptr, b, ni, st);
+    launch_conv<8, 8, 3, 1, 64, true, true, false, 2>(c[4], b, s8, 0, cc, a, ni, st);                 // a = 196
+  }
   // layer2 @120x160, 16 ch
   const long long s16 = 16LL * 120 * 160;
   launch_conv<8, 16, 3, 2, 32, true, false, false, 1, true>(c[5], a, s8, 0, nullptr, b, ni, st, &c[7], d);   // + shortcut -> d

@@ -198,3 +198,35 @@ def test_model_file_may_be_an_onnx_file(tmp_path):
     with pytest.raises(MsfError) as e:
         DNNFeatureMatcher(str(tmp_path / "absent.onnx"), threshold=0.15)
     assert e.value.code == _lib.MSF_ERR_IO
+
+
+def test_fused_basic_blocks_equal_the_layer_by_layer_path():
+    """The two 8-channel BasicBlocks at 240x320 run as one kernel each (k_block8: the intermediate activation stays in
+    LDS).  Same f32 MFMA chains in the same k order: confidences and features are bit-identical to the path with one
+    kernel per convolution (MSF_LOFTR_UNFUSED=1, in a child process because the switch is read at msf_create)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from mono_slam_framework_amd import synth\n"
+        "from mono_slam_framework_amd.matcher import DNNFeatureMatcher\n"
+        "a, b = synth.synth_pair(41, 640, 480, mode=1, shift=(32, 16))\n"
+        "dm = DNNFeatureMatcher(threshold=0.15, flags=4 | 16)\n"
+        "m = dm.MatchFrames(a, b, cap=8192)\n"
+        "np.savez(sys.argv[1], m=m, conf=dm.conf_matrix(), feat=dm.coarse_features())\n"
+    ) % root
+    import tempfile
+    outs = []
+    for unfused in ("0", "1"):
+        f = tempfile.NamedTemporaryFile(suffix=".npz", delete=False).name
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, MSF_LOFTR_UNFUSED=unfused),
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(np.load(f))
+        os.unlink(f)
+    assert len(outs[0]["m"]) > 20
+    np.testing.assert_array_equal(outs[0]["m"], outs[1]["m"])
+    np.testing.assert_array_equal(outs[0]["feat"].view(np.uint32), outs[1]["feat"].view(np.uint32))
+    np.testing.assert_array_equal(outs[0]["conf"].view(np.uint32), outs[1]["conf"].view(np.uint32))
