@@ -458,7 +458,12 @@ constexpr int SR = 64;                   // output rows per strip
 constexpr int RK = 16;                   // ring rows (power of two)
 constexpr int SPX = 248;                 // output px per strip
 constexpr int kSX0 = 24;                 // x of lane 0's first px in strip 0: lane 1 then holds px 28..31
-constexpr int kSGCap = 320, kSPCap = 256, kSHCap = 128, kSOCap = 96;
+constexpr int kSGCap = 288, kSPCap = 256, kSHCap = 64, kSOCap = 48;   // 10 224 B of LDS per wave: 16 waves per CU
+constexpr uint32_t kSGFlush = 32;        // records that trigger a flush at the end of a four-step group (<= 4 x 64 more arrive)
+static_assert(kSGCap >= (int)kSGFlush + 256, "record list capacity");
+// x = sum b_i 2^(8i) with 2-bit b_i: (x * kFlagGather) >> 24 = b0 | b1 << 2 | b2 << 4 | b3 << 6.  The cross terms below
+// bit 24 sum to at most 3 * (2^18 + 2^12 + 2^6 + 2^20 + 2^14 + 2^22) < 2^24, so nothing carries into the result.
+constexpr uint32_t kFlagGather = (1u << 24) | (1u << 18) | (1u << 12) | (1u << 6);
 // A row put at step s overwrites rel row s - 13; pending records read pixel rows >= last_flush - 2 and pending NMS
 // score rows >= last_flush - 1: the flush interval (a multiple of the four-step group) must stay below 11 rows.
 constexpr int kFlushRows = 8;
@@ -467,9 +472,9 @@ static_assert(kFlushRows < RK - 5 && kFlushRows % 4 == 0, "ring too short for th
 struct StreamSmem {
   __attribute__((aligned(16))) uint8_t px[RK * 256];
   __attribute__((aligned(16))) uint8_t sc[RK * 256];
-  uint2 g[kSGCap];
-  uint32_t p[kSPCap];
-  uint32_t h[kSHCap];
+  uint32_t g[kSGCap];        // lane | rel row << 6 | (brighter, darker) flag pairs of the 4 px << 16
+  uint16_t p[kSPCap];        // pixel entries: byte in row | ring row << 8 | darker-type << 12
+  uint16_t h[kSHCap];        // scored corners: byte in row | ring row << 8 (the rel row follows from the ring row)
   uint32_t okey[kSOCap];
   uint8_t osc[kSOCap];
 };
@@ -603,25 +608,26 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
     for (uint32_t c0 = 0; c0 < nG; c0 += 32) {
       uint32_t e0 = 0, mb = 0, md = 0;
       if (lane < 32 && c0 + lane < nG) {
-        const uint2 rec = sm.g[c0 + lane];
-        // pixel entry: byte in row (8 bits) | ring row (4 bits) << 8 | dark << 12 | rel row << 16
-        e0 = ((rec.x & 63u) << 2) | ((((rec.x >> 8) + 3u) & (uint32_t)(RK - 1)) << 8) | ((rec.x >> 8) << 16);
-        mb = rec.y & 0x80808080u;
-        md = (rec.y << 1) & 0x80808080u;
+        const uint32_t rec = sm.g[c0 + lane];
+        const uint32_t rr = (rec >> 6) & 127u, fl = rec >> 16;   // flags: bit 2j+1 = px j brighter-type, bit 2j = darker-type
+        // pixel entry: byte in row (8 bits) | ring row (4 bits) << 8 | dark << 12
+        e0 = ((rec & 63u) << 2) | (((rr + 3u) & (uint32_t)(RK - 1)) << 8);
+        mb = ((fl & 2u) << 6) | ((fl & 8u) << 12) | ((fl & 32u) << 18) | ((fl & 128u) << 24);
+        md = ((fl & 1u) << 7) | ((fl & 4u) << 13) | ((fl & 16u) << 19) | ((fl & 64u) << 25);
       }
       const uint32_t mine = __popc(mb) + __popc(md);
       const uint32_t incl = wave_incl_scan(mine);
       const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
       uint32_t k = incl - mine;
-      if (mb & 0x80u) sm.p[k++] = e0;
-      if (mb & 0x8000u) sm.p[k++] = e0 + 1;
-      if (mb & 0x800000u) sm.p[k++] = e0 + 2;
-      if (mb & 0x80000000u) sm.p[k++] = e0 + 3;
+      if (mb & 0x80u) sm.p[k++] = (uint16_t)e0;
+      if (mb & 0x8000u) sm.p[k++] = (uint16_t)(e0 + 1);
+      if (mb & 0x800000u) sm.p[k++] = (uint16_t)(e0 + 2);
+      if (mb & 0x80000000u) sm.p[k++] = (uint16_t)(e0 + 3);
       e0 |= 0x1000u;
-      if (md & 0x80u) sm.p[k++] = e0;
-      if (md & 0x8000u) sm.p[k++] = e0 + 1;
-      if (md & 0x800000u) sm.p[k++] = e0 + 2;
-      if (md & 0x80000000u) sm.p[k++] = e0 + 3;
+      if (md & 0x80u) sm.p[k++] = (uint16_t)e0;
+      if (md & 0x8000u) sm.p[k++] = (uint16_t)(e0 + 1);
+      if (md & 0x800000u) sm.p[k++] = (uint16_t)(e0 + 2);
+      if (md & 0x80000000u) sm.p[k++] = (uint16_t)(e0 + 3);
       MSF_WAVE_SYNC();
       for (uint32_t i0 = 0; i0 < total; i0 += 64) {
         const uint32_t i = i0 + lane;
@@ -637,7 +643,7 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
           const uint32_t cnt = (uint32_t)__popcll(bal);
           if (overflow || nH + cnt > (uint32_t)kSHCap) overflow = true;
           else {
-            if (sv) sm.h[nH + mbcnt64(bal)] = pe & 0xFFFF0FFFu;
+            if (sv) sm.h[nH + mbcnt64(bal)] = (uint16_t)(pe & 0x0FFFu);
             nH += cnt;
           }
         }
@@ -654,8 +660,9 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
         uint32_t key = 0, c = 0;
         if (i < nH) {
           const uint32_t he = sm.h[i];
-          const int rr = (int)(he >> 16);
           const uint32_t xl = he & 255u, row = (he >> 8) & 15u;                 // byte inside the row = 4 * lane + j
+          // the list holds rel rows nms_lo .. s, fewer than RK of them: the ring row identifies the rel row
+          const int rr = nms_lo + (int)((row - (uint32_t)(nms_lo + 3)) & (uint32_t)(RK - 1));
           const uint8_t* qc = scb + (row << 8) + xl;
           const uint8_t* qu = scb + (((row + RK - 1) & (RK - 1)) << 8) + xl;
           const uint8_t* qd = scb + (((row + 1) & (RK - 1)) << 8) + xl;
@@ -708,7 +715,7 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
         if (bal) {
           const uint32_t cnt = (uint32_t)__popcll(bal);
           // a row holds at most 256 corners; the list keeps what fits and the next flush falls back to the dense NMS
-          if (hit && nH + mbcnt64(bal) < (uint32_t)kSHCap) sm.h[nH + mbcnt64(bal)] = (4u * lane + j) | (row << 8) | ((uint32_t)s << 16);
+          if (hit && nH + mbcnt64(bal) < (uint32_t)kSHCap) sm.h[nH + mbcnt64(bal)] = (uint16_t)((4u * lane + j) | (row << 8));
           nH += cnt;
         }
       }
@@ -756,7 +763,9 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
       const bool has_ = (cb_ | cd_) != 0u;                                                                             \
       const unsigned long long bal_ = __ballot(has_);                                                                  \
       if (bal_) {                                                                                                      \
-        if (has_) sm.g[nG + mbcnt64(bal_)] = make_uint2((uint32_t)lane | ((uint32_t)ss_ << 8), cb_ | (cd_ >> 1));      \
+        /* the 8 flag bits (bits 7 / 6 of each byte) gathered into one byte by a multiply (no carries: see kFlagGather) */ \
+        if (has_) sm.g[nG + mbcnt64(bal_)] = (uint32_t)lane | ((uint32_t)ss_ << 6) |                                   \
+                                             ((((((cb_ | (cd_ >> 1)) >> 6) & 0x03030303u) * kFlagGather) >> 24) << 16); \
         nG += (uint32_t)__popcll(bal_);                                                                                \
       }                                                                                                                \
     }                                                                                                                  \
@@ -767,8 +776,8 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
     STREAM_STEP(q2, s + 2);
     STREAM_STEP(q3, s + 3);
     const int sl = min(s + 3, r_last);
-    // flushes happen between groups of four steps: at most 64 + 4 x 64 records wait (kSGCap), at most 8 rows
-    if (nG > 64u || sl - last_flush >= kFlushRows || sl == r_last) {
+    // flushes happen between groups of four steps: at most kSGFlush + 4 x 64 records wait (kSGCap), at most 8 rows
+    if (nG > kSGFlush || sl - last_flush >= kFlushRows || sl == r_last) {
       MSF_WAVE_SYNC();
       flush(sl);
     }
@@ -828,11 +837,11 @@ constexpr int kTauListCap = 2048;     // prefilter survivors kept per (frame, le
                                       // lower, still valid, tau)
 __global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, const uint8_t* pyr, int force_tau,
                                                   uint32_t* tau, uint32_t* tau_first, uint32_t* redo_cnt,
-                                                  uint32_t* redo_list) {
+                                                  uint32_t* redo_list, int level0) {
   __shared__ uint32_t hist[kTauBins];
   __shared__ uint32_t list[kTauListCap];
   __shared__ uint32_t nlist;
-  const int l = blockIdx.x, fi = blockIdx.y, slot = src.slot0 + fi, tid = threadIdx.x;
+  const int l = level0 + blockIdx.x, fi = blockIdx.y, slot = src.slot0 + fi, tid = threadIdx.x;
   const OrbLevelInfo L = g.lv[l];
   int tv = kFastT, pre_used = kTauPre;
   if (force_tau > 0) {
@@ -1619,6 +1628,12 @@ void OrbPipeline::destroy() {
   d_s1_ = nullptr; d_kp_ = nullptr; d_desc_ = nullptr; d_kp_cnt_ = nullptr; d_status_ = nullptr;
   if (ev_ok_) for (auto& e : ev_) hipEventDestroy(e);
   ev_ok_ = false;
+  if (tau_stream_) {
+    hipStreamSynchronize(tau_stream_);
+    for (auto& e : tau_ev_) hipEventDestroy(e);
+    hipStreamDestroy(tau_stream_);
+    tau_stream_ = nullptr;
+  }
 }
 
 #define MSF_HIP_TRY(expr)                                                                 \
@@ -1794,6 +1809,10 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     for (auto& e : ev_) MSF_HIP_TRY(hipEventCreate(&e));
     ev_ok_ = true;
   }
+  if (!getenv("MSF_ORB_NO_SIDE_STREAM")) {
+    MSF_HIP_TRY(hipStreamCreateWithFlags(&tau_stream_, hipStreamNonBlocking));
+    for (auto& e : tau_ev_) MSF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
   return "";
 }
 
@@ -1807,6 +1826,17 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
   if ((e = hipMemsetAsync(d_status_ + src.slot0, 0, (size_t)n * 4, st))) return e;
   if ((e = hipMemsetAsync(d_redo_, 0, 4, st))) return e;
   if (ev_ok_) hipEventRecord(ev_[0], st);
+  // k_fast_tau is a light, latency-bound kernel (one workgroup per (frame, level), scattered loads): for a batch it
+  // runs level by level on a side stream underneath the pyramid kernels, each level as soon as it exists
+  uint32_t* tau = d_tau_;
+  uint32_t* tau_first = d_tau_ + (size_t)max_slots_ * kOrbLevels;
+  const bool side = tau_stream_ != nullptr && n >= 64 && g.total_tiles > 0;
+  if (side) {
+    hipEventRecord(tau_ev_[0], st);
+    hipStreamWaitEvent(tau_stream_, tau_ev_[0], 0);
+    hipLaunchKernelGGL(k_fast_tau, dim3(1, n), dim3(256), 0, tau_stream_, g, src, d_pyr_, force_tau_, tau, tau_first, d_redo_,
+                       d_redo_ + 1, 0);
+  }
   for (int l = 1; l < g.nlevels; l++) {
     const OrbLevelInfo& L = g.lv[l];
     // band height: 8 output rows x 256 threads measured best (rth 4: 3.26 ms, 8: 2.71, 12: 2.77, 16: 2.74 per 2048
@@ -1822,13 +1852,22 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
     const uint32_t magic_groups = groups > 1 ? (uint32_t)(0x100000000ull / (uint32_t)groups) + 1u : 0u;
     hipLaunchKernelGGL(k_resize, dim3((L.h + rth - 1) / rth, n), dim3(threads), (size_t)lds_rows * sw16 + 8 * kResizeMaxRows,
                        st, g, src, d_pyr_, d_tab_, l, rth, lds_rows, magic_n16, magic_groups);
+    if (side) {
+      hipEventRecord(tau_ev_[l], st);
+      hipStreamWaitEvent(tau_stream_, tau_ev_[l], 0);
+      hipLaunchKernelGGL(k_fast_tau, dim3(1, n), dim3(256), 0, tau_stream_, g, src, d_pyr_, force_tau_, tau, tau_first,
+                         d_redo_, d_redo_ + 1, l);
+    }
   }
   if (ev_ok_) hipEventRecord(ev_[1], st);
   if (g.total_tiles > 0) {
-    uint32_t* tau = d_tau_;
-    uint32_t* tau_first = d_tau_ + (size_t)max_slots_ * kOrbLevels;
-    hipLaunchKernelGGL(k_fast_tau, dim3(g.nlevels, n), dim3(256), 0, st, g, src, d_pyr_, force_tau_, tau, tau_first, d_redo_,
-                       d_redo_ + 1);
+    if (side) {
+      hipEventRecord(tau_ev_[kOrbLevels], tau_stream_);
+      hipStreamWaitEvent(st, tau_ev_[kOrbLevels], 0);
+    } else {
+      hipLaunchKernelGGL(k_fast_tau, dim3(g.nlevels, n), dim3(256), 0, st, g, src, d_pyr_, force_tau_, tau, tau_first, d_redo_,
+                         d_redo_ + 1, 0);
+    }
     if (force_tau_ == kFastT) {   // MSF_FLAG_FAST_DENSE: the plain detector over every tile, nothing to verify
       hipLaunchKernelGGL(k_fast, dim3((unsigned)g.total_tiles * (unsigned)n), dim3(kFastThreads), 0, st, g, src, d_pyr_,
                          d_cand_cnt_, d_cand_, d_cand_sc_);

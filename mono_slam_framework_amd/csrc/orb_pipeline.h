@@ -101,6 +101,8 @@ class OrbPipeline {
   hipEvent_t ev_[kOrbStages + 2] = {};
   bool ev_ok_ = false, ev_recorded_ = false, ev_extract_pending_ = false, ev_match_only_ = false;
   FrameSrc last_src_{};
+  hipStream_t tau_stream_ = nullptr;            // k_fast_tau of a batch runs here, underneath the pyramid kernels
+  hipEvent_t tau_ev_[kOrbLevels + 1] = {};      // level l exists (fork points), all thresholds written (join)
 };
 
 }  // namespace msf
