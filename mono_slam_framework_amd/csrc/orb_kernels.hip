@@ -585,18 +585,25 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
     nO = 0;
   };
 
-  // append (keep ? one output : nothing) of every lane, in lane order
+  // append (keep ? one output : nothing) of every lane, in lane order; the two half-waves one after the other, so
+  // that a call adds at most 32 entries and the buffer (kSOCap >= 32) can always take them after a flush
+  static_assert(kSOCap >= 32, "output buffer smaller than one half-wave");
   auto emit = [&](bool keep, uint32_t key, uint32_t score) {
-    const unsigned long long bal = __ballot(keep);
-    if (bal == 0ull) return;
-    const uint32_t cnt = (uint32_t)__popcll(bal);
-    if (nO + cnt > (uint32_t)kSOCap) flush_out();
-    if (keep) {
-      const uint32_t k = nO + mbcnt64(bal);
-      sm.okey[k] = key;
-      sm.osc[k] = (uint8_t)score;
+    if (__ballot(keep) == 0ull) return;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const bool kh = keep && (lane >> 5) == half;
+      const unsigned long long bal = __ballot(kh);
+      if (bal == 0ull) continue;
+      const uint32_t cnt = (uint32_t)__popcll(bal);
+      if (nO + cnt > (uint32_t)kSOCap) flush_out();
+      if (kh) {
+        const uint32_t k = nO + mbcnt64(bal);
+        sm.okey[k] = key;
+        sm.osc[k] = (uint8_t)score;
+      }
+      nO += cnt;
     }
-    nO += cnt;
   };
 
   // scores everything recorded so far (rel rows <= s), then NMS of rel rows [nms_lo, s - 1]

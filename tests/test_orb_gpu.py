@@ -158,6 +158,43 @@ def test_level_size_formula_switch():
         np.testing.assert_array_equal(s0, s1)
 
 
+def test_streaming_fast_in_the_dense_regime():
+    """MSF_ORB_FAST_TAU=22 runs the streaming first pass just above fastThreshold on every level: nearly every pixel
+    that is a corner is recorded, so its fixed-size lists overflow all the time (forced flushes, the dense NMS path,
+    output-buffer flushes in mid-row, hit lists rebuilt from crowded rows) -- on textured, noisy and adversarial frames
+    the lists must still be the oracle's."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from mono_slam_framework_amd import synth\n"
+        "from mono_slam_framework_amd.matcher import FeatureMatcher\n"
+        "from oracle import orb\n"
+        "rng = np.random.default_rng(9)\n"
+        "y, x = np.mgrid[0:480, 0:640]\n"
+        "imgs = [synth.synth_pair(71, 640, 480, mode=0)[0], synth.synth_pair(72, 640, 480, mode=2, noise=0)[0],\n"
+        "        rng.integers(0, 256, size=(480, 640), dtype=np.uint8),\n"
+        "        (((x // 2) + (y // 2)) %% 2 * 200 + 20).astype(np.uint8),\n"
+        "        ((rng.random((480, 640)) < 0.08).astype(np.uint8) * 220 + 10)]\n"
+        "fm = FeatureMatcher(0.8, 640, 480, flags=16)\n"
+        "orc = orb.FeatureMatcherOracle(0.8)\n"
+        "for i, a in enumerate(imgs):\n"
+        "    b = np.roll(a, (3, 5), (0, 1))\n"
+        "    try:\n"
+        "        got = fm.MatchFrames(a, b)\n"
+        "    except Exception as e:\n"
+        "        assert getattr(e, 'code', 0) == -4, e    # a candidate list overflowed: loud, never wrong\n"
+        "        continue\n"
+        "    assert (fm.fast_tau(0)[:, 1] == 22).all()\n"
+        "    assert np.array_equal(got, orc.MatchFrames(a, b)), i\n"
+        "    k, d = orb.OrbOracle(640, 480).extract(a)\n"
+        "    assert len(fm.keypoints(0)) == len(k) and np.array_equal(fm.descriptors(0), d), i\n"
+    ) % ROOT
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MSF_ORB_FAST_TAU="22"), capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_threshold_and_blur_mode():
     a, b = synth.synth_pair(11, 640, 480)
     from mono_slam_framework_amd import _lib
