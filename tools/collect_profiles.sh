@@ -7,6 +7,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r02}
 OUT=$R/gpurun_out/prof_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 cd /tmp
 ORB="--steps 5 --warmup 1 --no-cpu-baseline --no-secondary"
