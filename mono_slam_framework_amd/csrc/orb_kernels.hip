@@ -1054,7 +1054,11 @@ __global__ __launch_bounds__(256) void k_thr_harris(OrbGeometry g, FrameSrc src,
                                                     uint32_t* s1_cnt, uint4* s1, uint32_t* status) {
   __shared__ uint32_t hist[256];
   __shared__ uint32_t thr_s, lcount;
+  // Launched with 256 threads when the candidate lists are the dense ones (tens of thousands per level) and with one
+  // wave when they come from the output-sensitive FAST pass (about a thousand): the stage is then a chain of short,
+  // latency-bound phases, and four times as many (frame, level)s in flight beat four waves idling at the barriers.
   const int l = blockIdx.x, fi = blockIdx.y, slot = src.slot0 + fi, tid = threadIdx.x;
+  const uint32_t nt = blockDim.x;
   if (l >= g.nlevels) return;
   const OrbLevelInfo L = g.lv[l];
   uint32_t n = cand_cnt[slot * kOrbLevels + l];
@@ -1065,11 +1069,11 @@ __global__ __launch_bounds__(256) void k_thr_harris(OrbGeometry g, FrameSrc src,
   const uint32_t* keys = cand_key + (long long)slot * g.cand_total + L.cand_off;
   const uint8_t* scs = cand_sc + (long long)slot * g.cand_total + L.cand_off;   // 16-byte aligned (cand_off % 16 == 0)
   uint4* out = s1 + (long long)slot * g.s1_total + L.s1_off;
-  hist[tid] = 0;
+  for (uint32_t b = tid; b < 256u; b += nt) hist[b] = 0;
   if (tid == 0) lcount = 0;
   __syncthreads();
   // 16 scores per lane and load; bytes past n inside the last group are stale and masked by index
-  for (uint32_t i = 16u * tid; i < n; i += 16u * 256u) {
+  for (uint32_t i = 16u * tid; i < n; i += 16u * nt) {
     const uint4 v = *reinterpret_cast<const uint4*>(scs + i);
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -1105,7 +1109,7 @@ __global__ __launch_bounds__(256) void k_thr_harris(OrbGeometry g, FrameSrc src,
   const uint8_t* img = level_ptr(g, src, pyr, fi, l, &pitch);
   // pass 1: compact the kept candidates (score >= thr) into the stage-1 list, response pending.  Kept candidates are
   // a few hundred out of tens of thousands: most waves see none and move on.
-  for (uint32_t i0 = 0; i0 < n; i0 += 16u * 256u) {
+  for (uint32_t i0 = 0; i0 < n; i0 += 16u * nt) {
     const uint32_t i = i0 + 16u * tid;
     uint32_t mask = 0;
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -1129,7 +1133,7 @@ __global__ __launch_bounds__(256) void k_thr_harris(OrbGeometry g, FrameSrc src,
   __syncthreads();
   // pass 2: Harris response on dense lanes
   const uint32_t kept = min(lcount, (uint32_t)kS1Cap);
-  for (uint32_t i = tid; i < kept; i += 256) {
+  for (uint32_t i = tid; i < kept; i += nt) {
     const uint32_t key = out[i].x;
     const float r = harris_at(img, pitch, key & 0xFFFF, key >> 16);
     out[i].y = __float_as_uint(r);
@@ -1892,8 +1896,8 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
     }
   }
   if (ev_ok_) hipEventRecord(ev_[2], st);
-  hipLaunchKernelGGL(k_thr_harris, dim3(g.nlevels, n), dim3(256), 0, st, g, src, d_pyr_, d_cand_cnt_, d_cand_, d_cand_sc_,
-                     d_s1_cnt_, d_s1_, d_status_);
+  hipLaunchKernelGGL(k_thr_harris, dim3(g.nlevels, n), dim3(force_tau_ == kFastT ? 256 : 64), 0, st, g, src, d_pyr_,
+                     d_cand_cnt_, d_cand_, d_cand_sc_, d_s1_cnt_, d_s1_, d_status_);
   hipLaunchKernelGGL(k_select, dim3(n), dim3(256), 0, st, g, src.slot0, d_s1_cnt_, d_s1_, d_kp_, d_kp_cnt_,
                      d_status_);
   if (ev_ok_) hipEventRecord(ev_[3], st);
