@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MSF_ABI_VERSION 1
+#define MSF_ABI_VERSION 2 /* 2: msf_weights_info, msf_convert_weights, msf_frame_cache_stats, flags FAST_DENSE / NO_FRAME_CACHE / LEVEL_SIZE_MUL_INV */
 
 typedef struct msf_handle msf_handle;
 
