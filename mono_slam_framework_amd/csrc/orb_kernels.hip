@@ -741,47 +741,59 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
     for (int k = 0; k < 6; k++) PUT_ROW(k, v[k]);
   }
   uint32_t q0 = LOAD_ROW(y0 + 3), q1 = LOAD_ROW(y0 + 4), q2 = LOAD_ROW(y0 + 5), q3 = LOAD_ROW(y0 + 6);
-  // One step = rel row s_: its row + 3 leaves the queue for the ring (and the queue slot is refilled four rows ahead),
-  // then the cardinal prefilter of the row (ring indices s_, s_ + 3, s_ + 6; see fast_tile for the SWAR form).
-  // Four steps are written out so that each queue register is named statically: a rotating queue would make every
-  // step wait for the load issued in the step before.
-#define STREAM_STEP(q_, s_)                                                                                            \
+  // One group = four rel rows s .. s+3, in three straight-line parts so that the four rows' dependent chains overlap
+  // (a wave has 4 x the instruction-level parallelism of one row at a time; the kernel is latency-bound):
+  //  1. the four queued rows (row + 3 of each step) go to the ring and their queue slots are refilled four rows ahead
+  //     -- each queue register is named statically: a rotating queue would make every step wait for the newest load;
+  //  2. the cardinal prefilters of the four rows (ring indices s_, s_ + 3, s_ + 6; see fast_tile for the SWAR form):
+  //     the row three below comes from the register just stored, the others from the ring;
+  //  3. the four record appends.
+#define STREAM_PRE(U_, C_, D_, s_, cb_, cd_)                                                                           \
   do {                                                                                                                 \
-    const int ss_ = (s_);                                                                                              \
-    const uint32_t D_ = (q_);                                                                                          \
-    PUT_ROW(ss_ + 6, D_);                                                                                              \
-    (q_) = LOAD_ROW(y0 + ss_ + 7);                                                                                     \
-    if (ss_ <= r_last) {                                                                                \
-      const uint32_t U_ = pxw[((ss_) & (RK - 1)) * 64 + lane];                                                         \
-      const uint32_t C_ = pxw[((ss_ + 3) & (RK - 1)) * 64 + lane];                                                     \
-      const uint32_t Lf_ = __builtin_amdgcn_update_dpp(0u, C_, 0x138, 0xf, 0xf, true); /* wave_shr:1: lane i <- i-1 */ \
-      const uint32_t Rt_ = __builtin_amdgcn_update_dpp(0u, C_, 0x130, 0xf, 0xf, true); /* wave_shl:1: lane i <- i+1 */ \
-      const uint32_t W3_ = __builtin_amdgcn_alignbyte(C_, Lf_, 1);                                                     \
-      const uint32_t E3_ = __builtin_amdgcn_alignbyte(Rt_, C_, 3);                                                     \
-      const uint32_t nC_ = ~C_;                                                                                        \
-      const uint32_t l0_ = __builtin_amdgcn_lerp(D_, nC_, 0), l4_ = __builtin_amdgcn_lerp(E3_, nC_, 0);                \
-      const uint32_t l8_ = __builtin_amdgcn_lerp(U_, nC_, 0), l12_ = __builtin_amdgcn_lerp(W3_, nC_, 0);               \
-      const uint32_t b0_ = __builtin_amdgcn_lerp(l0_, lerp_bright, 0), b4_ = __builtin_amdgcn_lerp(l4_, lerp_bright, 0);   \
-      const uint32_t b8_ = __builtin_amdgcn_lerp(l8_, lerp_bright, 0), b12_ = __builtin_amdgcn_lerp(l12_, lerp_bright, 0); \
-      const uint32_t n0_ = __builtin_amdgcn_lerp(l0_, lerp_not_dark, 0), n4_ = __builtin_amdgcn_lerp(l4_, lerp_not_dark, 0);   \
-      const uint32_t n8_ = __builtin_amdgcn_lerp(l8_, lerp_not_dark, 0), n12_ = __builtin_amdgcn_lerp(l12_, lerp_not_dark, 0); \
-      const uint32_t cb_ = ((b0_ | b8_) & (b4_ | b12_)) & vm;                                                          \
-      const uint32_t cd_ = ~((n0_ & n8_) | (n4_ & n12_)) & vm;                                                         \
-      const bool has_ = (cb_ | cd_) != 0u;                                                                             \
-      const unsigned long long bal_ = __ballot(has_);                                                                  \
-      if (bal_) {                                                                                                      \
-        /* the 8 flag bits (bits 7 / 6 of each byte) gathered into one byte by a multiply (no carries: see kFlagGather) */ \
-        if (has_) sm.g[nG + mbcnt64(bal_)] = (uint32_t)lane | ((uint32_t)ss_ << 6) |                                   \
-                                             ((((((cb_ | (cd_ >> 1)) >> 6) & 0x03030303u) * kFlagGather) >> 24) << 16); \
-        nG += (uint32_t)__popcll(bal_);                                                                                \
-      }                                                                                                                \
+    const uint32_t Lf_ = __builtin_amdgcn_update_dpp(0u, C_, 0x138, 0xf, 0xf, true); /* wave_shr:1: lane i <- i-1 */   \
+    const uint32_t Rt_ = __builtin_amdgcn_update_dpp(0u, C_, 0x130, 0xf, 0xf, true); /* wave_shl:1: lane i <- i+1 */   \
+    const uint32_t W3_ = __builtin_amdgcn_alignbyte(C_, Lf_, 1);                                                       \
+    const uint32_t E3_ = __builtin_amdgcn_alignbyte(Rt_, C_, 3);                                                       \
+    const uint32_t nC_ = ~(C_);                                                                                        \
+    const uint32_t l0_ = __builtin_amdgcn_lerp(D_, nC_, 0), l4_ = __builtin_amdgcn_lerp(E3_, nC_, 0);                  \
+    const uint32_t l8_ = __builtin_amdgcn_lerp(U_, nC_, 0), l12_ = __builtin_amdgcn_lerp(W3_, nC_, 0);                 \
+    const uint32_t b0_ = __builtin_amdgcn_lerp(l0_, lerp_bright, 0), b4_ = __builtin_amdgcn_lerp(l4_, lerp_bright, 0);     \
+    const uint32_t b8_ = __builtin_amdgcn_lerp(l8_, lerp_bright, 0), b12_ = __builtin_amdgcn_lerp(l12_, lerp_bright, 0);   \
+    const uint32_t n0_ = __builtin_amdgcn_lerp(l0_, lerp_not_dark, 0), n4_ = __builtin_amdgcn_lerp(l4_, lerp_not_dark, 0); \
+    const uint32_t n8_ = __builtin_amdgcn_lerp(l8_, lerp_not_dark, 0), n12_ = __builtin_amdgcn_lerp(l12_, lerp_not_dark, 0); \
+    const uint32_t vmr_ = (s_) <= r_last ? vm : 0u;                    /* rows past the strip's last scored row */      \
+    cb_ = ((b0_ | b8_) & (b4_ | b12_)) & vmr_;                                                                         \
+    cd_ = ~((n0_ & n8_) | (n4_ & n12_)) & vmr_;                                                                        \
+  } while (0)
+#define STREAM_APPEND(s_, cb_, cd_)                                                                                    \
+  do {                                                                                                                 \
+    const bool has_ = ((cb_) | (cd_)) != 0u;                                                                           \
+    const unsigned long long bal_ = __ballot(has_);                                                                    \
+    if (bal_) {                                                                                                        \
+      /* the 8 flag bits (bits 7 / 6 of each byte) gathered into one byte by a multiply (no carries: see kFlagGather) */ \
+      if (has_) sm.g[nG + mbcnt64(bal_)] = (uint32_t)lane | ((uint32_t)(s_) << 6) |                                    \
+                                           (((((((cb_) | ((cd_) >> 1)) >> 6) & 0x03030303u) * kFlagGather) >> 24) << 16); \
+      nG += (uint32_t)__popcll(bal_);                                                                                  \
     }                                                                                                                  \
   } while (0)
   for (int s = 0; s <= r_last; s += 4) {
-    STREAM_STEP(q0, s);
-    STREAM_STEP(q1, s + 1);
-    STREAM_STEP(q2, s + 2);
-    STREAM_STEP(q3, s + 3);
+    const uint32_t d0 = q0, d1 = q1, d2 = q2, d3 = q3;
+    PUT_ROW(s + 6, d0); q0 = LOAD_ROW(y0 + s + 7);
+    PUT_ROW(s + 7, d1); q1 = LOAD_ROW(y0 + s + 8);
+    PUT_ROW(s + 8, d2); q2 = LOAD_ROW(y0 + s + 9);
+    PUT_ROW(s + 9, d3); q3 = LOAD_ROW(y0 + s + 10);
+    const uint32_t u0 = pxw[((s) & (RK - 1)) * 64 + lane], u1 = pxw[((s + 1) & (RK - 1)) * 64 + lane];
+    const uint32_t u2 = pxw[((s + 2) & (RK - 1)) * 64 + lane], u3 = pxw[((s + 3) & (RK - 1)) * 64 + lane];   // = c0
+    const uint32_t c1 = pxw[((s + 4) & (RK - 1)) * 64 + lane], c2 = pxw[((s + 5) & (RK - 1)) * 64 + lane];
+    uint32_t cb0, cd0, cb1, cd1, cb2, cd2, cb3, cd3;
+    STREAM_PRE(u0, u3, d0, s, cb0, cd0);
+    STREAM_PRE(u1, c1, d1, s + 1, cb1, cd1);
+    STREAM_PRE(u2, c2, d2, s + 2, cb2, cd2);
+    STREAM_PRE(u3, d0, d3, s + 3, cb3, cd3);       // the centre row of step s + 3 is the row stored first in this group
+    STREAM_APPEND(s, cb0, cd0);
+    STREAM_APPEND(s + 1, cb1, cd1);
+    STREAM_APPEND(s + 2, cb2, cd2);
+    STREAM_APPEND(s + 3, cb3, cd3);
     const int sl = min(s + 3, r_last);
     // flushes happen between groups of four steps: at most kSGFlush + 4 x 64 records wait (kSGCap), at most 8 rows
     if (nG > kSGFlush || sl - last_flush >= kFlushRows || sl == r_last) {
@@ -789,7 +801,8 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
       flush(sl);
     }
   }
-#undef STREAM_STEP
+#undef STREAM_PRE
+#undef STREAM_APPEND
   flush_out();
 #undef LOAD_ROW
 #undef PUT_ROW
