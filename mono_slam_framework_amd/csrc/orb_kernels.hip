@@ -1321,24 +1321,51 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
   uint32_t* raw32 = reinterpret_cast<uint32_t*>(raw);
   // Each wave owns its LDS patch and walks its own key points: waves never wait for each other.  LDS operations of
   // one wave are executed in issue order, so a wavefront-scope fence (compiler ordering) is all the staging needs.
-  for (uint32_t k = blockIdx.x * 4 + wave; k < count; k += gridDim.x * 4) {
+  // Fetching the 45 x 48-byte patch is 63 % of this kernel when it is waited for (the patches of a batch amount to one
+  // more read of the whole pyramid, at HBM speed): the patch of the wave's NEXT key point is requested into registers
+  // before the current one is processed, and its position one key point earlier still.
+  constexpr int NPL = (PD * (PP / 4) + 63) / 64;          // dword loads per lane and patch
+  const uint32_t kstride = gridDim.x * 4;
+  uint32_t k = blockIdx.x * 4 + wave;
+  uint32_t pre[NPL];
+  int xo_pre = 0;
+  // position (level, x, y) of key point k_ -> packed; patch loads of a packed position -> pre[], xo_pre
+  auto meta = [&](uint32_t k_) -> uint3 {
+    if (k_ >= count) return make_uint3(0u, 0u, 0u);
+    const msf_keypoint* Kp = kp + (long long)slot * kKpCap + k_;
+    return make_uint3((uint32_t)Kp->octave, (uint32_t)Kp->lx, (uint32_t)Kp->ly);
+  };
+  auto issue = [&](uint3 m) {
+    int pitch_;
+    const uint8_t* img_ = level_ptr(g, src, pyr, fi, (int)m.x, &pitch_);
+    // raw patch, radius 22, fetched as aligned dwords: columns ax .. ax+47 hold x = cx-22 .. cx+22 at byte
+    // offset xo (keypoints sit >= 31 px inside the level, so this never leaves the row)
+    const int ax = ((int)m.y - PR) & ~3;
+    xo_pre = ((int)m.y - PR) - ax;
+    const uint8_t* base = img_ + (long long)((int)m.z - PR) * pitch_ + ax;
+#pragma unroll
+    for (int u = 0; u < NPL; u++) {
+      const int i = lane + 64 * u;
+      const int r = i / (PP / 4), c = i % (PP / 4);
+      pre[u] = i < PD * (PP / 4) ? *reinterpret_cast<const uint32_t*>(base + (long long)r * pitch_ + 4 * c) : 0u;
+    }
+  };
+  uint3 m_cur = meta(k), m_next = meta(k + kstride);
+  if (k < count) issue(m_cur);
+  for (; k < count; k += kstride) {
     const bool active = true;
     msf_keypoint* K = kp + (long long)slot * kKpCap + k;
-    int l = 0, cx = 0, cy = 0, pitch = 0, xo = 0;
-    const uint8_t* img = nullptr;
-    if (active) {
-      l = K->octave; cx = K->lx; cy = K->ly;
-      img = level_ptr(g, src, pyr, fi, l, &pitch);
-      // raw patch, radius 22, fetched as aligned dwords: columns ax .. ax+47 hold x = cx-22 .. cx+22 at byte
-      // offset xo (keypoints sit >= 31 px inside the level, so this never leaves the row)
-      const int ax = (cx - PR) & ~3;
-      xo = (cx - PR) - ax;
-      const uint8_t* base = img + (long long)(cy - PR) * pitch + ax;
-      for (int i = lane; i < PD * (PP / 4); i += 64) {
-        const int r = i / (PP / 4), c = i % (PP / 4);
-        raw32[i] = *reinterpret_cast<const uint32_t*>(base + (long long)r * pitch + 4 * c);
-      }
+    const int l = (int)m_cur.x, cx = (int)m_cur.y, cy = (int)m_cur.z;
+    (void)l; (void)cx; (void)cy;
+    const int xo = xo_pre;
+#pragma unroll
+    for (int u = 0; u < NPL; u++) {
+      const int i = lane + 64 * u;
+      if (i < PD * (PP / 4)) raw32[i] = pre[u];
     }
+    m_cur = m_next;
+    if (k + kstride < count) issue(m_cur);          // next patch: in flight while this key point is processed
+    m_next = meta(k + 2 * kstride);
     MSF_WAVE_SYNC();
     float angle = 0.f;
     if (active) {
