@@ -66,6 +66,8 @@ typedef enum msf_kind {
 #define MSF_FLAG_KEEP_DEBUG 4u       /* LoFTR: keep pair 0's confidence matrix and coarse features for msf_debug_get */
 #define MSF_FLAG_LEVEL_SIZE_MUL_INV 32u /* ORB pyramid level size cvRound(W * (1.f / scale)) instead of cvRound(W / scale) */
 #define MSF_FLAG_NO_FRAME_CACHE 16u  /* msf_match_pair: extract both frames on every call (no transparent per-frame cache) */
+#define MSF_FLAG_FAST_STREAM 64u     /* ORB: the output-sensitive FAST pass also for calls of fewer than 8 frames (those use the
+                                        dense kernel by default: lower latency, same results) */
 #define MSF_FLAG_FAST_DENSE 8u       /* ORB: score every pixel at fastThreshold (no output-sensitive first pass); same results */
 
 typedef struct msf_config {

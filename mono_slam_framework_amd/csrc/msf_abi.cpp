@@ -337,7 +337,7 @@ int msf_create(const msf_config* cfg, msf_handle** out) {
       h->fc_slot0 = 4 * cfg->max_batch_pairs;
       err = h->orb.init(cfg->image_width, cfg->image_height, 4 * cfg->max_batch_pairs + n_cache,
                         (cfg->flags & MSF_FLAG_BLUR_TIE_HALF_UP) != 0, profile, (cfg->flags & MSF_FLAG_FAST_DENSE) != 0,
-                        (cfg->flags & MSF_FLAG_LEVEL_SIZE_MUL_INV) != 0);
+                        (cfg->flags & MSF_FLAG_LEVEL_SIZE_MUL_INV) != 0, (cfg->flags & MSF_FLAG_FAST_STREAM) ? 1 : 8);
     } else {
       if (cfg->image_width != 640 || cfg->image_height != 480) {
         delete h;

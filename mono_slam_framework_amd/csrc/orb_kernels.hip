@@ -1694,7 +1694,7 @@ void OrbPipeline::destroy() {
   } while (0)
 
 std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_half_up, bool profile, bool dense_fast,
-                              bool level_size_mul_inv) {
+                              bool level_size_mul_inv, int stream_min_frames) {
   if (width < 64 || height < 64 || width > 8192 || height > 8192) return "arg: ORB image size must be in [64, 8192] x [64, 8192]";
   if (max_slots < 2) return "arg: ORB max_slots < 2";
   max_slots_ = max_slots;
@@ -1703,6 +1703,7 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   // MSF_ORB_FAST_TAU forces the first-pass FAST threshold (tests: a value no level can reach sends every level through
   // the check + dense second pass); MSF_FLAG_FAST_DENSE = 20 = the plain dense detector
   force_tau_ = dense_fast ? kFastT : 0;
+  stream_min_frames_ = stream_min_frames;
   if (const char* e = getenv("MSF_ORB_FAST_TAU")) {
     const int v = atoi(e) & ~1;
     if (v >= kFastT && v <= 254) force_tau_ = v;
@@ -1881,11 +1882,15 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
   // runs level by level on a side stream underneath the pyramid kernels, each level as soon as it exists
   uint32_t* tau = d_tau_;
   uint32_t* tau_first = d_tau_ + (size_t)max_slots_ * kOrbLevels;
-  const bool side = tau_stream_ != nullptr && n >= 64 && g.total_tiles > 0;
+  // A call of a few frames (the single-pair MatchFrames, a key frame upload) is latency-bound: a wave of the
+  // streaming pass walks its strip in ~70 dependent steps, whereas the dense tile kernel is one short workgroup per
+  // tile.  Such calls take the dense kernel directly; the result is the same either way.
+  const int force_tau = (force_tau_ == 0 && n < stream_min_frames_) ? kFastT : force_tau_;
+  const bool side = tau_stream_ != nullptr && n >= 64 && g.total_tiles > 0 && force_tau != kFastT;
   if (side) {
     hipEventRecord(tau_ev_[0], st);
     hipStreamWaitEvent(tau_stream_, tau_ev_[0], 0);
-    hipLaunchKernelGGL(k_fast_tau, dim3(1, n), dim3(256), 0, tau_stream_, g, src, d_pyr_, force_tau_, tau, tau_first, d_redo_,
+    hipLaunchKernelGGL(k_fast_tau, dim3(1, n), dim3(256), 0, tau_stream_, g, src, d_pyr_, force_tau, tau, tau_first, d_redo_,
                        d_redo_ + 1, 0);
   }
   for (int l = 1; l < g.nlevels; l++) {
@@ -1906,7 +1911,7 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
     if (side) {
       hipEventRecord(tau_ev_[l], st);
       hipStreamWaitEvent(tau_stream_, tau_ev_[l], 0);
-      hipLaunchKernelGGL(k_fast_tau, dim3(1, n), dim3(256), 0, tau_stream_, g, src, d_pyr_, force_tau_, tau, tau_first,
+      hipLaunchKernelGGL(k_fast_tau, dim3(1, n), dim3(256), 0, tau_stream_, g, src, d_pyr_, force_tau, tau, tau_first,
                          d_redo_, d_redo_ + 1, l);
     }
   }
@@ -1916,10 +1921,10 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
       hipEventRecord(tau_ev_[kOrbLevels], tau_stream_);
       hipStreamWaitEvent(st, tau_ev_[kOrbLevels], 0);
     } else {
-      hipLaunchKernelGGL(k_fast_tau, dim3(g.nlevels, n), dim3(256), 0, st, g, src, d_pyr_, force_tau_, tau, tau_first, d_redo_,
+      hipLaunchKernelGGL(k_fast_tau, dim3(g.nlevels, n), dim3(256), 0, st, g, src, d_pyr_, force_tau, tau, tau_first, d_redo_,
                          d_redo_ + 1, 0);
     }
-    if (force_tau_ == kFastT) {   // MSF_FLAG_FAST_DENSE: the plain detector over every tile, nothing to verify
+    if (force_tau == kFastT) {   // MSF_FLAG_FAST_DENSE: the plain detector over every tile, nothing to verify
       hipLaunchKernelGGL(k_fast, dim3((unsigned)g.total_tiles * (unsigned)n), dim3(kFastThreads), 0, st, g, src, d_pyr_,
                          d_cand_cnt_, d_cand_, d_cand_sc_);
     } else {
@@ -1936,7 +1941,7 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
     }
   }
   if (ev_ok_) hipEventRecord(ev_[2], st);
-  hipLaunchKernelGGL(k_thr_harris, dim3(g.nlevels, n), dim3(force_tau_ == kFastT ? 256 : 64), 0, st, g, src, d_pyr_,
+  hipLaunchKernelGGL(k_thr_harris, dim3(g.nlevels, n), dim3(force_tau == kFastT ? 256 : 64), 0, st, g, src, d_pyr_,
                      d_cand_cnt_, d_cand_, d_cand_sc_, d_s1_cnt_, d_s1_, d_status_);
   hipLaunchKernelGGL(k_select, dim3(n), dim3(256), 0, st, g, src.slot0, d_s1_cnt_, d_s1_, d_kp_, d_kp_cnt_,
                      d_status_);

@@ -63,7 +63,7 @@ class OrbPipeline {
   ~OrbPipeline();
   // returns empty string on success
   std::string init(int width, int height, int max_slots, bool blur_half_up, bool profile, bool dense_fast = false,
-                   bool level_size_mul_inv = false);
+                   bool level_size_mul_inv = false, int stream_min_frames = 8);
   void destroy();
 
   // extract features of n frames into slots [src.slot0, src.slot0 + n)
@@ -81,6 +81,7 @@ class OrbPipeline {
   OrbGeometry g_{};
   int max_slots_ = 0;
   bool half_up_ = false, profile_ = false;
+  int stream_min_frames_ = 8;      // calls with fewer frames take the dense FAST kernel (latency), others the streaming pass
   int force_tau_ = 0;              // > 0: every (frame, level) starts at this FAST score threshold (20 = dense)
   // device storage
   uint8_t* d_pyr_ = nullptr;

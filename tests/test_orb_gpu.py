@@ -17,7 +17,9 @@ def _matcher(w, h, thr=0.8, pairs=1, flags=0):
     # (the transparent frame cache has its own tests: tests/test_frame_cache_gpu.py)
     from mono_slam_framework_amd import _lib
     from mono_slam_framework_amd.matcher import FeatureMatcher
-    return FeatureMatcher(thr, w, h, max_batch_pairs=pairs, flags=flags | _lib.MSF_FLAG_NO_FRAME_CACHE)
+    # MSF_FLAG_FAST_STREAM: the streaming FAST pass also for these one-pair calls (it is the batch path by default)
+    return FeatureMatcher(thr, w, h, max_batch_pairs=pairs,
+                          flags=flags | _lib.MSF_FLAG_NO_FRAME_CACHE | _lib.MSF_FLAG_FAST_STREAM)
 
 
 def _noise_image(w, h, seed):
@@ -117,7 +119,7 @@ def test_fast_threshold_fallback_path():
         "from oracle import orb\n"
         "for (w, h, mode) in ((640, 480, 0), (333, 257, 1), (1280, 720, 2)):\n"
         "    A, B = synth.synth_batch(900, 3, w, h, mode=mode)\n"
-        "    fm = FeatureMatcher(0.8, w, h, max_batch_pairs=3)\n"
+        "    fm = FeatureMatcher(0.8, w, h, max_batch_pairs=3, flags=64)\n"
         "    got = fm.match_batch(list(A), list(B))\n"
         "    t = fm.fast_tau(0)\n"
         "    assert (t[:, 1] == int(sys.argv[1])).all(), t\n"
@@ -177,7 +179,7 @@ def test_streaming_fast_in_the_dense_regime():
         "        rng.integers(0, 256, size=(480, 640), dtype=np.uint8),\n"
         "        (((x // 2) + (y // 2)) %% 2 * 200 + 20).astype(np.uint8),\n"
         "        ((rng.random((480, 640)) < 0.08).astype(np.uint8) * 220 + 10)]\n"
-        "fm = FeatureMatcher(0.8, 640, 480, flags=16)\n"
+        "fm = FeatureMatcher(0.8, 640, 480, flags=16 | 64)\n"
         "orc = orb.FeatureMatcherOracle(0.8)\n"
         "for i, a in enumerate(imgs):\n"
         "    b = np.roll(a, (3, 5), (0, 1))\n"
@@ -193,6 +195,20 @@ def test_streaming_fast_in_the_dense_regime():
     ) % ROOT
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MSF_ORB_FAST_TAU="22"), capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_small_calls_take_the_dense_kernel_with_the_same_result():
+    """Calls of fewer than 8 frames skip the streaming pass (latency); the lists are the same as with it."""
+    from mono_slam_framework_amd import _lib
+    from mono_slam_framework_amd.matcher import FeatureMatcher
+    a, b = synth.synth_pair(17, 640, 480)
+    f_dense = FeatureMatcher(0.7, 640, 480, flags=_lib.MSF_FLAG_NO_FRAME_CACHE)
+    f_stream = FeatureMatcher(0.7, 640, 480, flags=_lib.MSF_FLAG_NO_FRAME_CACHE | _lib.MSF_FLAG_FAST_STREAM)
+    m1, m2 = f_dense.MatchFrames(a, b), f_stream.MatchFrames(a, b)
+    np.testing.assert_array_equal(m1, m2)
+    assert (f_dense.fast_tau(0)[:, 0] == 20).all() and (f_stream.fast_tau(0)[:, 0] > 20).any()
+    np.testing.assert_array_equal(f_dense.descriptors(0), f_stream.descriptors(0))
+    np.testing.assert_array_equal(m1, oracle_orb.FeatureMatcherOracle(0.7).MatchFrames(a, b))
 
 
 def test_threshold_and_blur_mode():
