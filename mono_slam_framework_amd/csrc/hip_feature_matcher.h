@@ -102,8 +102,9 @@ class HipFeatureMatcher : public HipMatcherBase {
 };
 
 // ::DNNFeatureMatcher(model_file_path, threshold = 0.15f, image_width = 640, image_height = 480,
-//                     model_resolution = 16)  (dnnfeaturematcher.h:11-13); model_file_path is the weights blob
-// extracted from model/LoFTR_teacher.onnx (empty = the blob shipped next to libmsf.so).
+//                     model_resolution = 16)  (dnnfeaturematcher.h:11-13); model_file_path is the model file the
+// reference opens, model/LoFTR_teacher.onnx (read directly: csrc/weights_io.cpp), or an MSFLTR01 blob written by
+// msf_convert_weights; empty = the blob shipped next to libmsf.so.
 class HipDNNFeatureMatcher : public HipMatcherBase {
  public:
   explicit HipDNNFeatureMatcher(const std::string& model_file_path = "", float threshold = 0.15f,

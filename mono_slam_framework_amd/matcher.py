@@ -242,7 +242,9 @@ class FeatureMatcher(_Matcher):
 
 
 class DNNFeatureMatcher(_Matcher):
-    """LoFTR_teacher (model/LoFTR_teacher.onnx restated as HIP kernels) + threshold + decode, on the GPU."""
+    """LoFTR_teacher (model/LoFTR_teacher.onnx restated as HIP kernels) + threshold + decode, on the GPU.
+    model_file_path: the reference's .onnx file (read directly) or an MSFLTR01 blob; None = the blob shipped with the
+    package."""
     _kind = _lib.MSF_KIND_LOFTR
 
     def __init__(self, model_file_path=None, threshold=0.15, image_width=640, image_height=480,
