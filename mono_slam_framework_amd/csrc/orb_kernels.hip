@@ -872,7 +872,7 @@ __global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, c
     __syncthreads();
     int pitch;
     const uint8_t* img = level_ptr(g, src, pyr, fi, l, &pitch);
-    const int rw = L.w - 2 * kEdge, rh = L.h - 2 * kEdge;
+    const int rh = L.h - 2 * kEdge;
     // A sample site is a run of 4 adjacent pixels (one aligned dword): the cardinal test then works on 4 px at once
     // from 5 dword loads (the SWAR form of fast_tile's prefilter at kTauPre), a quarter of the loads per pixel.
     // Four sampled rows per iteration, so that their 20 loads are in flight together.
@@ -1784,7 +1784,7 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     L.samp_sx = L.samp_sy = 1;
     L.samp_rows = L.samp_cols = 0;
     if (L.tiles_x > 0) {
-      const int rw = L.w - 2 * kEdge, rh = L.h - 2 * kEdge;
+      const int rh = L.h - 2 * kEdge;
       const int n_dw = (L.w - kEdge - ((kEdge + 3) & ~3)) >> 2;          // aligned dwords fully inside [31, w - 31)
       const double s2 = (double)n_dw * rh / 1024.0;                      // (dword, row) sites per sampled run
       int sx = (int)(sqrt(s2 > 1.0 ? s2 : 1.0) / 4.0);
