@@ -322,6 +322,10 @@ int msf_create(const msf_config* cfg, msf_handle** out) {
     if ((e = hipSetDevice(cfg->device)) != hipSuccess) return hip_fail(nullptr, "hipSetDevice", e);
     msf_handle* h = new (std::nothrow) msf_handle();
     if (!h) return fail(nullptr, MSF_ERR_HIP, "out of host memory");
+    struct Guard {   // whatever path leaves this function without success (an exception included) frees the handle
+      msf_handle* h;
+      ~Guard() { if (h) msf_destroy(h); }
+    } guard{h};
     h->cfg = *cfg;
     h->cfg.weights_path = nullptr;
     std::string err;
@@ -340,21 +344,18 @@ int msf_create(const msf_config* cfg, msf_handle** out) {
                         (cfg->flags & MSF_FLAG_LEVEL_SIZE_MUL_INV) != 0, (cfg->flags & MSF_FLAG_FAST_STREAM) ? 1 : 8);
     } else {
       if (cfg->image_width != 640 || cfg->image_height != 480) {
-        delete h;
-        return fail(nullptr, MSF_ERR_UNSUPPORTED, "LoFTR_teacher is a fixed-shape 1x1x480x640 graph (model/LoFTR_teacher.onnx)");
+          return fail(nullptr, MSF_ERR_UNSUPPORTED, "LoFTR_teacher is a fixed-shape 1x1x480x640 graph (model/LoFTR_teacher.onnx)");
       }
       h->fc_slot0 = 2 * cfg->max_batch_pairs;
       err = h->loftr.init(cfg->weights_path, cfg->max_batch_pairs, profile, (cfg->flags & MSF_FLAG_KEEP_DEBUG) != 0, n_cache);
     }
     if (!err.empty()) {
       const bool io = err.rfind("io:", 0) == 0, arg = err.rfind("arg:", 0) == 0;
-      delete h;
       return fail(nullptr, io ? MSF_ERR_IO : arg ? MSF_ERR_INVALID_ARG : MSF_ERR_HIP, err);
     }
     // hipStreamDefault (a "blocking" stream): work on the handle's own stream is ordered against the legacy null stream,
     // which is where a caller that passes stream = NULL (e.g. torch's default stream) has its own work (msf_abi.h)
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamDefault)) != hipSuccess) {
-      delete h;
       return hip_fail(nullptr, "hipStreamCreate", e);
     }
     if (n_cache > 0) {
@@ -362,11 +363,11 @@ int msf_create(const msf_config* cfg, msf_handle** out) {
       for (int i = 0; i < n_cache; i++) ids[i] = h->fc_slot0 + i;
       if ((e = hipMalloc(&h->d_fc_slots, (size_t)n_cache * sizeof(int32_t))) != hipSuccess ||
           (e = hipMemcpy(h->d_fc_slots, ids.data(), (size_t)n_cache * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess) {
-        msf_destroy(h);
         return hip_fail(nullptr, "hipMalloc(frame cache slots)", e);
       }
       h->fc.resize(n_cache);
     }
+    guard.h = nullptr;
     *out = h;
     return MSF_OK;
   } catch (...) {
