@@ -377,13 +377,27 @@ __global__ __launch_bounds__(256) void k_block8(const float* __restrict__ in, co
       f32x4 acc[5];
 #pragma unroll
       for (int u = 0; u < 5; u++) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // software pipeline: the five fragment reads of step s + 1 are issued before the five MFMAs of step s (the
+      // scheduler, left alone, hoists dozens of reads)
+      const float* xbase = &xT[kq * XPLANE + XO + 16 * m + i];
+      float an[5], ac[5];
+#pragma unroll
+      for (int u = 0; u < 5; u++) ac[u] = xbase[2 * u * XPITCH];
 #pragma unroll
       for (int step = 0; step < KSTEPS; step++) {
-        const int kk = (step * 4) / 8, c = (step * 4) % 8 + kq;
-        const int ky = kk / 3, kx = kk - ky * 3;
-        const float* ap = &xT[c * XPLANE + ky * XPITCH + kx + XO + 16 * m + i];
+        if (step + 1 < KSTEPS) {
+          const int kk = ((step + 1) * 4) / 8, c = ((step + 1) * 4) % 8;
+          const int ky = kk / 3, kx = kk - ky * 3;
+          const float* ap = xbase + c * XPLANE + ky * XPITCH + kx;
 #pragma unroll
-        for (int u = 0; u < 5; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[2 * u * XPITCH], bw1[step], acc[u], 0, 0, 0);
+          for (int u = 0; u < 5; u++) an[u] = ap[2 * u * XPITCH];
+        }
+#pragma unroll
+        for (int u = 0; u < 5; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], bw1[step], acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 5; u++) ac[u] = an[u];
+        __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);   // 5 LDS reads
+        __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);   // 5 MFMAs
       }
 #pragma unroll
       for (int u = 0; u < 5; u++) {
@@ -423,13 +437,25 @@ __global__ __launch_bounds__(256) void k_block8(const float* __restrict__ in, co
       f32x4 acc[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* tbase = &tT[kq * TPLANE];
+      float an[4], ac[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) ac[u] = tbase[colterm[0] + 2 * u * TPITCH];
 #pragma unroll
       for (int step = 0; step < KSTEPS; step++) {
-        const int kk = (step * 4) / 8, c = (step * 4) % 8 + kq;
-        const int ky = kk / 3, kx = kk - ky * 3;
-        const float* ap = &tT[c * TPLANE + ky * TPITCH + colterm[kx]];
+        if (step + 1 < KSTEPS) {
+          const int kk = ((step + 1) * 4) / 8, c = ((step + 1) * 4) % 8;
+          const int ky = kk / 3, kx = kk - ky * 3;
+          const float* ap = tbase + c * TPLANE + ky * TPITCH + colterm[kx];
 #pragma unroll
-        for (int u = 0; u < 4; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[2 * u * TPITCH], bw2[step], acc[u], 0, 0, 0);
+          for (int u = 0; u < 4; u++) an[u] = ap[2 * u * TPITCH];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], bw2[step], acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) ac[u] = an[u];
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
@@ -441,6 +467,193 @@ __global__ __launch_bounds__(256) void k_block8(const float* __restrict__ in, co
       }
     }
   }
+#undef MSF_BLK_ISSUE
+}
+
+// ------------------------------------------------------------------ fused BasicBlock, 16 channels, stride 1 (layer2 @ 120 x 160)
+// The same scheme as k_block8 without row packing (the 16 MFMA columns are the 16 output channels): a workgroup owns a
+// band of R = 8 output rows and walks its x tiles of 32 columns; wave w takes M tile w & 1 (16 columns) of the t rows
+// 5 (w >> 1) .. +4 in conv1 and of the output rows 4 (w >> 1) .. +3 in conv2.  Both convolutions' 36 weight fragments
+// stay in registers.  75.8 KB of LDS: two workgroups per CU.  Same MFMA chains in the same k order as k_conv<16,16,3,1>:
+// bit-identical to the two-kernel path.
+namespace blk16 {
+constexpr int CH = 16, R = 8, TW = 32;
+constexpr int XH = R + 4;                          // x rows oy0-2 .. oy0+9
+constexpr int XO = 3;                              // staged rows start at the float4-aligned column 32k - 4; window starts at 32k - 1
+constexpr int XW4 = (TW + 2 + XO + 3) / 4;         // 10 float4 per staged row
+constexpr int XPITCH = 4 * XW4;                    // 40
+constexpr int XPLANE = ((XH * XPITCH + 15) / 32) * 32 + 16;
+constexpr int TROWS = R + 2;                       // t rows oy0-1 .. oy0+8
+constexpr int TPITCH = 2 * TW + 4;                 // two 32-column segments, halo columns 64 / 66, zero column 65
+constexpr int TPLANE = ((TROWS * TPITCH + 15) / 32) * 32 + 16;
+constexpr int KSTEPS = 36;                         // 3 x 3 x 16 / 4
+constexpr int LDS_FLOATS = CH * XPLANE + CH * TPLANE;
+static_assert(XPLANE % 32 == 16 && TPLANE % 32 == 16, "plane strides");
+static_assert(XPLANE >= XH * XPITCH && TPLANE >= TROWS * TPITCH, "planes too small");
+}  // namespace blk16
+
+__global__ __launch_bounds__(256, 2) void k_block16(const float* __restrict__ in, const float* __restrict__ w1,
+                                                 const float* __restrict__ b1, const float* __restrict__ w2,
+                                                 const float* __restrict__ b2, float* __restrict__ out, int H, int W,
+                                                 int n_bands) {
+  using namespace blk16;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xT = lds;
+  float* tT = lds + CH * XPLANE;
+  const int nwg = gridDim.x, per = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7;
+  const int unit = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);     // XCD-contiguous (image, band) order
+  const int img = unit / n_bands;
+  const int oy0 = (unit - img * n_bands) * R;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;          // MFMA column = output channel i
+  const int m = wave & 1, hf = wave >> 1;           // M tile (16 columns of the 32), row half
+  const float* inf = in + (long long)img * CH * H * W;
+  float* outf = out + (long long)img * CH * H * W;
+
+  float bw1[KSTEPS], bw2[KSTEPS];
+#pragma unroll
+  for (int j = 0; j < KSTEPS; j++) {
+    bw1[j] = w1[(j * 4 + kq) * 16 + i];
+    bw2[j] = w2[(j * 4 + kq) * 16 + i];
+  }
+  const float bias1 = b1[i], bias2 = b2[i];
+  // halo column of tile 0 (= padding), the zero column and the second halo column
+  for (int idx = tid; idx < CH * TROWS; idx += 256) {
+    const int c = idx / TROWS, r = idx - c * TROWS;
+    *reinterpret_cast<f32x4*>(&tT[c * TPLANE + r * TPITCH + 2 * TW]) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  constexpr int TOTAL = CH * XH * XW4;
+  constexpr int NLD = (TOTAL + 255) / 256;
+  f32x4 pre[NLD];
+  // (channel, row, float4 column) of a thread's u-th group is re-derived where it is needed (divisions by constants):
+  // keeping the offsets in registers would cost 16 VGPRs and the second wave per SIMD
+#define MSF_BLK_DECODE(u_)                                  \
+  const int idx_ = tid + 256 * (u_);                        \
+  const int c_ = idx_ / (XH * XW4);                         \
+  const int rm_ = idx_ - c_ * (XH * XW4);                   \
+  const int r_ = rm_ / XW4;                                 \
+  const int x4_ = rm_ - r_ * XW4;
+#define MSF_BLK_ISSUE(k_)                                                                       \
+  {                                                                                             \
+    const int gx0_ = TW * (k_) - 4;                                                             \
+    _Pragma("unroll") for (int u = 0; u < NLD; u++) {                                           \
+      MSF_BLK_DECODE(u)                                                                         \
+      const int gy = oy0 - 2 + r_, gx = gx0_ + 4 * x4_;                                         \
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                      \
+      if (idx_ < TOTAL && gy >= 0 && gy < H && gx >= 0 && gx + 4 <= W)                          \
+        v = *reinterpret_cast<const f32x4*>(inf + (c_ * H + gy) * W + gx);                      \
+      pre[u] = v;                                                                               \
+    }                                                                                           \
+  }
+#define MSF_BLK_COMMIT()                                                                        \
+  {                                                                                             \
+    _Pragma("unroll") for (int u = 0; u < NLD; u++) {                                           \
+      MSF_BLK_DECODE(u)                                                                         \
+      if (idx_ < TOTAL) *reinterpret_cast<f32x4*>(&xT[c_ * XPLANE + r_ * XPITCH + 4 * x4_]) = pre[u]; \
+    }                                                                                           \
+  }
+  const int ntx = W / TW;
+  MSF_BLK_ISSUE(0)
+  MSF_BLK_COMMIT()
+  // iteration k: conv1 of tile k | barrier | x tile k+1 and the halo column into LDS, conv2 of tile k-1 (see k_block8)
+  for (int k = 0; k <= ntx; k++) {
+    __syncthreads();
+    if (k + 1 < ntx) MSF_BLK_ISSUE(k + 1)
+    if (k < ntx) {
+      // ---- conv1 of tile k: t rows 5 hf + u (u = 0..4), columns 16m .. 16m+15 of the tile
+      f32x4 acc[5];
+#pragma unroll
+      for (int u = 0; u < 5; u++) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // software pipeline: the five fragment reads of step s + 1 are issued before the five MFMAs of step s, and the
+      // scheduler is told to keep it that way (left alone it hoists dozens of reads and the kernel no longer fits two
+      // waves per SIMD)
+      const float* xbase = &xT[kq * XPLANE + 5 * hf * XPITCH + XO + 16 * m + i];
+      float an[5], ac[5];
+#pragma unroll
+      for (int u = 0; u < 5; u++) ac[u] = xbase[u * XPITCH];
+#pragma unroll
+      for (int step = 0; step < KSTEPS; step++) {
+        if (step + 1 < KSTEPS) {
+          const int kk = ((step + 1) * 4) / CH, c = ((step + 1) * 4) % CH;
+          const int ky = kk / 3, kx = kk - ky * 3;
+          const float* ap = xbase + c * XPLANE + ky * XPITCH + kx;
+#pragma unroll
+          for (int u = 0; u < 5; u++) an[u] = ap[u * XPITCH];
+        }
+#pragma unroll
+        for (int u = 0; u < 5; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], bw1[step], acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 5; u++) ac[u] = an[u];
+        __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);   // 5 LDS reads
+        __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);   // 5 MFMAs
+      }
+#pragma unroll
+      for (int u = 0; u < 5; u++) {
+        const int tr = 5 * hf + u, gy = oy0 - 1 + tr;
+        f32x4 v = acc[u] + f32x4{bias1, bias1, bias1, bias1};
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        if (gy < 0 || gy >= H) v = f32x4{0.f, 0.f, 0.f, 0.f};        // conv2 pads t with zeros
+        *reinterpret_cast<f32x4*>(&tT[i * TPLANE + tr * TPITCH + (k & 1) * TW + 16 * m + 4 * kq]) = v;
+      }
+    }
+    __syncthreads();                       // t of tile k is complete; nobody reads the x tile any more
+    if (k + 1 < ntx) MSF_BLK_COMMIT()
+    if (k >= 1 && k < ntx) {               // last column of tile k-1 -> the halo column conv2 of tile k reads (next iteration)
+      for (int idx = tid; idx < CH * TROWS; idx += 256) {
+        const int c = idx / TROWS, r = idx - c * TROWS;
+        float* row = &tT[c * TPLANE + r * TPITCH];
+        row[2 * TW + 2 * (k & 1)] = row[((k - 1) & 1) * TW + TW - 1];
+      }
+    }
+    if (k >= 1) {
+      // ---- conv2 of tile j = k-1: output rows oy0 + 4 hf + u (u = 0..3), columns 32j + 16m .. +15
+      const int j = k - 1;
+      f32x4 rv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++)     // residual = x, requested before the MFMA loop
+        rv[u] = *reinterpret_cast<const f32x4*>(inf + ((long long)i * H + (oy0 + 4 * hf + u)) * W + TW * j + 16 * m + 4 * kq);
+      int colterm[3];
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++) {
+        const int cr = 16 * m + i + kx - 1;                               // column inside the tile, -1 .. 32
+        colterm[kx] = cr < 0 ? 2 * TW + 2 * (j & 1) : cr >= TW ? (k < ntx ? (k & 1) * TW : 2 * TW + 1) : (j & 1) * TW + cr;
+      }
+      f32x4 acc[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* tbase = &tT[kq * TPLANE + 4 * hf * TPITCH];
+      float an[4], ac[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) ac[u] = tbase[colterm[0] + u * TPITCH];
+#pragma unroll
+      for (int step = 0; step < KSTEPS; step++) {
+        if (step + 1 < KSTEPS) {
+          const int kk = ((step + 1) * 4) / CH, c = ((step + 1) * 4) % CH;
+          const int ky = kk / 3, kx = kk - ky * 3;
+          const float* ap = tbase + c * TPLANE + ky * TPITCH + colterm[kx];
+#pragma unroll
+          for (int u = 0; u < 4; u++) an[u] = ap[u * TPITCH];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], bw2[step], acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) ac[u] = an[u];
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int oy = oy0 + 4 * hf + u;
+        f32x4 v = acc[u] + f32x4{bias2, bias2, bias2, bias2};
+        v += rv[u];
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        *reinterpret_cast<f32x4*>(outf + ((long long)i * H + oy) * W + TW * j + 16 * m + 4 * kq) = v;
+      }
+    }
+  }
+#undef MSF_BLK_DECODE
+#undef MSF_BLK_COMMIT
 #undef MSF_BLK_ISSUE
 }
 
@@ -1006,9 +1219,11 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
   {
     if (const char* d = getenv("MSF_LOFTR_DENSE_HEAD")) P.dense_head = atoi(d) != 0;   // tests: force the dense head
     if (const char* d = getenv("MSF_LOFTR_UNFUSED")) P.fuse_blocks = atoi(d) == 0;
-    const char* e = getenv("MSF_LOFTR_CHUNK");   // pairs per backbone pass (activation working set)
-    const int want = e ? atoi(e) : 64;
-    P.chunk = max_pairs < want ? max_pairs : (want > 0 ? want : 64);
+    // pairs per backbone pass (activation working set: 19.7 MB per pair).  Whole launches of 512 images fill the 512
+    // workgroup slots of the fused block kernels in whole rounds (64 pairs: conv stack 8.41 ms, 128: 8.15, 256: 8.07)
+    const char* e = getenv("MSF_LOFTR_CHUNK");
+    const int want = e ? atoi(e) : 256;
+    P.chunk = max_pairs < want ? max_pairs : (want > 0 ? want : 256);
   }
   P.profile = profile;
   P.keep_debug = keep_debug;
@@ -1199,6 +1414,19 @@ void launch_block8(const ConvDesc& ca, const ConvDesc& cb, const float* in, floa
                      ca.wout, n_bands);
 }
 
+// the same for a 16-channel, stride-1 BasicBlock at 120 x 160 (k_block16)
+void launch_block16(const ConvDesc& ca, const ConvDesc& cb, const float* in, float* out, int n_img, hipStream_t st) {
+  const size_t lds = (size_t)blk16::LDS_FLOATS * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_block16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const int n_bands = ca.hout / blk16::R;     // 120 / 8
+  hipLaunchKernelGGL(k_block16, dim3(n_bands * n_img), dim3(256), lds, st, in, ca.d_w, ca.d_b, cb.d_w, cb.d_b, out, ca.hout,
+                     ca.wout, n_bands);
+}
+
 }  // namespace
 
 namespace {
@@ -1286,8 +1514,12 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
   const long long s16 = 16LL * 120 * 160;
   launch_conv<8, 16, 3, 2, 32, true, false, false, 1, true>(c[5], a, s8, 0, nullptr, b, ni, st, &c[7], d);   // + shortcut -> d
   launch_conv<16, 16, 3, 1, 32, true, true, false>(c[6], b, s16, 0, d, cc, ni, st);              // cc = 205
-  launch_conv<16, 16, 3, 1, 32, true, false, false>(c[8], cc, s16, 0, nullptr, b, ni, st);
-  launch_conv<16, 16, 3, 1, 32, true, true, false>(c[9], b, s16, 0, cc, a, ni, st);              // a = 212
+  if (P.fuse_blocks) {
+    launch_block16(c[8], c[9], cc, a, ni, st);                                                     // a = 212
+  } else {
+    launch_conv<16, 16, 3, 1, 32, true, false, false>(c[8], cc, s16, 0, nullptr, b, ni, st);
+    launch_conv<16, 16, 3, 1, 32, true, true, false>(c[9], b, s16, 0, cc, a, ni, st);              // a = 212
+  }
   // layer3 @60x80, 32 ch
   const long long s32 = 32LL * 60 * 80;
   launch_conv<16, 32, 3, 2, 16, true, false, false, 1, true>(c[10], a, s16, 0, nullptr, b, ni, st, &c[12], d);
