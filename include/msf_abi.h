@@ -222,8 +222,10 @@ typedef enum msf_debug_what {
   MSF_DBG_STAGE1 = 5,        /* msf_keypoint [n] (lx, ly, octave, fast_score, response) of (slot, level), unordered */
   MSF_DBG_LOFTR_CONF = 6,    /* float [1200][1200] confidence matrix of pair `slot` (debug launch only) */
   MSF_DBG_LOFTR_FEAT = 7,    /* float [2][1200][32] coarse features after the transformer of pair `slot` */
-  MSF_DBG_FAST_TAU = 8       /* int32 [nlevels][2] of slot: FAST score threshold the candidate list was built with
+  MSF_DBG_FAST_TAU = 8,      /* int32 [nlevels][2] of slot: FAST score threshold the candidate list was built with
                                 (20 = dense, also after a failed check), and the first estimate */
+  MSF_DBG_LOFTR_ACT = 9      /* float NCHW activation of the first frame of the last backbone pass after ResNet stage
+                                `level` + 1: [8][240][320], [16][120][160], [32][60][80], [32][30][40] (level 0..3) */
 } msf_debug_what;
 /* copies to host; *n_bytes = bytes available (may exceed cap_bytes, then only cap_bytes are written) */
 int msf_debug_get(msf_handle* h, int32_t what, int32_t slot, int32_t level,

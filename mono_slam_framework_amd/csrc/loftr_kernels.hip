@@ -470,6 +470,212 @@ __global__ __launch_bounds__(256) void k_block8(const float* __restrict__ in, co
 #undef MSF_BLK_ISSUE
 }
 
+// ------------------------------------------------------------------ fused BasicBlock, 8 channels, split-bf16 MFMA
+// The same block as k_block8 on v_mfma_f32_16x16x32_bf16 (16 x the f32 MFMA rate) with every f32 operand split into
+// hi = bf16(v) and lo = bf16(v - hi): v * w = hi*whi + hi*wlo + lo*whi + O(2^-16 |v w|), three MFMAs accumulating in
+// f32.  One MFMA spans K = 32 = 4 input rows x 8 channels of one kx (row packing as in k_block8: the 16 output columns
+// are 8 channels of two adjacent rows), so a 3 x 3 x 8 convolution of a row pair is 3 (kx) x 3 (products) MFMAs of
+// 16 cycles instead of 24 of 32: the block is no longer MFMA-bound but streams at its HBM time.
+//  * activations live in LDS channels-last, as two planes (hi, lo) of 16-byte pixels (8 x bf16): one ds_read_b128 is
+//    one operand fragment (lane = pixel i of the M tile and input row kq); row pitches are multiples of 16 pixels so
+//    the two input rows a lane group reads fall on disjoint banks;
+//  * conv1 runs transposed (A = weights, B = pixels): a lane then holds 4 consecutive channels of one t pixel, i.e.
+//    one 8-byte store per plane; conv2 runs as in k_block8 (A = pixels, B = weights): 4 consecutive pixels of one
+//    output channel per lane, float4 stores to NCHW;
+//  * the x tile is fetched as one dword per (pixel, channel) -- lanes along x, coalesced -- and split on the way in.
+// Not bit-identical to the f32 path: |error| <= ~2^-15 of the operand products per convolution; the f32 kernels
+// remain behind MSF_FLAG_LOFTR_F32 / MSF_LOFTR_F32=1 (tests compare the two and the ONNX golden).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace blk8x {
+constexpr int R = 8, TW = 64;
+constexpr int XH = R + 4;                          // x rows oy0-2 .. oy0+9
+constexpr int XP = 80;                             // x row pitch in pixels (columns 64k-1 .. 64k+64 used): multiple of 16
+constexpr int XPLANE = XH * XP;
+constexpr int TROWS = R + 2;                       // t rows oy0-1 .. oy0+8
+constexpr int TP = 144;                            // two 64-pixel segments, halo pixels 128 / 129, zero pixel 130
+constexpr int TPLANE = TROWS * TP;
+constexpr int LDS_BYTES = 16 * (2 * XPLANE + 2 * TPLANE);   // 76 800: two workgroups per CU
+constexpr int WFRAG = 2 * 3 * 64 * 8;              // bf16 elements of one convolution's packed weights [hi|lo][kx][lane][8]
+}  // namespace blk8x
+
+__device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
+  hi = (__bf16)v;
+  lo = (__bf16)(v - (float)hi);
+}
+
+__global__ __launch_bounds__(256, 2) void k_block8x(const float* __restrict__ in, const uint16_t* __restrict__ wx1,
+                                                    const float* __restrict__ b1, const uint16_t* __restrict__ wx2,
+                                                    const float* __restrict__ b2, float* __restrict__ out, int H, int W,
+                                                    int n_bands) {
+  using namespace blk8x;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  bf16x8* xh = reinterpret_cast<bf16x8*>(lds);
+  bf16x8* xl = xh + XPLANE;
+  bf16x8* th = xl + XPLANE;
+  bf16x8* tl = th + TPLANE;
+  const int nwg = gridDim.x, per = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7;
+  const int unit = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);     // XCD-contiguous (image, band) order
+  const int img = unit / n_bands;
+  const int oy0 = (unit - img * n_bands) * R;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int m = wave;                              // this wave's M tile (16 pixels) of every row pair
+  const long long HW = (long long)H * W;
+  const float* inf = in + (long long)img * 8 * HW;
+  float* outf = out + (long long)img * 8 * HW;
+
+  // weight fragments of both convolutions: [hi | lo][kx] (lane = (channel + 8 row, input row kq), 8 input channels)
+  bf16x8 w1h[3], w1l[3], w2h[3], w2l[3];
+  {
+    const bf16x8* p1 = reinterpret_cast<const bf16x8*>(wx1);
+    const bf16x8* p2 = reinterpret_cast<const bf16x8*>(wx2);
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+      w1h[g] = p1[g * 64 + lane]; w1l[g] = p1[(3 + g) * 64 + lane];
+      w2h[g] = p2[g * 64 + lane]; w2l[g] = p2[(3 + g) * 64 + lane];
+    }
+  }
+  const f32x4 bias1 = *reinterpret_cast<const f32x4*>(b1 + 4 * (kq & 1));   // conv1: lane = 4 channels of one t pixel
+  const float bias2 = b2[i & 7];                                             // conv2: lane = one channel, 4 pixels
+  // halo pixels and the zero pixel of every t row (halo of tile 0 = padding)
+  if (tid < 2 * TROWS) {
+    bf16x8* pl = tid < TROWS ? th : tl;
+    const int r = tid < TROWS ? tid : tid - TROWS;
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; j++) z[j] = (__bf16)0.f;
+    pl[r * TP + 128] = z; pl[r * TP + 129] = z; pl[r * TP + 130] = z;
+  }
+
+  // x staging: item = one pixel (8 channel dwords).  Items 0..2 of a thread: row (tid >> 6) + 4u, column (tid & 63) + 1
+  // (image column 64k + (tid & 63): always inside); item 3 (threads 0..23): the two halo columns 0 and 65.
+  float pre[4][8];
+  constexpr int kNoRow = -(1 << 30);
+  int goff[4];                                     // gy * W + column offset inside the tile window (>= -1), or kNoRow
+  bool hcol = false;                               // item 3: right halo column
+#pragma unroll
+  for (int u = 0; u < 3; u++) {
+    const int gy = oy0 - 2 + (tid >> 6) + 4 * u;
+    goff[u] = (gy >= 0 && gy < H) ? gy * W + (tid & 63) : kNoRow;
+  }
+  {
+    const int gy = oy0 - 2 + (tid >> 1);
+    hcol = (tid & 1) != 0;
+    goff[3] = (tid < 2 * XH && gy >= 0 && gy < H) ? gy * W + (hcol ? TW : -1) : kNoRow;
+  }
+  const int ntx = W / TW;
+#define MSF_BX_ISSUE(k_)                                                                          \
+  {                                                                                               \
+    _Pragma("unroll") for (int u = 0; u < 4; u++) {                                               \
+      bool ok = goff[u] != kNoRow;                                                                \
+      if (u == 3) ok = ok && (hcol ? (k_) + 1 < ntx : (k_) > 0);                                  \
+      const float* src = inf + (ok ? goff[u] : 0) + TW * (k_);                                    \
+      _Pragma("unroll") for (int c = 0; c < 8; c++) pre[u][c] = ok ? src[c * HW] : 0.f;           \
+    }                                                                                             \
+  }
+#define MSF_BX_COMMIT()                                                                           \
+  {                                                                                               \
+    _Pragma("unroll") for (int u = 0; u < 4; u++) {                                               \
+      if (u == 3 && tid >= 2 * XH) continue;                                                      \
+      const int slot = u < 3 ? ((tid >> 6) + 4 * u) * XP + (tid & 63) + 1 : (tid >> 1) * XP + (hcol ? TW + 1 : 0); \
+      bf16x8 vh, vl;                                                                              \
+      _Pragma("unroll") for (int c = 0; c < 8; c++) {                                             \
+        __bf16 a, b;                                                                              \
+        split_bf16(pre[u][c], a, b);                                                              \
+        vh[c] = a; vl[c] = b;                                                                     \
+      }                                                                                           \
+      xh[slot] = vh; xl[slot] = vl;                                                               \
+    }                                                                                             \
+  }
+  MSF_BX_ISSUE(0)
+  MSF_BX_COMMIT()
+  // iteration k: conv1 of tile k | barrier | x tile k+1 and the halo pixel into LDS, conv2 of tile k-1 (see k_block8)
+  for (int k = 0; k <= ntx; k++) {
+    __syncthreads();
+    if (k + 1 < ntx) MSF_BX_ISSUE(k + 1)
+    if (k < ntx) {
+      // ---- conv1 of tile k, transposed: D[channel + 8 row][pixel]; t rows 2u, 2u+1 (u = 0..4), pixels 16m .. 16m+15
+      f32x4 acc[5];
+#pragma unroll
+      for (int u = 0; u < 5; u++) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int xb = kq * XP + 16 * m + i;
+#pragma unroll
+      for (int u = 0; u < 5; u++)
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+          const bf16x8 ph = xh[xb + 2 * u * XP + g], pl = xl[xb + 2 * u * XP + g];
+          acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1l[g], ph, acc[u], 0, 0, 0);
+          acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1h[g], pl, acc[u], 0, 0, 0);
+          acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1h[g], ph, acc[u], 0, 0, 0);
+        }
+      bf16x4* th4 = reinterpret_cast<bf16x4*>(th);
+      bf16x4* tl4 = reinterpret_cast<bf16x4*>(tl);
+#pragma unroll
+      for (int u = 0; u < 5; u++) {
+        const int tr = 2 * u + (kq >> 1), gy = oy0 - 1 + tr;
+        f32x4 v = acc[u] + bias1;
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        if (gy < 0 || gy >= H) v = f32x4{0.f, 0.f, 0.f, 0.f};        // conv2 pads t with zeros
+        bf16x4 vh, vl;
+        __bf16 a, b;
+        split_bf16(v.x, a, b); vh[0] = a; vl[0] = b;
+        split_bf16(v.y, a, b); vh[1] = a; vl[1] = b;
+        split_bf16(v.z, a, b); vh[2] = a; vl[2] = b;
+        split_bf16(v.w, a, b); vh[3] = a; vl[3] = b;
+        const int slot = tr * TP + (k & 1) * TW + 16 * m + i;
+        th4[2 * slot + (kq & 1)] = vh;
+        tl4[2 * slot + (kq & 1)] = vl;
+      }
+    }
+    __syncthreads();                       // t of tile k is complete; nobody reads the x tile any more
+    if (k + 1 < ntx) MSF_BX_COMMIT()
+    if (k >= 1 && k < ntx && tid < 2 * TROWS) {   // last pixel of tile k-1 -> the halo pixel conv2 of tile k reads
+      bf16x8* pl = tid < TROWS ? th : tl;
+      const int r = tid < TROWS ? tid : tid - TROWS;
+      pl[r * TP + 128 + (k & 1)] = pl[r * TP + ((k - 1) & 1) * TW + TW - 1];
+    }
+    if (k >= 1) {
+      // ---- conv2 of tile j = k-1: output rows oy0 + 2u, +1 (u = 0..3), pixels 64j + 16m .. +15
+      const int j = k - 1;
+      const int rowsel = i >> 3, co = i & 7;
+      f32x4 rv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++)     // residual = x (f32, from global / L2), requested before the MFMAs
+        rv[u] = *reinterpret_cast<const f32x4*>(inf + ((long long)co * H + (oy0 + 2 * u + rowsel)) * W + TW * j + 16 * m + 4 * kq);
+      int colslot[3];
+#pragma unroll
+      for (int g = 0; g < 3; g++) {
+        const int cr = 16 * m + i + g - 1;                               // pixel inside the tile, -1 .. 64
+        colslot[g] = kq * TP + (cr < 0 ? 128 + (j & 1) : cr >= TW ? (k < ntx ? (k & 1) * TW : 130) : (j & 1) * TW + cr);
+      }
+      f32x4 acc[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+          const bf16x8 ah = th[colslot[g] + 2 * u * TP], al = tl[colslot[g] + 2 * u * TP];
+          acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, w2l[g], acc[u], 0, 0, 0);
+          acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, w2h[g], acc[u], 0, 0, 0);
+          acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, w2h[g], acc[u], 0, 0, 0);
+        }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int oy = oy0 + 2 * u + rowsel;
+        f32x4 v = acc[u] + f32x4{bias2, bias2, bias2, bias2};
+        v += rv[u];
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        *reinterpret_cast<f32x4*>(outf + ((long long)co * H + oy) * W + TW * j + 16 * m + 4 * kq) = v;
+      }
+    }
+  }
+#undef MSF_BX_ISSUE
+#undef MSF_BX_COMMIT
+}
+
 // ------------------------------------------------------------------ fused BasicBlock, 16 channels, stride 1 (layer2 @ 120 x 160)
 // The same scheme as k_block8 without row packing (the 16 MFMA columns are the 16 output channels): a workgroup owns a
 // band of R = 8 output rows and walks its x tiles of 32 columns; wave w takes M tile w & 1 (16 columns) of the t rows
@@ -1144,6 +1350,7 @@ struct ConvDesc {
   int cin, cout, ks, stride, hin, win, hout, wout;
   float* d_w = nullptr;   // [KSTEPS*4][NPAD]
   float* d_w2 = nullptr;  // row-packed variant (RP = 2) for the 8 -> 8 layers
+  uint16_t* d_wx = nullptr;  // split-bf16 fragments of the 8 -> 8 layers (k_block8x): [hi | lo][kx][lane][8]
   float* d_b = nullptr;   // [cout] or null
 };
 
@@ -1169,9 +1376,11 @@ struct LoftrPipeline::Impl {
   uint32_t* cand_cnt = nullptr;
   bool dense_head = false;
   bool fuse_blocks = true;   // MSF_LOFTR_UNFUSED=1: one kernel per convolution (tests: bit-identical results)
+  bool split_bf16 = true;    // MSF_LOFTR_F32=1: every convolution on the f32 MFMA (no split-bf16 kernels)
   bool keep_debug = false;   // MSF_FLAG_KEEP_DEBUG: pair 0's confidence matrix + features for the parity tests
   float* conf_dbg = nullptr; // [1200][1200]
   float* feat_dbg = nullptr; // [2][1200][32]
+  float* act_dbg[4] = {nullptr, nullptr, nullptr, nullptr};   // frame A of pair 0 after layer1..4: [8][240][320], [16][120][160], [32][60][80], [32][30][40]
   int dbg_pair = 0;
   bool have_dbg = false;
   std::vector<hipEvent_t> ev;  // start, backbone done, transformer done, head done
@@ -1219,6 +1428,7 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
   {
     if (const char* d = getenv("MSF_LOFTR_DENSE_HEAD")) P.dense_head = atoi(d) != 0;   // tests: force the dense head
     if (const char* d = getenv("MSF_LOFTR_UNFUSED")) P.fuse_blocks = atoi(d) == 0;
+    if (const char* d = getenv("MSF_LOFTR_F32")) P.split_bf16 = atoi(d) == 0;
     // pairs per backbone pass (activation working set: 19.7 MB per pair).  Whole launches of 512 images fill the 512
     // workgroup slots of the fused block kernels in whole rounds (64 pairs: conv stack 8.41 ms, 128: 8.15, 256: 8.07)
     const char* e = getenv("MSF_LOFTR_CHUNK");
@@ -1287,6 +1497,35 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
                 w2[(size_t)k * 16 + rs * 8 + co] = (*w)[(((size_t)co * c.cin + ci) * c.ks + ky) * c.ks + kx];
               }
       LF_TRY(upload(w2, &c.d_w2));
+    }
+    if (c.cout == 8 && c.cin == 8 && c.stride == 1) {
+      // k_block8x: element j of lane (idx = co + 8 rs, input row s) of fragment kx is w[co][ci = j][ky = s - rs][kx]
+      // (0 where output row rs does not see input row s), as hi = bf16(w) and lo = bf16(w - hi)
+      auto to_bf16 = [](float f) -> uint16_t {
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        u += 0x7FFFu + ((u >> 16) & 1u);      // round to nearest even (weights are finite)
+        return (uint16_t)(u >> 16);
+      };
+      auto from_bf16 = [](uint16_t h) -> float {
+        const uint32_t u = (uint32_t)h << 16;
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+      };
+      std::vector<uint16_t> wx(blk8x::WFRAG, 0);
+      for (int g = 0; g < 3; g++)
+        for (int l = 0; l < 64; l++)
+          for (int j = 0; j < 8; j++) {
+            const int co = l & 7, rs = (l >> 3) & 1, s = l >> 4, ky = s - rs;
+            const float v = (ky >= 0 && ky <= 2) ? (*w)[(((size_t)co * 8 + j) * 3 + ky) * 3 + g] : 0.f;
+            const uint16_t hi = to_bf16(v), lo = to_bf16(v - from_bf16(hi));
+            wx[((size_t)(0 * 3 + g) * 64 + l) * 8 + j] = hi;
+            wx[((size_t)(1 * 3 + g) * 64 + l) * 8 + j] = lo;
+          }
+      LF_TRY(hipMalloc(reinterpret_cast<void**>(&c.d_wx), wx.size() * sizeof(uint16_t)));
+      P.allocs.push_back(reinterpret_cast<float*>(c.d_wx));
+      LF_TRY(hipMemcpy(c.d_wx, wx.data(), wx.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     if (i < 20) {
       snprintf(nm, sizeof nm, "conv%02d.b", i);
@@ -1372,6 +1611,10 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
   }
   LF_TRY(dalloc(&P.conf_dbg, (size_t)NTOK * NTOK));
   LF_TRY(dalloc(&P.feat_dbg, (size_t)2 * NTOK * DM));
+  if (keep_debug) {
+    const size_t act_elems[4] = {8u * 240 * 320, 16u * 120 * 160, 32u * 60 * 80, 32u * 30 * 40};
+    for (int l = 0; l < 4; l++) LF_TRY(dalloc(&P.act_dbg[l], act_elems[l]));
+  }
   if (profile) {
     P.ev.resize(4);
     for (auto& e : P.ev) LF_TRY(hipEventCreate(&e));
@@ -1412,6 +1655,18 @@ void launch_block8(const ConvDesc& ca, const ConvDesc& cb, const float* in, floa
   const int n_bands = ca.hout / blk8::R;      // 240 / 8
   hipLaunchKernelGGL(k_block8, dim3(n_bands * n_img), dim3(256), lds, st, in, ca.d_w2, ca.d_b, cb.d_w2, cb.d_b, out, ca.hout,
                      ca.wout, n_bands);
+}
+
+// the same block on split-bf16 MFMAs (k_block8x)
+void launch_block8x(const ConvDesc& ca, const ConvDesc& cb, const float* in, float* out, int n_img, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_block8x), hipFuncAttributeMaxDynamicSharedMemorySize, blk8x::LDS_BYTES);
+    attr_set = true;
+  }
+  const int n_bands = ca.hout / blk8x::R;
+  hipLaunchKernelGGL(k_block8x, dim3(n_bands * n_img), dim3(256), blk8x::LDS_BYTES, st, in, ca.d_wx, ca.d_b, cb.d_wx, cb.d_b,
+                     out, ca.hout, ca.wout, n_bands);
 }
 
 // the same for a 16-channel, stride-1 BasicBlock at 120 x 160 (k_block16)
@@ -1502,14 +1757,23 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
   if (nB) launch_conv<1, 8, 7, 2, 64, true, false, true, 2>(c[0], srcB, frame_stride, row_stride, nullptr, a + (long long)nA * s8, nB, st);
   // layer1 @240x320, 8 ch
   if (P.fuse_blocks) {   // each BasicBlock in one kernel: the intermediate activation stays in LDS
-    launch_block8(c[1], c[2], a, cc, ni, st);
-    launch_block8(c[3], c[4], cc, a, ni, st);                                                        // a = 196
+    if (P.split_bf16) {
+      launch_block8x(c[1], c[2], a, cc, ni, st);
+      launch_block8x(c[3], c[4], cc, a, ni, st);                                                     // a = 196
+    } else {
+      launch_block8(c[1], c[2], a, cc, ni, st);
+      launch_block8(c[3], c[4], cc, a, ni, st);                                                      // a = 196
+    }
   } else {
     launch_conv<8, 8, 3, 1, 64, true, false, false, 2>(c[1], a, s8, 0, nullptr, b, ni, st);
     launch_conv<8, 8, 3, 1, 64, true, true, false, 2>(c[2], b, s8, 0, a, cc, ni, st);
     launch_conv<8, 8, 3, 1, 64, true, false, false, 2>(c[3], cc, s8, 0, nullptr, b, ni, st);
     launch_conv<8, 8, 3, 1, 64, true, true, false, 2>(c[4], b, s8, 0, cc, a, ni, st);                 // a = 196
   }
+  auto keep = [&](int l, const float* src, size_t elems) {   // MSF_FLAG_KEEP_DEBUG: the first image's activation
+    if (P.act_dbg[l]) hipMemcpyAsync(P.act_dbg[l], src, elems * sizeof(float), hipMemcpyDeviceToDevice, st);
+  };
+  keep(0, a, 8u * 240 * 320);
   // layer2 @120x160, 16 ch
   const long long s16 = 16LL * 120 * 160;
   launch_conv<8, 16, 3, 2, 32, true, false, false, 1, true>(c[5], a, s8, 0, nullptr, b, ni, st, &c[7], d);   // + shortcut -> d
@@ -1520,18 +1784,21 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
     launch_conv<16, 16, 3, 1, 32, true, false, false>(c[8], cc, s16, 0, nullptr, b, ni, st);
     launch_conv<16, 16, 3, 1, 32, true, true, false>(c[9], b, s16, 0, cc, a, ni, st);              // a = 212
   }
+  keep(1, a, 16u * 120 * 160);
   // layer3 @60x80, 32 ch
   const long long s32 = 32LL * 60 * 80;
   launch_conv<16, 32, 3, 2, 16, true, false, false, 1, true>(c[10], a, s16, 0, nullptr, b, ni, st, &c[12], d);
   launch_conv<32, 32, 3, 1, 16, true, true, false>(c[11], b, s32, 0, d, cc, ni, st);             // cc = 221
   launch_conv<32, 32, 3, 1, 16, true, false, false>(c[13], cc, s32, 0, nullptr, b, ni, st);
   launch_conv<32, 32, 3, 1, 16, true, true, false>(c[14], b, s32, 0, cc, a, ni, st);             // a = 228
+  keep(2, a, 32u * 60 * 80);
   // layer4 @30x40, 32 ch
   const long long s40 = 32LL * 30 * 40;
   launch_conv<32, 32, 3, 2, 16, true, false, false, 1, true>(c[15], a, s32, 0, nullptr, b, ni, st, &c[17], d);
   launch_conv<32, 32, 3, 1, 16, true, true, false>(c[16], b, s40, 0, d, cc, ni, st);             // cc = 237
   launch_conv<32, 32, 3, 1, 16, true, false, false>(c[18], cc, s40, 0, nullptr, b, ni, st);
   launch_conv<32, 32, 3, 1, 16, true, true, false>(c[19], b, s40, 0, cc, a, ni, st);             // a = 244
+  keep(3, a, 32u * 30 * 40);
   launch_conv<32, 32, 1, 1, 16, false, false, false>(c[20], a, s40, 0, nullptr, b, ni, st);      // b = 245
   if (nA) hipLaunchKernelGGL(k_tokens, dim3((nA * NTOK * DM + 255) / 256), dim3(256), 0, st, b, P.d_pe, tokA, nA);
   if (nB) hipLaunchKernelGGL(k_tokens, dim3((nB * NTOK * DM + 255) / 256), dim3(256), 0, st, b + (long long)nA * 32LL * 30 * 40, P.d_pe, tokB, nB);
@@ -1613,6 +1880,11 @@ int LoftrPipeline::debug_get(int what, int slot, int level, void* host_out, size
   size_t bytes = 0;
   if (what == MSF_DBG_LOFTR_CONF) { src = p_->conf_dbg; bytes = (size_t)NTOK * NTOK * 4; }
   else if (what == MSF_DBG_LOFTR_FEAT) { src = p_->feat_dbg; bytes = (size_t)2 * NTOK * DM * 4; }
+  else if (what == MSF_DBG_LOFTR_ACT && level >= 0 && level < 4 && p_->act_dbg[level]) {
+    const size_t act_elems[4] = {8u * 240 * 320, 16u * 120 * 160, 32u * 60 * 80, 32u * 30 * 40};
+    src = p_->act_dbg[level];
+    bytes = act_elems[level] * 4;
+  }
   else { *err = "unknown debug item for LoFTR"; return MSF_ERR_INVALID_ARG; }
   *n_bytes = bytes;
   const size_t n = bytes < cap ? bytes : cap;

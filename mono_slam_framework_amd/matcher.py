@@ -258,3 +258,8 @@ class DNNFeatureMatcher(_Matcher):
 
     def coarse_features(self, pair=0):
         return self._debug(_lib.DBG_LOFTR_FEAT, pair, 0, np.float32, 2 * 1200 * 32 * 4).reshape(2, 1200, 32)
+
+    def backbone_activation(self, stage):
+        """NCHW activation of the first frame of the last call after ResNet stage `stage` + 1 (MSF_FLAG_KEEP_DEBUG)"""
+        shape = [(8, 240, 320), (16, 120, 160), (32, 60, 80), (32, 30, 40)][stage]
+        return self._debug(_lib.DBG_LOFTR_ACT, 0, stage, np.float32, int(np.prod(shape)) * 4).reshape(shape)

@@ -200,33 +200,53 @@ def test_model_file_may_be_an_onnx_file(tmp_path):
     assert e.value.code == _lib.MSF_ERR_IO
 
 
-def test_fused_basic_blocks_equal_the_layer_by_layer_path():
-    """The two 8-channel BasicBlocks at 240x320 run as one kernel each (k_block8: the intermediate activation stays in
-    LDS).  Same f32 MFMA chains in the same k order: confidences and features are bit-identical to the path with one
-    kernel per convolution (MSF_LOFTR_UNFUSED=1, in a child process because the switch is read at msf_create)."""
+def _run_child(env_extra, seed=41):
+    """one pair through a fresh handle in a child process (the kernel switches are read at msf_create)"""
     import subprocess
     import sys
+    import tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = (
         "import numpy as np, sys\n"
         "sys.path.insert(0, %r)\n"
         "from mono_slam_framework_amd import synth\n"
         "from mono_slam_framework_amd.matcher import DNNFeatureMatcher\n"
-        "a, b = synth.synth_pair(41, 640, 480, mode=1, shift=(32, 16))\n"
+        "a, b = synth.synth_pair(%d, 640, 480, mode=1, shift=(32, 16))\n"
         "dm = DNNFeatureMatcher(threshold=0.15, flags=4 | 16)\n"
         "m = dm.MatchFrames(a, b, cap=8192)\n"
         "np.savez(sys.argv[1], m=m, conf=dm.conf_matrix(), feat=dm.coarse_features())\n"
-    ) % root
-    import tempfile
-    outs = []
-    for unfused in ("0", "1"):
-        f = tempfile.NamedTemporaryFile(suffix=".npz", delete=False).name
-        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, MSF_LOFTR_UNFUSED=unfused),
-                           capture_output=True, text=True)
-        assert r.returncode == 0, r.stdout + r.stderr
-        outs.append(np.load(f))
-        os.unlink(f)
+    ) % (root, seed)
+    f = tempfile.NamedTemporaryFile(suffix=".npz", delete=False).name
+    r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env_extra), capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = dict(np.load(f))
+    os.unlink(f)
+    return out
+
+
+def test_fused_basic_blocks_equal_the_layer_by_layer_path():
+    """f32 kernels (MSF_LOFTR_F32=1): the fused BasicBlocks (k_block8 at 240x320, k_block16 at 120x160: the intermediate
+    activation stays in LDS) run the same f32 MFMA chains in the same k order as one kernel per convolution
+    (MSF_LOFTR_UNFUSED=1): confidences and features are bit-identical."""
+    outs = [_run_child({"MSF_LOFTR_F32": "1", "MSF_LOFTR_UNFUSED": u}) for u in ("0", "1")]
     assert len(outs[0]["m"]) > 20
     np.testing.assert_array_equal(outs[0]["m"], outs[1]["m"])
     np.testing.assert_array_equal(outs[0]["feat"].view(np.uint32), outs[1]["feat"].view(np.uint32))
     np.testing.assert_array_equal(outs[0]["conf"].view(np.uint32), outs[1]["conf"].view(np.uint32))
+
+
+def test_split_bf16_blocks_stay_within_a_tenth_of_the_tolerance():
+    """Default path: the fused blocks run on bf16 MFMAs with every f32 operand split into hi + lo (three products,
+    f32 accumulation).  Against the all-f32 path (MSF_LOFTR_F32=1) confidences must agree to 1e-4 -- a tenth of the
+    north-star tolerance -- and the match lists wherever the f32 confidence is not within 1e-4 of the threshold."""
+    for seed in (41, 7):
+        x, f = _run_child({}, seed), _run_child({"MSF_LOFTR_F32": "1"}, seed)
+        dconf = np.abs(x["conf"] - f["conf"]).max()
+        dfeat = np.abs(x["feat"] - f["feat"]).max()
+        print("split-bf16 vs f32: max |dconf| %.3g, max |dfeat| %.3g" % (dconf, dfeat))
+        assert dconf <= 1e-4 and dfeat <= 1e-3
+        assert len(f["m"]) > 20
+        sure = np.argwhere(f["conf"] > 0.15 + 1e-4)
+        maybe = np.argwhere(f["conf"] > 0.15 - 1e-4)
+        cell = lambda m: set(((y1 // 16) * 40 + x1 // 16, (y2 // 16) * 40 + x2 // 16) for x1, y1, x2, y2 in m)
+        assert set(map(tuple, sure)) <= cell(x["m"]) <= set(map(tuple, maybe))
