@@ -676,6 +676,154 @@ __global__ __launch_bounds__(256, 2) void k_block8x(const float* __restrict__ in
 #undef MSF_BX_COMMIT
 }
 
+// ------------------------------------------------------------------ 3x3 stride-1 convolution, C -> C channels, split-bf16 MFMA
+// k_conv's tiling (a workgroup walks the 16-pixel x tiles of a band of output rows, the next tile's loads in flight)
+// with the arithmetic of k_block8x: operands split into bf16 hi + lo, three v_mfma_f32_16x16x32_bf16 per product.
+//  * LDS holds the input tile as planes of 8 channels: [hi | lo][channel block][row][pixel] x 16 bytes, so one
+//    ds_read_b128 is the fragment of (tap, channel block) for a lane's pixel; K = 32 of one MFMA = the 4 channel
+//    blocks of one tap (C = 32: lane group kq = channel block; 9 MFMA groups = the 9 taps).  A channel-block plane is
+//    a multiple of 16 pixels, so the two blocks a lane group reads fall on disjoint banks.
+//  * the packed weights ([tap][cout tile][hi | lo][lane], 36.9 KB for C = 32) are copied to LDS once per workgroup;
+//  * a wave computes output rows w and w + 4 of the band (8 rows), all C output channels: per tap 4 pixel + 4 weight
+//    fragment reads feed 12 MFMAs.
+// At 1/5 of the f32 MFMA time these layers run at their memory time.  Not bit-identical to k_conv (see k_block8x).
+namespace cvx {
+constexpr int OTW = 16, OTH = 8;
+constexpr int IN_H = OTH + 2, IN_W = OTW + 2;
+constexpr int PITCH = 24;                          // pixel slots per tile row (18 used)
+constexpr int CBPLANE = IN_H * PITCH;              // 240 = 15 x 16
+static_assert(CBPLANE % 16 == 0, "channel-block planes must be multiples of 16 pixel slots");
+template <int C>
+struct Cfg {
+  static_assert(C == 32, "k_convx: 32 channels");
+  static constexpr int NCB = C / 8, NT = C / 16, G = 9;
+  static constexpr int HLPLANE = NCB * CBPLANE;
+  static constexpr int XSLOTS = 2 * HLPLANE;
+  static constexpr int WSLOTS = G * NT * 2 * 64;   // 16-byte fragments: [tap][cout tile][hi | lo][lane]
+  static constexpr int LDS_BYTES = 16 * (XSLOTS + WSLOTS);
+  static constexpr int NITEMS = NCB * IN_H * IN_W;
+  static constexpr int NLD = (NITEMS + 255) / 256;
+};
+}  // namespace cvx
+
+template <int C, bool RES>
+__global__ __launch_bounds__(256, 2) void k_convx(const float* __restrict__ in, const uint16_t* __restrict__ wx,
+                                                  const float* __restrict__ bias, const float* __restrict__ res,
+                                                  float* __restrict__ out, int H, int W, int n_bands) {
+  using namespace cvx;
+  using F = Cfg<C>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  bf16x8* xs = reinterpret_cast<bf16x8*>(lds);
+  bf16x8* ws = xs + F::XSLOTS;
+  const int nwg = gridDim.x, per = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7;
+  const int unit = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);     // XCD-contiguous (image, band) order
+  const int img = unit / n_bands;
+  const int oy0 = (unit - img * n_bands) * OTH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const long long HW = (long long)H * W;
+  const float* inf = in + (long long)img * C * HW;
+
+  {  // the layer's weight fragments -> LDS
+    const bf16x8* src = reinterpret_cast<const bf16x8*>(wx);
+    for (int idx = tid; idx < F::WSLOTS; idx += 256) ws[idx] = src[idx];
+  }
+  // staging items: (channel block, tile row, tile column) -> 8 channel dwords of one pixel
+  constexpr int kNoRow = -(1 << 30);
+  float pre[F::NLD][8];
+  int goff[F::NLD], lslot[F::NLD], col[F::NLD];
+#pragma unroll
+  for (int u = 0; u < F::NLD; u++) {
+    const int idx = tid + 256 * u;
+    const int cb = idx / (IN_H * IN_W), rm = idx - cb * (IN_H * IN_W);
+    const int r = rm / IN_W, c = rm - r * IN_W;
+    const int gy = oy0 - 1 + r;
+    col[u] = c - 1;
+    lslot[u] = idx < F::NITEMS ? cb * CBPLANE + r * PITCH + c : -1;
+    goff[u] = (idx < F::NITEMS && gy >= 0 && gy < H) ? (8 * cb * H + gy) * W + c - 1 : kNoRow;
+  }
+#define MSF_CX_ISSUE(ox0_)                                                                        \
+  {                                                                                               \
+    _Pragma("unroll") for (int u = 0; u < F::NLD; u++) {                                          \
+      const int gx = (ox0_) + col[u];                                                             \
+      const bool ok = goff[u] != kNoRow && gx >= 0 && gx < W;                                     \
+      const float* src = inf + (ok ? goff[u] + (ox0_) : 0);                                       \
+      _Pragma("unroll") for (int c = 0; c < 8; c++) pre[u][c] = ok ? src[c * HW] : 0.f;           \
+    }                                                                                             \
+  }
+  const int ntx = (W + OTW - 1) / OTW;
+  MSF_CX_ISSUE(0)
+  for (int tx = 0; tx < ntx; tx++) {
+    const int ox0 = tx * OTW;
+    __syncthreads();                       // every wave is done reading the previous tile
+#pragma unroll
+    for (int u = 0; u < F::NLD; u++) {
+      if (lslot[u] < 0) continue;
+      bf16x8 vh, vl;
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        __bf16 a, b;
+        split_bf16(pre[u][c], a, b);
+        vh[c] = a; vl[c] = b;
+      }
+      xs[lslot[u]] = vh;
+      xs[F::HLPLANE + lslot[u]] = vl;
+    }
+    __syncthreads();
+    if (tx + 1 < ntx) MSF_CX_ISSUE(ox0 + OTW)
+
+    f32x4 acc[2][F::NT], rv[2][F::NT];
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+      for (int n = 0; n < F::NT; n++) {
+        acc[u][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        rv[u][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (RES) {      // residual operand: requested now, consumed after the MFMAs
+          const int oy = oy0 + wave + 4 * u, px = ox0 + 4 * kq;
+          if (oy < H && px < W)
+            rv[u][n] = *reinterpret_cast<const f32x4*>(res + (((long long)img * C + 16 * n + i) * H + oy) * W + px);
+        }
+      }
+    const int ab = kq * CBPLANE + wave * PITCH + i;
+#pragma unroll
+    for (int g = 0; g < F::G; g++) {
+      const int ky = g / 3, kx = g - 3 * ky;
+      bf16x8 bh[F::NT], bl[F::NT];
+#pragma unroll
+      for (int n = 0; n < F::NT; n++) {
+        bh[n] = ws[((g * F::NT + n) * 2 + 0) * 64 + lane];
+        bl[n] = ws[((g * F::NT + n) * 2 + 1) * 64 + lane];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int slot = ab + (4 * u + ky) * PITCH + kx;
+        const bf16x8 ah = xs[slot], al = xs[F::HLPLANE + slot];
+#pragma unroll
+        for (int n = 0; n < F::NT; n++) {
+          acc[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[u][n], 0, 0, 0);
+          acc[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[u][n], 0, 0, 0);
+          acc[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[u][n], 0, 0, 0);
+        }
+      }
+    }
+    // epilogue: D[pixel 4 kq + r][cout 16 n + i] -> out[img][cout][oy][4 consecutive px], + bias (+ residual), ReLU
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+      for (int n = 0; n < F::NT; n++) {
+        const int oy = oy0 + wave + 4 * u, px = ox0 + 4 * kq, co = 16 * n + i;
+        if (oy >= H || px >= W) continue;
+        const float bv = bias[co];
+        f32x4 v = acc[u][n] + f32x4{bv, bv, bv, bv};
+        if (RES) v += rv[u][n];
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        *reinterpret_cast<f32x4*>(out + (((long long)img * C + co) * H + oy) * W + px) = v;
+      }
+  }
+#undef MSF_CX_ISSUE
+}
+
 // ------------------------------------------------------------------ fused BasicBlock, 16 channels, stride 1 (layer2 @ 120 x 160)
 // The same scheme as k_block8 without row packing (the 16 MFMA columns are the 16 output channels): a workgroup owns a
 // band of R = 8 output rows and walks its x tiles of 32 columns; wave w takes M tile w & 1 (16 columns) of the t rows
@@ -1350,7 +1498,8 @@ struct ConvDesc {
   int cin, cout, ks, stride, hin, win, hout, wout;
   float* d_w = nullptr;   // [KSTEPS*4][NPAD]
   float* d_w2 = nullptr;  // row-packed variant (RP = 2) for the 8 -> 8 layers
-  uint16_t* d_wx = nullptr;  // split-bf16 fragments of the 8 -> 8 layers (k_block8x): [hi | lo][kx][lane][8]
+  uint16_t* d_wx = nullptr;  // split-bf16 fragments: 8 -> 8 layers (k_block8x) [hi | lo][kx][lane][8]; 32 -> 32 stride-1
+                             // layers (k_convx) [tap][cout tile][hi | lo][lane][8]
   float* d_b = nullptr;   // [cout] or null
 };
 
@@ -1498,21 +1647,27 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
               }
       LF_TRY(upload(w2, &c.d_w2));
     }
+    auto to_bf16 = [](float f) -> uint16_t {
+      uint32_t u;
+      memcpy(&u, &f, 4);
+      u += 0x7FFFu + ((u >> 16) & 1u);      // round to nearest even (weights are finite)
+      return (uint16_t)(u >> 16);
+    };
+    auto from_bf16 = [](uint16_t h) -> float {
+      const uint32_t u = (uint32_t)h << 16;
+      float f;
+      memcpy(&f, &u, 4);
+      return f;
+    };
+    auto upload16 = [&](const std::vector<uint16_t>& h, uint16_t** d) -> hipError_t {
+      hipError_t e = hipMalloc(reinterpret_cast<void**>(d), h.size() * sizeof(uint16_t));
+      if (e != hipSuccess) return e;
+      P.allocs.push_back(reinterpret_cast<float*>(*d));
+      return hipMemcpy(*d, h.data(), h.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    };
     if (c.cout == 8 && c.cin == 8 && c.stride == 1) {
       // k_block8x: element j of lane (idx = co + 8 rs, input row s) of fragment kx is w[co][ci = j][ky = s - rs][kx]
       // (0 where output row rs does not see input row s), as hi = bf16(w) and lo = bf16(w - hi)
-      auto to_bf16 = [](float f) -> uint16_t {
-        uint32_t u;
-        memcpy(&u, &f, 4);
-        u += 0x7FFFu + ((u >> 16) & 1u);      // round to nearest even (weights are finite)
-        return (uint16_t)(u >> 16);
-      };
-      auto from_bf16 = [](uint16_t h) -> float {
-        const uint32_t u = (uint32_t)h << 16;
-        float f;
-        memcpy(&f, &u, 4);
-        return f;
-      };
       std::vector<uint16_t> wx(blk8x::WFRAG, 0);
       for (int g = 0; g < 3; g++)
         for (int l = 0; l < 64; l++)
@@ -1523,9 +1678,24 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
             wx[((size_t)(0 * 3 + g) * 64 + l) * 8 + j] = hi;
             wx[((size_t)(1 * 3 + g) * 64 + l) * 8 + j] = lo;
           }
-      LF_TRY(hipMalloc(reinterpret_cast<void**>(&c.d_wx), wx.size() * sizeof(uint16_t)));
-      P.allocs.push_back(reinterpret_cast<float*>(c.d_wx));
-      LF_TRY(hipMemcpy(c.d_wx, wx.data(), wx.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+      LF_TRY(upload16(wx, &c.d_wx));
+    }
+    if (c.cout == 32 && c.cin == 32 && c.stride == 1 && c.ks == 3) {
+      // k_convx<32>: fragment (tap g, cout tile n, hi | lo): element j of lane (cout 16 n + (l & 15), channel block l >> 4)
+      // is w[cout][ci = 8 (l >> 4) + j][ky = g / 3][kx = g % 3]
+      using F = cvx::Cfg<32>;
+      std::vector<uint16_t> wx((size_t)F::WSLOTS * 8, 0);
+      for (int g = 0; g < F::G; g++)
+        for (int n = 0; n < F::NT; n++)
+          for (int l = 0; l < 64; l++)
+            for (int j = 0; j < 8; j++) {
+              const int co = 16 * n + (l & 15), ci = 8 * (l >> 4) + j;
+              const float v = (*w)[(((size_t)co * 32 + ci) * 3 + g / 3) * 3 + g % 3];
+              const uint16_t hi = to_bf16(v), lo = to_bf16(v - from_bf16(hi));
+              wx[((size_t)((g * F::NT + n) * 2 + 0) * 64 + l) * 8 + j] = hi;
+              wx[((size_t)((g * F::NT + n) * 2 + 1) * 64 + l) * 8 + j] = lo;
+            }
+      LF_TRY(upload16(wx, &c.d_wx));
     }
     if (i < 20) {
       snprintf(nm, sizeof nm, "conv%02d.b", i);
@@ -1669,6 +1839,21 @@ void launch_block8x(const ConvDesc& ca, const ConvDesc& cb, const float* in, flo
                      out, ca.hout, ca.wout, n_bands);
 }
 
+// 3x3 stride-1 C -> C convolution (+ residual) + ReLU on split-bf16 MFMAs (k_convx)
+template <int C, bool RES>
+void launch_convx(const ConvDesc& c, const float* in, const float* res, float* out, int n_img, hipStream_t st) {
+  using F = cvx::Cfg<C>;
+  auto kern = k_convx<C, RES>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, F::LDS_BYTES);
+    attr_set = true;
+  }
+  const int n_bands = (c.hout + cvx::OTH - 1) / cvx::OTH;
+  hipLaunchKernelGGL(kern, dim3(n_bands * n_img), dim3(256), F::LDS_BYTES, st, in, c.d_wx, c.d_b, res, out, c.hout, c.wout,
+                     n_bands);
+}
+
 // the same for a 16-channel, stride-1 BasicBlock at 120 x 160 (k_block16)
 void launch_block16(const ConvDesc& ca, const ConvDesc& cb, const float* in, float* out, int n_img, hipStream_t st) {
   const size_t lds = (size_t)blk16::LDS_FLOATS * sizeof(float);
@@ -1788,16 +1973,28 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
   // layer3 @60x80, 32 ch
   const long long s32 = 32LL * 60 * 80;
   launch_conv<16, 32, 3, 2, 16, true, false, false, 1, true>(c[10], a, s16, 0, nullptr, b, ni, st, &c[12], d);
-  launch_conv<32, 32, 3, 1, 16, true, true, false>(c[11], b, s32, 0, d, cc, ni, st);             // cc = 221
-  launch_conv<32, 32, 3, 1, 16, true, false, false>(c[13], cc, s32, 0, nullptr, b, ni, st);
-  launch_conv<32, 32, 3, 1, 16, true, true, false>(c[14], b, s32, 0, cc, a, ni, st);             // a = 228
+  if (P.split_bf16) {
+    launch_convx<32, true>(c[11], b, d, cc, ni, st);                                               // cc = 221
+    launch_convx<32, false>(c[13], cc, nullptr, b, ni, st);
+    launch_convx<32, true>(c[14], b, cc, a, ni, st);                                               // a = 228
+  } else {
+    launch_conv<32, 32, 3, 1, 16, true, true, false>(c[11], b, s32, 0, d, cc, ni, st);             // cc = 221
+    launch_conv<32, 32, 3, 1, 16, true, false, false>(c[13], cc, s32, 0, nullptr, b, ni, st);
+    launch_conv<32, 32, 3, 1, 16, true, true, false>(c[14], b, s32, 0, cc, a, ni, st);             // a = 228
+  }
   keep(2, a, 32u * 60 * 80);
   // layer4 @30x40, 32 ch
   const long long s40 = 32LL * 30 * 40;
   launch_conv<32, 32, 3, 2, 16, true, false, false, 1, true>(c[15], a, s32, 0, nullptr, b, ni, st, &c[17], d);
-  launch_conv<32, 32, 3, 1, 16, true, true, false>(c[16], b, s40, 0, d, cc, ni, st);             // cc = 237
-  launch_conv<32, 32, 3, 1, 16, true, false, false>(c[18], cc, s40, 0, nullptr, b, ni, st);
-  launch_conv<32, 32, 3, 1, 16, true, true, false>(c[19], b, s40, 0, cc, a, ni, st);             // a = 244
+  if (P.split_bf16) {
+    launch_convx<32, true>(c[16], b, d, cc, ni, st);                                               // cc = 237
+    launch_convx<32, false>(c[18], cc, nullptr, b, ni, st);
+    launch_convx<32, true>(c[19], b, cc, a, ni, st);                                               // a = 244
+  } else {
+    launch_conv<32, 32, 3, 1, 16, true, true, false>(c[16], b, s40, 0, d, cc, ni, st);             // cc = 237
+    launch_conv<32, 32, 3, 1, 16, true, false, false>(c[18], cc, s40, 0, nullptr, b, ni, st);
+    launch_conv<32, 32, 3, 1, 16, true, true, false>(c[19], b, s40, 0, cc, a, ni, st);             // a = 244
+  }
   keep(3, a, 32u * 30 * 40);
   launch_conv<32, 32, 1, 1, 16, false, false, false>(c[20], a, s40, 0, nullptr, b, ni, st);      // b = 245
   if (nA) hipLaunchKernelGGL(k_tokens, dim3((nA * NTOK * DM + 255) / 256), dim3(256), 0, st, b, P.d_pe, tokA, nA);
