@@ -676,6 +676,207 @@ __global__ __launch_bounds__(256, 2) void k_block8x(const float* __restrict__ in
 #undef MSF_BX_COMMIT
 }
 
+// ------------------------------------------------------------------ fused BasicBlock, 16 channels, split-bf16 MFMA
+// k_block16's tiling (bands of 8 rows, x tiles of 32 columns, wave = (M tile, row half), conv2 one tile behind conv1)
+// with the arithmetic and LDS layout of k_block8x / k_convx: planes [hi | lo][channel block of 8][row][pixel] x 16 B.
+// K = 32 of one MFMA = two taps x two channel blocks (lane group kq: tap 2g + (kq >> 1), channel block kq & 1; five
+// groups, the tenth tap has zero weights).  conv1 runs transposed (a lane holds 4 consecutive channels of one t pixel:
+// 8-byte stores), conv2 as k_block16.  Both convolutions' fragments (80 VGPRs) stay in registers.
+namespace blk16x {
+constexpr int R = 8, TW = 32;
+constexpr int XH = R + 4;                          // x rows oy0-2 .. oy0+9
+constexpr int XP = 36;                             // x row pitch in pixels (columns 32k-1 .. 32k+32 in slots 0 .. 33)
+constexpr int XCB = XH * XP;                       // 432 = 27 x 16: channel-block planes on disjoint banks
+constexpr int TROWS = R + 2;                       // t rows oy0-1 .. oy0+8
+constexpr int TP = 72;                             // two 32-pixel segments, halo pixels 64 / 65, zero pixel 66
+constexpr int TCB = TROWS * TP;                    // 720 = 45 x 16
+static_assert(XCB % 16 == 0 && TCB % 16 == 0, "channel-block planes must be multiples of 16 pixel slots");
+constexpr int G = 5;
+constexpr int LDS_BYTES = 16 * (4 * XCB + 4 * TCB);   // 73 728: two workgroups per CU
+constexpr int WFRAG = 2 * G * 64 * 8;              // bf16 elements of one convolution's fragments [hi | lo][g][lane][8]
+}  // namespace blk16x
+
+__global__ __launch_bounds__(256, 2) void k_block16x(const float* __restrict__ in, const uint16_t* __restrict__ wx1,
+                                                     const float* __restrict__ b1, const uint16_t* __restrict__ wx2,
+                                                     const float* __restrict__ b2, float* __restrict__ out, int H, int W,
+                                                     int n_bands) {
+  using namespace blk16x;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  bf16x8* xh = reinterpret_cast<bf16x8*>(lds);
+  bf16x8* xl = xh + 2 * XCB;
+  bf16x8* th = xl + 2 * XCB;
+  bf16x8* tl = th + 2 * TCB;
+  const int nwg = gridDim.x, per = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7;
+  const int unit = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);     // XCD-contiguous (image, band) order
+  const int img = unit / n_bands;
+  const int oy0 = (unit - img * n_bands) * R;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int m = wave & 1, hf = wave >> 1;           // M tile (16 pixels of the 32), row half
+  const long long HW = (long long)H * W;
+  const float* inf = in + (long long)img * 16 * HW;
+  float* outf = out + (long long)img * 16 * HW;
+
+  bf16x8 w1h[G], w1l[G], w2h[G], w2l[G];
+  {
+    const bf16x8* p1 = reinterpret_cast<const bf16x8*>(wx1);
+    const bf16x8* p2 = reinterpret_cast<const bf16x8*>(wx2);
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      w1h[g] = p1[g * 64 + lane]; w1l[g] = p1[(G + g) * 64 + lane];
+      w2h[g] = p2[g * 64 + lane]; w2l[g] = p2[(G + g) * 64 + lane];
+    }
+  }
+  const f32x4 bias1 = *reinterpret_cast<const f32x4*>(b1 + 4 * kq);          // conv1: lane = channels 4 kq .. +3 of one t pixel
+  const float bias2 = b2[i];                                                 // conv2: lane = channel i, 4 pixels
+  // halo pixels and the zero pixel of every t row, every plane
+  if (tid < 4 * TROWS) {
+    bf16x8* pl = th + (tid / TROWS) * TCB;          // th[cb 0], th[cb 1], tl[cb 0], tl[cb 1] are contiguous
+    const int r = tid % TROWS;
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; j++) z[j] = (__bf16)0.f;
+    pl[r * TP + 2 * TW] = z; pl[r * TP + 2 * TW + 1] = z; pl[r * TP + 2 * TW + 2] = z;
+  }
+
+  // x staging: item = 8 channel dwords of one pixel.  Items 0..2 of a thread: (channel block, row, column 1 + (tid & 31))
+  // with (block, row) = (tid >> 5) + 8u; item 3 (threads 0..47): the halo columns 0 and 33 of (block, row) = tid >> 1.
+  constexpr int kNoRow = -(1 << 30);
+  float pre[4][8];
+  int goff[4], lslot[4];
+#pragma unroll
+  for (int u = 0; u < 3; u++) {
+    const int br = (tid >> 5) + 8 * u, cb = br / XH, r = br - cb * XH;
+    const int gy = oy0 - 2 + r;
+    goff[u] = (gy >= 0 && gy < H) ? (8 * cb * H + gy) * W + (tid & 31) : kNoRow;
+    lslot[u] = cb * XCB + r * XP + (tid & 31) + 1;
+  }
+  const bool hcol = (tid & 1) != 0;                 // item 3: right halo column
+  {
+    const int br = tid >> 1, cb = br / XH, r = br - cb * XH;
+    const int gy = oy0 - 2 + r;
+    goff[3] = (tid < 4 * XH && gy >= 0 && gy < H) ? (8 * cb * H + gy) * W + (hcol ? TW : -1) : kNoRow;
+    lslot[3] = tid < 4 * XH ? cb * XCB + r * XP + (hcol ? TW + 1 : 0) : -1;
+  }
+  const int ntx = W / TW;
+#define MSF_BX_ISSUE(k_)                                                                          \
+  {                                                                                               \
+    _Pragma("unroll") for (int u = 0; u < 4; u++) {                                               \
+      bool ok = goff[u] != kNoRow;                                                                \
+      if (u == 3) ok = ok && (hcol ? (k_) + 1 < ntx : (k_) > 0);                                  \
+      const float* src = inf + (ok ? goff[u] : 0) + TW * (k_);                                    \
+      _Pragma("unroll") for (int c = 0; c < 8; c++) pre[u][c] = ok ? src[c * HW] : 0.f;           \
+    }                                                                                             \
+  }
+#define MSF_BX_COMMIT()                                                                           \
+  {                                                                                               \
+    _Pragma("unroll") for (int u = 0; u < 4; u++) {                                               \
+      if (lslot[u] < 0) continue;                                                                 \
+      bf16x8 vh, vl;                                                                              \
+      _Pragma("unroll") for (int c = 0; c < 8; c++) {                                             \
+        __bf16 a, b;                                                                              \
+        split_bf16(pre[u][c], a, b);                                                              \
+        vh[c] = a; vl[c] = b;                                                                     \
+      }                                                                                           \
+      xh[lslot[u]] = vh; xl[lslot[u]] = vl;                                                       \
+    }                                                                                             \
+  }
+  // this lane's tap of MFMA group g: 2 g + (kq >> 1) (the tenth tap has zero weights: any valid address), block kq & 1
+  int xoff[G], tky[G], tkx[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    int t = 2 * g + (kq >> 1);
+    t = t < 9 ? t : 8;
+    tky[g] = t / 3;
+    tkx[g] = t - 3 * tky[g];
+    xoff[g] = (kq & 1) * XCB + tky[g] * XP + tkx[g];
+  }
+  MSF_BX_ISSUE(0)
+  MSF_BX_COMMIT()
+  for (int k = 0; k <= ntx; k++) {
+    __syncthreads();
+    if (k + 1 < ntx) MSF_BX_ISSUE(k + 1)
+    if (k < ntx) {
+      // ---- conv1 of tile k, transposed: D[channel][pixel]; t rows 5 hf + u (u = 0..4), pixels 16m .. 16m+15
+      f32x4 acc[5];
+#pragma unroll
+      for (int u = 0; u < 5; u++) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int xb = 5 * hf * XP + 16 * m + i;
+#pragma unroll
+      for (int u = 0; u < 5; u++)
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+          const bf16x8 ph = xh[xb + u * XP + xoff[g]], pl = xl[xb + u * XP + xoff[g]];
+          acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1l[g], ph, acc[u], 0, 0, 0);
+          acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1h[g], pl, acc[u], 0, 0, 0);
+          acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1h[g], ph, acc[u], 0, 0, 0);
+        }
+      bf16x4* th4 = reinterpret_cast<bf16x4*>(th);
+      bf16x4* tl4 = reinterpret_cast<bf16x4*>(tl);
+#pragma unroll
+      for (int u = 0; u < 5; u++) {
+        const int tr = 5 * hf + u, gy = oy0 - 1 + tr;
+        f32x4 v = acc[u] + bias1;
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        if (gy < 0 || gy >= H) v = f32x4{0.f, 0.f, 0.f, 0.f};        // conv2 pads t with zeros
+        bf16x4 vh, vl;
+        __bf16 a, b;
+        split_bf16(v.x, a, b); vh[0] = a; vl[0] = b;
+        split_bf16(v.y, a, b); vh[1] = a; vl[1] = b;
+        split_bf16(v.z, a, b); vh[2] = a; vl[2] = b;
+        split_bf16(v.w, a, b); vh[3] = a; vl[3] = b;
+        const int slot = (kq >> 1) * TCB + tr * TP + (k & 1) * TW + 16 * m + i;   // channels 4 kq .. +3: block kq >> 1, half kq & 1
+        th4[2 * slot + (kq & 1)] = vh;
+        tl4[2 * slot + (kq & 1)] = vl;
+      }
+    }
+    __syncthreads();                       // t of tile k is complete; nobody reads the x tile any more
+    if (k + 1 < ntx) MSF_BX_COMMIT()
+    if (k >= 1 && k < ntx && tid < 4 * TROWS) {   // last pixel of tile k-1 -> the halo pixel conv2 of tile k reads
+      bf16x8* pl = th + (tid / TROWS) * TCB;
+      const int r = tid % TROWS;
+      pl[r * TP + 2 * TW + (k & 1)] = pl[r * TP + ((k - 1) & 1) * TW + TW - 1];
+    }
+    if (k >= 1) {
+      // ---- conv2 of tile j = k-1: output rows oy0 + 4 hf + u (u = 0..3), pixels 32j + 16m .. +15
+      const int j = k - 1;
+      f32x4 rv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++)     // residual = x (f32, from global / L2), requested before the MFMAs
+        rv[u] = *reinterpret_cast<const f32x4*>(inf + ((long long)i * H + (oy0 + 4 * hf + u)) * W + TW * j + 16 * m + 4 * kq);
+      int toff[G];
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        const int cr = 16 * m + i + tkx[g] - 1;                          // pixel inside the tile, -1 .. 32
+        const int cs = cr < 0 ? 2 * TW + (j & 1) : cr >= TW ? (k < ntx ? (k & 1) * TW : 2 * TW + 2) : (j & 1) * TW + cr;
+        toff[g] = (kq & 1) * TCB + (4 * hf + tky[g]) * TP + cs;
+      }
+      f32x4 acc[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+          const bf16x8 ah = th[toff[g] + u * TP], al = tl[toff[g] + u * TP];
+          acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, w2l[g], acc[u], 0, 0, 0);
+          acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, w2h[g], acc[u], 0, 0, 0);
+          acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, w2h[g], acc[u], 0, 0, 0);
+        }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int oy = oy0 + 4 * hf + u;
+        f32x4 v = acc[u] + f32x4{bias2, bias2, bias2, bias2};
+        v += rv[u];
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        *reinterpret_cast<f32x4*>(outf + ((long long)i * H + oy) * W + TW * j + 16 * m + 4 * kq) = v;
+      }
+    }
+  }
+#undef MSF_BX_ISSUE
+#undef MSF_BX_COMMIT
+}
+
 // ------------------------------------------------------------------ 3x3 stride-1 convolution, C -> C channels, split-bf16 MFMA
 // k_conv's tiling (a workgroup walks the 16-pixel x tiles of a band of output rows, the next tile's loads in flight)
 // with the arithmetic of k_block8x: operands split into bf16 hi + lo, three v_mfma_f32_16x16x32_bf16 per product.
@@ -1680,6 +1881,21 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
           }
       LF_TRY(upload16(wx, &c.d_wx));
     }
+    if (c.cout == 16 && c.cin == 16 && c.stride == 1) {
+      // k_block16x: fragment (hi | lo, g): element j of lane (cout l & 15, kq = l >> 4) is
+      // w[cout][ci = 8 (kq & 1) + j][tap 2 g + (kq >> 1)] (0 for the tenth tap)
+      std::vector<uint16_t> wx(blk16x::WFRAG, 0);
+      for (int g = 0; g < blk16x::G; g++)
+        for (int l = 0; l < 64; l++)
+          for (int j = 0; j < 8; j++) {
+            const int co = l & 15, q = l >> 4, t = 2 * g + (q >> 1), ci = 8 * (q & 1) + j;
+            const float v = t < 9 ? (*w)[(((size_t)co * 16 + ci) * 3 + t / 3) * 3 + t % 3] : 0.f;
+            const uint16_t hi = to_bf16(v), lo = to_bf16(v - from_bf16(hi));
+            wx[((size_t)(0 * blk16x::G + g) * 64 + l) * 8 + j] = hi;
+            wx[((size_t)(1 * blk16x::G + g) * 64 + l) * 8 + j] = lo;
+          }
+      LF_TRY(upload16(wx, &c.d_wx));
+    }
     if (c.cout == 32 && c.cin == 32 && c.stride == 1 && c.ks == 3) {
       // k_convx<32>: fragment (tap g, cout tile n, hi | lo): element j of lane (cout 16 n + (l & 15), channel block l >> 4)
       // is w[cout][ci = 8 (l >> 4) + j][ky = g / 3][kx = g % 3]
@@ -1839,6 +2055,18 @@ void launch_block8x(const ConvDesc& ca, const ConvDesc& cb, const float* in, flo
                      out, ca.hout, ca.wout, n_bands);
 }
 
+// the 16-channel BasicBlock on split-bf16 MFMAs (k_block16x)
+void launch_block16x(const ConvDesc& ca, const ConvDesc& cb, const float* in, float* out, int n_img, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_block16x), hipFuncAttributeMaxDynamicSharedMemorySize, blk16x::LDS_BYTES);
+    attr_set = true;
+  }
+  const int n_bands = ca.hout / blk16x::R;
+  hipLaunchKernelGGL(k_block16x, dim3(n_bands * n_img), dim3(256), blk16x::LDS_BYTES, st, in, ca.d_wx, ca.d_b, cb.d_wx, cb.d_b,
+                     out, ca.hout, ca.wout, n_bands);
+}
+
 // 3x3 stride-1 C -> C convolution (+ residual) + ReLU on split-bf16 MFMAs (k_convx)
 template <int C, bool RES>
 void launch_convx(const ConvDesc& c, const float* in, const float* res, float* out, int n_img, hipStream_t st) {
@@ -1964,7 +2192,8 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
   launch_conv<8, 16, 3, 2, 32, true, false, false, 1, true>(c[5], a, s8, 0, nullptr, b, ni, st, &c[7], d);   // + shortcut -> d
   launch_conv<16, 16, 3, 1, 32, true, true, false>(c[6], b, s16, 0, d, cc, ni, st);              // cc = 205
   if (P.fuse_blocks) {
-    launch_block16(c[8], c[9], cc, a, ni, st);                                                     // a = 212
+    if (P.split_bf16) launch_block16x(c[8], c[9], cc, a, ni, st);                                  // a = 212
+    else launch_block16(c[8], c[9], cc, a, ni, st);
   } else {
     launch_conv<16, 16, 3, 1, 32, true, false, false>(c[8], cc, s16, 0, nullptr, b, ni, st);
     launch_conv<16, 16, 3, 1, 32, true, true, false>(c[9], b, s16, 0, cc, a, ni, st);              // a = 212
