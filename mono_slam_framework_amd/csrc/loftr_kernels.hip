@@ -589,12 +589,14 @@ __global__ __launch_bounds__(256, 2) void k_block8x(const float* __restrict__ in
       xh[slot] = vh; xl[slot] = vl;                                                               \
     }                                                                                             \
   }
+  // the loads of tile k+2 are issued right after tile k+1 went to LDS: they have conv2(k-1) and conv1(k+1) to land
+  // (these kernels run at memory speed: one convolution's MFMA time is shorter than a trip to HBM)
   MSF_BX_ISSUE(0)
   MSF_BX_COMMIT()
+  if (1 < ntx) MSF_BX_ISSUE(1)
   // iteration k: conv1 of tile k | barrier | x tile k+1 and the halo pixel into LDS, conv2 of tile k-1 (see k_block8)
   for (int k = 0; k <= ntx; k++) {
     __syncthreads();
-    if (k + 1 < ntx) MSF_BX_ISSUE(k + 1)
     if (k < ntx) {
       // ---- conv1 of tile k, transposed: D[channel + 8 row][pixel]; t rows 2u, 2u+1 (u = 0..4), pixels 16m .. 16m+15
       f32x4 acc[5];
@@ -631,6 +633,7 @@ __global__ __launch_bounds__(256, 2) void k_block8x(const float* __restrict__ in
     }
     __syncthreads();                       // t of tile k is complete; nobody reads the x tile any more
     if (k + 1 < ntx) MSF_BX_COMMIT()
+    if (k + 2 < ntx) MSF_BX_ISSUE(k + 2)
     if (k >= 1 && k < ntx && tid < 2 * TROWS) {   // last pixel of tile k-1 -> the halo pixel conv2 of tile k reads
       bf16x8* pl = tid < TROWS ? th : tl;
       const int r = tid < TROWS ? tid : tid - TROWS;
@@ -791,11 +794,13 @@ __global__ __launch_bounds__(256, 2) void k_block16x(const float* __restrict__ i
     tkx[g] = t - 3 * tky[g];
     xoff[g] = (kq & 1) * XCB + tky[g] * XP + tkx[g];
   }
+  // the loads of tile k+2 are issued right after tile k+1 went to LDS: they have conv2(k-1) and conv1(k+1) to land
+  // (these kernels run at memory speed: one convolution's MFMA time is shorter than a trip to HBM)
   MSF_BX_ISSUE(0)
   MSF_BX_COMMIT()
+  if (1 < ntx) MSF_BX_ISSUE(1)
   for (int k = 0; k <= ntx; k++) {
     __syncthreads();
-    if (k + 1 < ntx) MSF_BX_ISSUE(k + 1)
     if (k < ntx) {
       // ---- conv1 of tile k, transposed: D[channel][pixel]; t rows 5 hf + u (u = 0..4), pixels 16m .. 16m+15
       f32x4 acc[5];
@@ -832,6 +837,7 @@ __global__ __launch_bounds__(256, 2) void k_block16x(const float* __restrict__ i
     }
     __syncthreads();                       // t of tile k is complete; nobody reads the x tile any more
     if (k + 1 < ntx) MSF_BX_COMMIT()
+    if (k + 2 < ntx) MSF_BX_ISSUE(k + 2)
     if (k >= 1 && k < ntx && tid < 4 * TROWS) {   // last pixel of tile k-1 -> the halo pixel conv2 of tile k reads
       bf16x8* pl = th + (tid / TROWS) * TCB;
       const int r = tid % TROWS;
@@ -1769,7 +1775,7 @@ std::string default_weights() {
   } while (0)
 
 std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool profile, bool keep_debug,
-                                int extra_slots) {
+                                int extra_slots, bool f32_convs) {
   destroy();
   p_ = new Impl();
   Impl& P = *p_;
@@ -1778,6 +1784,7 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
   {
     if (const char* d = getenv("MSF_LOFTR_DENSE_HEAD")) P.dense_head = atoi(d) != 0;   // tests: force the dense head
     if (const char* d = getenv("MSF_LOFTR_UNFUSED")) P.fuse_blocks = atoi(d) == 0;
+    P.split_bf16 = !f32_convs;
     if (const char* d = getenv("MSF_LOFTR_F32")) P.split_bf16 = atoi(d) == 0;
     // pairs per backbone pass (activation working set: 19.7 MB per pair).  Whole launches of 512 images fill the 512
     // workgroup slots of the fused block kernels in whole rounds (64 pairs: conv stack 8.41 ms, 128: 8.15, 256: 8.07)

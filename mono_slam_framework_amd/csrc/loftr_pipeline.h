@@ -18,7 +18,9 @@ class LoftrPipeline {
   ~LoftrPipeline();
   // returns empty string on success; "io: ..." for weight-file problems
   // extra_slots: token slots beyond the 2 * max_pairs caller-visible ones (the handle's transparent frame cache)
-  std::string init(const char* weights_path, int max_pairs, bool profile, bool keep_debug, int extra_slots = 0);
+  // f32_convs: MSF_FLAG_LOFTR_F32 (no split-bf16 kernels)
+  std::string init(const char* weights_path, int max_pairs, bool profile, bool keep_debug, int extra_slots = 0,
+                   bool f32_convs = false);
   void destroy();
   hipError_t match(int n_pairs, const uint8_t* d_a, const uint8_t* d_b, long long frame_stride, int row_stride,
                    float threshold, msf_match* d_out, int cap_per_pair, int32_t* d_n_out, hipStream_t st);

@@ -347,7 +347,8 @@ int msf_create(const msf_config* cfg, msf_handle** out) {
           return fail(nullptr, MSF_ERR_UNSUPPORTED, "LoFTR_teacher is a fixed-shape 1x1x480x640 graph (model/LoFTR_teacher.onnx)");
       }
       h->fc_slot0 = 2 * cfg->max_batch_pairs;
-      err = h->loftr.init(cfg->weights_path, cfg->max_batch_pairs, profile, (cfg->flags & MSF_FLAG_KEEP_DEBUG) != 0, n_cache);
+      err = h->loftr.init(cfg->weights_path, cfg->max_batch_pairs, profile, (cfg->flags & MSF_FLAG_KEEP_DEBUG) != 0, n_cache,
+                          (cfg->flags & MSF_FLAG_LOFTR_F32) != 0);
     }
     if (!err.empty()) {
       const bool io = err.rfind("io:", 0) == 0, arg = err.rfind("arg:", 0) == 0;
