@@ -475,14 +475,19 @@ __global__ __launch_bounds__(256) void k_block8(const float* __restrict__ in, co
 // hi = bf16(v) and lo = bf16(v - hi): v * w = hi*whi + hi*wlo + lo*whi + O(2^-16 |v w|), three MFMAs accumulating in
 // f32.  One MFMA spans K = 32 = 4 input rows x 8 channels of one kx (row packing as in k_block8: the 16 output columns
 // are 8 channels of two adjacent rows), so a 3 x 3 x 8 convolution of a row pair is 3 (kx) x 3 (products) MFMAs of
-// 16 cycles instead of 24 of 32: the block is no longer MFMA-bound but streams at its HBM time.
+// 16 cycles instead of 24 of 32: the block is no longer MFMA-bound but runs at memory speed (all its MFMAs together
+// are 10 % of its time), so the structure minimises traffic and exposed latency instead of matrix work:
 //  * activations live in LDS channels-last, as two planes (hi, lo) of 16-byte pixels (8 x bf16): one ds_read_b128 is
 //    one operand fragment (lane = pixel i of the M tile and input row kq); row pitches are multiples of 16 pixels so
 //    the two input rows a lane group reads fall on disjoint banks;
+//  * conv1 produces t for the tile AND its two halo columns (66 columns = 5 M tiles, the fifth nearly empty: cheap at
+//    this MFMA rate), so conv2 of the same tile follows directly -- no lag, no halo hand-over, one t segment;
 //  * conv1 runs transposed (A = weights, B = pixels): a lane then holds 4 consecutive channels of one t pixel, i.e.
 //    one 8-byte store per plane; conv2 runs as in k_block8 (A = pixels, B = weights): 4 consecutive pixels of one
 //    output channel per lane, float4 stores to NCHW;
-//  * the x tile is fetched as one dword per (pixel, channel) -- lanes along x, coalesced -- and split on the way in.
+//  * the x tile is fetched as one dword per (pixel, channel) -- lanes along x, coalesced -- two tiles ahead, and split
+//    on the way into LDS; the residual operand (x again, as f32) is requested right behind the tile's own loads, while
+//    its lines are still in L2 (requested when conv2 needs it, it missed: 185 of 900 us per 512 images).
 // Not bit-identical to the f32 path: |error| <= ~2^-15 of the operand products per convolution; the f32 kernels
 // remain behind MSF_FLAG_LOFTR_F32 / MSF_LOFTR_F32=1 (tests compare the two and the ONNX golden).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -491,12 +496,13 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 namespace blk8x {
 constexpr int R = 8, TW = 64;
 constexpr int XH = R + 4;                          // x rows oy0-2 .. oy0+9
-constexpr int XP = 80;                             // x row pitch in pixels (columns 64k-1 .. 64k+64 used): multiple of 16
+constexpr int XP = 96;                             // x row pitch in pixels: columns 64k-2 .. 64k+65 in slots 0 .. 67; conv1's
+                                                   // fifth M tile reads up to slot 81 (values unused); multiple of 16
 constexpr int XPLANE = XH * XP;
 constexpr int TROWS = R + 2;                       // t rows oy0-1 .. oy0+8
-constexpr int TP = 144;                            // two 64-pixel segments, halo pixels 128 / 129, zero pixel 130
+constexpr int TP = 80;                             // t columns 64k-1 .. 64k+64 in slots 0 .. 65 (5 M tiles written)
 constexpr int TPLANE = TROWS * TP;
-constexpr int LDS_BYTES = 16 * (2 * XPLANE + 2 * TPLANE);   // 76 800: two workgroups per CU
+constexpr int LDS_BYTES = 16 * (2 * XPLANE + 2 * TPLANE);   // 62 464: two workgroups per CU
 constexpr int WFRAG = 2 * 3 * 64 * 8;              // bf16 elements of one convolution's packed weights [hi|lo][kx][lane][8]
 }  // namespace blk8x
 
@@ -522,6 +528,7 @@ __global__ __launch_bounds__(256, 2) void k_block8x(const float* __restrict__ in
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int m = wave;                              // this wave's M tile (16 pixels) of every row pair
+  const int rowsel = i >> 3, co = i & 7;           // conv2: MFMA column -> (row of the pair, output channel)
   const long long HW = (long long)H * W;
   const float* inf = in + (long long)img * 8 * HW;
   float* outf = out + (long long)img * 8 * HW;
@@ -538,39 +545,29 @@ __global__ __launch_bounds__(256, 2) void k_block8x(const float* __restrict__ in
     }
   }
   const f32x4 bias1 = *reinterpret_cast<const f32x4*>(b1 + 4 * (kq & 1));   // conv1: lane = 4 channels of one t pixel
-  const float bias2 = b2[i & 7];                                             // conv2: lane = one channel, 4 pixels
-  // halo pixels and the zero pixel of every t row (halo of tile 0 = padding)
-  if (tid < 2 * TROWS) {
-    bf16x8* pl = tid < TROWS ? th : tl;
-    const int r = tid < TROWS ? tid : tid - TROWS;
-    bf16x8 z;
-#pragma unroll
-    for (int j = 0; j < 8; j++) z[j] = (__bf16)0.f;
-    pl[r * TP + 128] = z; pl[r * TP + 129] = z; pl[r * TP + 130] = z;
-  }
+  const float bias2 = b2[co];                                               // conv2: lane = one channel, 4 pixels
 
-  // x staging: item = one pixel (8 channel dwords).  Items 0..2 of a thread: row (tid >> 6) + 4u, column (tid & 63) + 1
-  // (image column 64k + (tid & 63): always inside); item 3 (threads 0..23): the two halo columns 0 and 65.
-  float pre[4][8];
+  // x staging: item = one pixel (8 channel dwords).  Items 0..2 of a thread: row (tid >> 6) + 4u, slot (tid & 63) + 2
+  // (image column 64k + (tid & 63): always inside); item 3 (threads 0..47): the four halo columns, slots 0, 1, 66, 67.
   constexpr int kNoRow = -(1 << 30);
-  int goff[4];                                     // gy * W + column offset inside the tile window (>= -1), or kNoRow
-  bool hcol = false;                               // item 3: right halo column
+  float pre[4][8];
+  int goff[4];                                     // gy * W + column offset inside the tile window (>= -2), or kNoRow
+  const int hc = tid & 3;                          // item 3: halo column 0..3
 #pragma unroll
   for (int u = 0; u < 3; u++) {
     const int gy = oy0 - 2 + (tid >> 6) + 4 * u;
     goff[u] = (gy >= 0 && gy < H) ? gy * W + (tid & 63) : kNoRow;
   }
   {
-    const int gy = oy0 - 2 + (tid >> 1);
-    hcol = (tid & 1) != 0;
-    goff[3] = (tid < 2 * XH && gy >= 0 && gy < H) ? gy * W + (hcol ? TW : -1) : kNoRow;
+    const int gy = oy0 - 2 + (tid >> 2);
+    goff[3] = (tid < 4 * XH && gy >= 0 && gy < H) ? gy * W + (hc < 2 ? hc - 2 : TW + hc - 2) : kNoRow;
   }
   const int ntx = W / TW;
 #define MSF_BX_ISSUE(k_)                                                                          \
   {                                                                                               \
     _Pragma("unroll") for (int u = 0; u < 4; u++) {                                               \
       bool ok = goff[u] != kNoRow;                                                                \
-      if (u == 3) ok = ok && (hcol ? (k_) + 1 < ntx : (k_) > 0);                                  \
+      if (u == 3) ok = ok && (hc < 2 ? (k_) > 0 : (k_) + 1 < ntx);                                \
       const float* src = inf + (ok ? goff[u] : 0) + TW * (k_);                                    \
       _Pragma("unroll") for (int c = 0; c < 8; c++) pre[u][c] = ok ? src[c * HW] : 0.f;           \
     }                                                                                             \
@@ -578,8 +575,8 @@ __global__ __launch_bounds__(256, 2) void k_block8x(const float* __restrict__ in
 #define MSF_BX_COMMIT()                                                                           \
   {                                                                                               \
     _Pragma("unroll") for (int u = 0; u < 4; u++) {                                               \
-      if (u == 3 && tid >= 2 * XH) continue;                                                      \
-      const int slot = u < 3 ? ((tid >> 6) + 4 * u) * XP + (tid & 63) + 1 : (tid >> 1) * XP + (hcol ? TW + 1 : 0); \
+      if (u == 3 && tid >= 4 * XH) continue;                                                      \
+      const int slot = u < 3 ? ((tid >> 6) + 4 * u) * XP + (tid & 63) + 2 : (tid >> 2) * XP + (hc < 2 ? hc : TW + hc); \
       bf16x8 vh, vl;                                                                              \
       _Pragma("unroll") for (int c = 0; c < 8; c++) {                                             \
         __bf16 a, b;                                                                              \
@@ -589,44 +586,62 @@ __global__ __launch_bounds__(256, 2) void k_block8x(const float* __restrict__ in
       xh[slot] = vh; xl[slot] = vl;                                                               \
     }                                                                                             \
   }
-  // the loads of tile k+2 are issued right after tile k+1 went to LDS: they have conv2(k-1) and conv1(k+1) to land
-  // (these kernels run at memory speed: one convolution's MFMA time is shorter than a trip to HBM)
+  // residual operand of tile k_: 4 consecutive pixels of channel co, rows oy0 + 2u + rowsel
+#define MSF_BX_RV(dst_, k_)                                                                       \
+  _Pragma("unroll") for (int u = 0; u < 4; u++)                                                   \
+    dst_[u] = *reinterpret_cast<const f32x4*>(inf + ((long long)co * H + (oy0 + 2 * u + rowsel)) * W + TW * (k_) + 16 * m + 4 * kq);
+
+  f32x4 rv_cur[4], rv_nxt[4];
   MSF_BX_ISSUE(0)
+  MSF_BX_RV(rv_cur, 0)
   MSF_BX_COMMIT()
-  if (1 < ntx) MSF_BX_ISSUE(1)
-  // iteration k: conv1 of tile k | barrier | x tile k+1 and the halo pixel into LDS, conv2 of tile k-1 (see k_block8)
-  for (int k = 0; k <= ntx; k++) {
-    __syncthreads();
-    if (k < ntx) {
-      // ---- conv1 of tile k, transposed: D[channel + 8 row][pixel]; t rows 2u, 2u+1 (u = 0..4), pixels 16m .. 16m+15
+  if (1 < ntx) {
+    MSF_BX_ISSUE(1)
+    MSF_BX_RV(rv_nxt, 1)
+  }
+  bf16x4* th4 = reinterpret_cast<bf16x4*>(th);
+  bf16x4* tl4 = reinterpret_cast<bf16x4*>(tl);
+  for (int k = 0; k < ntx; k++) {
+    __syncthreads();                       // x tile k is in LDS; every wave is done with t of tile k-1
+    // ---- conv1 of tile k, transposed: D[channel + 8 row][pixel]; t rows 2u, 2u+1, t columns 16q .. 16q+15.
+    // Jobs (q, u): this wave's M tile q = m for u = 0..4, then the halo M tile q = 4 for u = m (wave 0 also u = 4).
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+      const int q = pass == 0 ? m : 4;
+      const int nu = pass == 0 ? 5 : (m == 0 ? 2 : 1);
       f32x4 acc[5];
 #pragma unroll
       for (int u = 0; u < 5; u++) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int xb = kq * XP + 16 * m + i;
+      const int xb = kq * XP + 16 * q + i;
 #pragma unroll
-      for (int u = 0; u < 5; u++)
+      for (int u = 0; u < 5; u++) {
+        if (u >= nu) break;
+        const int uu = pass == 0 ? u : (u == 0 ? m : 4);
 #pragma unroll
         for (int g = 0; g < 3; g++) {
-          const bf16x8 ph = xh[xb + 2 * u * XP + g], pl = xl[xb + 2 * u * XP + g];
+          const bf16x8 ph = xh[xb + 2 * uu * XP + g], pl = xl[xb + 2 * uu * XP + g];
           acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1l[g], ph, acc[u], 0, 0, 0);
           acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1h[g], pl, acc[u], 0, 0, 0);
           acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1h[g], ph, acc[u], 0, 0, 0);
         }
-      bf16x4* th4 = reinterpret_cast<bf16x4*>(th);
-      bf16x4* tl4 = reinterpret_cast<bf16x4*>(tl);
+      }
+      const int tc = 16 * q + i;                   // t column slot; image column 64k - 1 + tc
+      const int gx = TW * k - 1 + tc;
 #pragma unroll
       for (int u = 0; u < 5; u++) {
-        const int tr = 2 * u + (kq >> 1), gy = oy0 - 1 + tr;
+        if (u >= nu) break;
+        const int uu = pass == 0 ? u : (u == 0 ? m : 4);
+        const int tr = 2 * uu + (kq >> 1), gy = oy0 - 1 + tr;
         f32x4 v = acc[u] + bias1;
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        if (gy < 0 || gy >= H) v = f32x4{0.f, 0.f, 0.f, 0.f};        // conv2 pads t with zeros
+        if (gy < 0 || gy >= H || gx < 0 || gx >= W) v = f32x4{0.f, 0.f, 0.f, 0.f};   // conv2 pads t with zeros
         bf16x4 vh, vl;
         __bf16 a, b;
         split_bf16(v.x, a, b); vh[0] = a; vl[0] = b;
         split_bf16(v.y, a, b); vh[1] = a; vl[1] = b;
         split_bf16(v.z, a, b); vh[2] = a; vl[2] = b;
         split_bf16(v.w, a, b); vh[3] = a; vl[3] = b;
-        const int slot = tr * TP + (k & 1) * TW + 16 * m + i;
+        const int slot = tr * TP + tc;
         th4[2 * slot + (kq & 1)] = vh;
         tl4[2 * slot + (kq & 1)] = vl;
       }
@@ -634,33 +649,17 @@ __global__ __launch_bounds__(256, 2) void k_block8x(const float* __restrict__ in
     __syncthreads();                       // t of tile k is complete; nobody reads the x tile any more
     if (k + 1 < ntx) MSF_BX_COMMIT()
     if (k + 2 < ntx) MSF_BX_ISSUE(k + 2)
-    if (k >= 1 && k < ntx && tid < 2 * TROWS) {   // last pixel of tile k-1 -> the halo pixel conv2 of tile k reads
-      bf16x8* pl = tid < TROWS ? th : tl;
-      const int r = tid < TROWS ? tid : tid - TROWS;
-      pl[r * TP + 128 + (k & 1)] = pl[r * TP + ((k - 1) & 1) * TW + TW - 1];
-    }
-    if (k >= 1) {
-      // ---- conv2 of tile j = k-1: output rows oy0 + 2u, +1 (u = 0..3), pixels 64j + 16m .. +15
-      const int j = k - 1;
-      const int rowsel = i >> 3, co = i & 7;
-      f32x4 rv[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++)     // residual = x (f32, from global / L2), requested before the MFMAs
-        rv[u] = *reinterpret_cast<const f32x4*>(inf + ((long long)co * H + (oy0 + 2 * u + rowsel)) * W + TW * j + 16 * m + 4 * kq);
-      int colslot[3];
-#pragma unroll
-      for (int g = 0; g < 3; g++) {
-        const int cr = 16 * m + i + g - 1;                               // pixel inside the tile, -1 .. 64
-        colslot[g] = kq * TP + (cr < 0 ? 128 + (j & 1) : cr >= TW ? (k < ntx ? (k & 1) * TW : 130) : (j & 1) * TW + cr);
-      }
+    {
+      // ---- conv2 of tile k: output rows oy0 + 2u, +1 (u = 0..3), pixels 64k + 16m .. +15 (t slots + 1)
       f32x4 acc[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int tb = kq * TP + 16 * m + i;
 #pragma unroll
       for (int u = 0; u < 4; u++)
 #pragma unroll
         for (int g = 0; g < 3; g++) {
-          const bf16x8 ah = th[colslot[g] + 2 * u * TP], al = tl[colslot[g] + 2 * u * TP];
+          const bf16x8 ah = th[tb + 2 * u * TP + g], al = tl[tb + 2 * u * TP + g];
           acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, w2l[g], acc[u], 0, 0, 0);
           acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, w2h[g], acc[u], 0, 0, 0);
           acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, w2h[g], acc[u], 0, 0, 0);
@@ -669,14 +668,18 @@ __global__ __launch_bounds__(256, 2) void k_block8x(const float* __restrict__ in
       for (int u = 0; u < 4; u++) {
         const int oy = oy0 + 2 * u + rowsel;
         f32x4 v = acc[u] + f32x4{bias2, bias2, bias2, bias2};
-        v += rv[u];
+        v += rv_cur[u];
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        *reinterpret_cast<f32x4*>(outf + ((long long)co * H + oy) * W + TW * j + 16 * m + 4 * kq) = v;
+        *reinterpret_cast<f32x4*>(outf + ((long long)co * H + oy) * W + TW * k + 16 * m + 4 * kq) = v;
       }
     }
+#pragma unroll
+    for (int u = 0; u < 4; u++) rv_cur[u] = rv_nxt[u];
+    if (k + 2 < ntx) { MSF_BX_RV(rv_nxt, k + 2) }
   }
 #undef MSF_BX_ISSUE
 #undef MSF_BX_COMMIT
+#undef MSF_BX_RV
 }
 
 // ------------------------------------------------------------------ fused BasicBlock, 16 channels, split-bf16 MFMA

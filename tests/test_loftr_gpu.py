@@ -214,7 +214,8 @@ def _run_child(env_extra, seed=41):
         "a, b = synth.synth_pair(%d, 640, 480, mode=1, shift=(32, 16))\n"
         "dm = DNNFeatureMatcher(threshold=0.15, flags=4 | 16)\n"
         "m = dm.MatchFrames(a, b, cap=8192)\n"
-        "np.savez(sys.argv[1], m=m, conf=dm.conf_matrix(), feat=dm.coarse_features())\n"
+        "np.savez(sys.argv[1], m=m, conf=dm.conf_matrix(), feat=dm.coarse_features(),"
+        " **{'act%%d' %% l: dm.backbone_activation(l) for l in range(4)})\n"
     ) % (root, seed)
     f = tempfile.NamedTemporaryFile(suffix=".npz", delete=False).name
     r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env_extra), capture_output=True, text=True)
@@ -245,6 +246,11 @@ def test_split_bf16_blocks_stay_within_a_tenth_of_the_tolerance():
         dfeat = np.abs(x["feat"] - f["feat"]).max()
         print("split-bf16 vs f32: max |dconf| %.3g, max |dfeat| %.3g" % (dconf, dfeat))
         assert dconf <= 1e-4 and dfeat <= 1e-3
+        # every ResNet stage's activation (MSF_DBG_LOFTR_ACT): a split product drops terms below 2^-16 of |x w|
+        for l in range(4):
+            d = np.abs(x["act%d" % l] - f["act%d" % l])
+            assert np.abs(f["act%d" % l]).max() > 1.0
+            assert d.max() <= 5e-4 and np.median(d) <= 2e-5, (l, d.max(), np.median(d))
         assert len(f["m"]) > 20
         sure = np.argwhere(f["conf"] > 0.15 + 1e-4)
         maybe = np.argwhere(f["conf"] > 0.15 - 1e-4)
