@@ -18,6 +18,8 @@
 #include <string.h>
 
 #include <map>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 namespace msf {
@@ -680,6 +682,218 @@ __global__ __launch_bounds__(256, 2) void k_block8x(const float* __restrict__ in
 #undef MSF_BX_ISSUE
 #undef MSF_BX_COMMIT
 #undef MSF_BX_RV
+}
+
+// ------------------------------------------------------------------ streaming 8-channel BasicBlocks (layer1), split-bf16 MFMA
+// k_block8x runs at memory speed, and what it moves is 1.5 x its input (row halos of 8-row bands) + the residual
+// operand + the output, once per block.  This kernel removes all of that but one read and one write for BOTH blocks of
+// layer1: a workgroup owns a 64-column strip of one image and walks it top to bottom two rows (one MFMA row pair) per
+// step, and every convolution stage keeps its last six row pairs in an LDS ring ([hi | lo] planes of 16-byte pixels
+// as in k_block8x).  The 2 NB convolutions are a software pipeline over the steps with ONE barrier per step: stage c
+// (waves 8 / NS * (c - 1) ...) works on pair n - 2c at step n, reading only what stage c-1 wrote in earlier steps:
+//   step n:  pair n of x -> ring 0 (fetched four steps ahead into a statically named register queue, one pixel = 8
+//            channel dwords per loader thread)
+//            stage 1: pair n-2 of t1 from pairs n-3 .. n-1 of x
+//            stage 2: pair n-4 of y1 from pairs n-5 .. n-3 of t1, + residual pair n-4 of x (still in ring 0, hi + lo)
+//            stage 3: pair n-6 of t2 from y1,  stage 4: pair n-8 of y2 from t2 + residual y1 -> global memory
+// No row is fetched or computed twice, no intermediate leaves LDS; only the strip's halo columns (2 NB each side) are
+// recomputed.  All stages run transposed (A = weights, B = pixels): a lane holds 4 consecutive channels of one pixel,
+// i.e. one 8-byte LDS access per plane for ring writes and residual reads; the last stage stores dwords (16 lanes = 64
+// contiguous bytes per channel row).  A wave holds only its own stage's weight fragments (24 VGPRs).
+namespace strip8 {
+constexpr int S = 64;                              // output columns per strip
+constexpr int XP = 72;                             // ring row pitch in pixels (widest ring: 64 + 2 * 4 columns)
+constexpr int RROWS = 12;                          // six row pairs per ring (five are live in a step)
+constexpr int RING = RROWS * XP;                   // pixel slots per plane
+constexpr int TAIL = 16;                           // the fifth M tile of a stage reads up to 10 slots past a ring row
+constexpr int WAVES = 8;
+template <int NB>
+constexpr int lds_bytes() { return 16 * (2 * NB * 2 * RING + TAIL); }
+__device__ __forceinline__ int ring_row(int r) {   // r mod 12 for r >= -24 (multiply-shift exact below 1200)
+  const int x = r + 24;
+  return x - 12 * ((x * 2731) >> 15);
+}
+}  // namespace strip8
+
+struct StripW {
+  const uint16_t* wx[4];
+  const float* b[4];
+};
+
+template <int NB>
+__global__ __launch_bounds__(64 * strip8::WAVES) void k_strip8x(const float* __restrict__ in, StripW sw, float* __restrict__ out,
+                                                                int H, int W, int n_strips) {
+  using namespace strip8;
+  constexpr int NS = 2 * NB;                       // convolution stages
+  constexpr int WPS = WAVES / NS;                  // waves per stage
+  constexpr int MAXJOBS = (5 + WPS - 1) / WPS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  bf16x8* ring = reinterpret_cast<bf16x8*>(lds);   // ring c (c = 0: x): hi plane at c * 2 RING, lo plane RING behind it
+  const int nwg = gridDim.x, per = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7;
+  const int unit = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);     // XCD-contiguous (image, strip) order
+  const int img = __builtin_amdgcn_readfirstlane(unit / n_strips);              // SGPRs: uniform base pointers below
+  const int X0 = __builtin_amdgcn_readfirstlane((unit - img * n_strips) * S);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int HW = H * W;                            // one image is 8 HW floats: 32-bit offsets from wave-uniform bases
+  const float* inf = in + (long long)img * 8 * HW;                  // SGPR bases: loads / stores take a 32-bit lane offset
+  float* outf = out + (long long)img * 8 * HW;
+  const int npairs = H / 2;
+  // this wave's stage (1-based) and its share of the stage's M tiles
+  const int cst = __builtin_amdgcn_readfirstlane(wave / WPS) + 1, ws = __builtin_amdgcn_readfirstlane(wave % WPS);
+  const bool last = cst == NS, has_res = (cst & 1) == 0;
+  const int MT = last ? 4 : 5;                     // M tiles: 64 (+ 2 (NS - c) halo) columns
+
+  bf16x8 wh[3], wl[3];
+  {
+    const bf16x8* pw = reinterpret_cast<const bf16x8*>(sw.wx[cst - 1]);
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+      wh[g] = pw[g * 64 + lane];
+      wl[g] = pw[(3 + g) * 64 + lane];
+    }
+  }
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(sw.b[cst - 1] + 4 * (kq & 1));   // lane = channels 4 (kq & 1) .. +3
+  {  // rows above the image (pair -1) and everything a stage has not written yet read as zero
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; j++) z[j] = (__bf16)0.f;
+    for (int idx = tid; idx < NS * 2 * RING + TAIL; idx += 64 * WAVES) ring[idx] = z;
+  }
+  // x loader (the last 2 XW threads of the workgroup: the waves with the fewest M tiles): thread (row lr of the pair,
+  // ring column lc) fetches one pixel = 8 channel dwords per step
+  constexpr int XW = S + 2 * NS;
+  const int ltid = tid - (64 * WAVES - 2 * XW);
+  const bool ld = ltid >= 0;
+  const int lr = ld ? ltid / XW : 0, lc = ld ? ltid - lr * XW : 0;
+  const int lgx = X0 - NS + lc;
+  const bool colok = ld && lgx >= 0 && lgx < W;
+  const uint32_t lofs = colok ? (uint32_t)lgx : 0u;
+  const bool ldwave = wave >= (64 * WAVES - 2 * XW) / 64;        // wave-uniform: waves with loader threads
+  // The loads of a step are consumed four steps later.  The compiler's s_waitcnt insertion only keeps that distance if
+  // every path between issue and use issues the same loads: no guard around an issue (addresses are clamped to valid
+  // ones instead, the value is discarded at commit time), and loader and non-loader waves run separate copies of the
+  // step loop (with a per-wave `if` around the issue it waited for vmcnt(0) at every step).
+#define MSF_ST_ISSUE(q_, n_)                                                                      \
+  {                                                                                               \
+    const int gy = 2 * (n_) + lr;                                                                 \
+    const bool ok = colok && gy < H;                                                              \
+    const uint32_t so = ok ? 4u * (lofs + (uint32_t)(gy * W)) : 0u;   /* byte offset from the SGPR base */ \
+    _Pragma("unroll") for (int c = 0; c < 8; c++)                                                 \
+      q_[c] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(inf) + (so + 4u * (uint32_t)(c * HW))); \
+  }
+#define MSF_ST_COMMIT(q_, n_)                                                                     \
+  if (ld) {                                                                                       \
+    const bool ok = colok && 2 * (n_) + lr < H;   /* outside the image: the (valid-address) load is discarded */ \
+    bf16x8 vh, vl;                                                                                \
+    _Pragma("unroll") for (int c = 0; c < 8; c++) {                                               \
+      __bf16 a, b;                                                                                \
+      split_bf16(ok ? q_[c] : 0.f, a, b);                                                         \
+      vh[c] = a; vl[c] = b;                                                                       \
+    }                                                                                             \
+    const int slot = ring_row(2 * (n_) + lr) * XP + lc;                                           \
+    ring[slot] = vh; ring[RING + slot] = vl;                                                      \
+  }
+  // this wave's stage makes pair p of ring cst (or of the output) from pairs p-1 .. p+1 of ring cst-1
+  const bf16x8* inh = ring + (cst - 1) * 2 * RING;
+  const bf16x8* inl = inh + RING;
+  const bf16x4* resh = reinterpret_cast<const bf16x4*>(ring + (has_res ? cst - 2 : 0) * 2 * RING);
+  const bf16x4* resl = resh + 2 * RING;
+  bf16x4* outh = reinterpret_cast<bf16x4*>(ring + (last ? 0 : cst) * 2 * RING);
+  bf16x4* outl = outh + 2 * RING;
+  auto stage = [&](int p) {
+    const int rin = ring_row(2 * p - 1 + kq) * XP;        // fragment row of this lane group
+    const int orow = 2 * p + (kq >> 1);                    // D[channel + 8 row][pixel]: this lane's output row
+    const int ror = ring_row(orow) * XP;
+    f32x4 acc[MAXJOBS];
+#pragma unroll
+    for (int jb = 0; jb < MAXJOBS; jb++) {
+      acc[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int q = ws + WPS * jb;
+      if (q < MT && p < npairs) {
+        const int rb = rin + 16 * q + i;
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+          const bf16x8 ph = inh[rb + g], pl = inl[rb + g];
+          acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[g], ph, acc[jb], 0, 0, 0);
+          acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g], pl, acc[jb], 0, 0, 0);
+          acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g], ph, acc[jb], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int jb = 0; jb < MAXJOBS; jb++) {
+      const int q = ws + WPS * jb;
+      if (q >= MT) continue;
+      const int j = 16 * q + i;                    // this lane's pixel slot in the stage's output geometry
+      f32x4 v = acc[jb] + bias;
+      if (has_res) {                               // second convolution of a block: + block input (ring cst-2, slot j + 2)
+        const int rs = 2 * (ror + j + 2) + (kq & 1);
+        const bf16x4 a = resh[rs], b = resl[rs];
+        v.x += (float)a[0] + (float)b[0]; v.y += (float)a[1] + (float)b[1];
+        v.z += (float)a[2] + (float)b[2]; v.w += (float)a[3] + (float)b[3];
+      }
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      if (last) {
+        if (p < npairs) {
+          const uint32_t oo = 4u * (uint32_t)((4 * (kq & 1) * H + orow) * W + X0 + j);   // byte offset from the SGPR base
+          char* ob = reinterpret_cast<char*>(outf);
+          *reinterpret_cast<float*>(ob + oo) = v.x;
+          *reinterpret_cast<float*>(ob + (oo + 4u * (uint32_t)HW)) = v.y;
+          *reinterpret_cast<float*>(ob + (oo + 8u * (uint32_t)HW)) = v.z;
+          *reinterpret_cast<float*>(ob + (oo + 12u * (uint32_t)HW)) = v.w;
+        }
+      } else {
+        const int gx = X0 - (NS - cst) + j;        // image column of slot j of ring cst
+        if (p >= npairs || gx < 0 || gx >= W) v = f32x4{0.f, 0.f, 0.f, 0.f};   // the next stage's zero padding
+        if (j < XP) {
+          bf16x4 vh, vl;
+          __bf16 a, b;
+          split_bf16(v.x, a, b); vh[0] = a; vl[0] = b;
+          split_bf16(v.y, a, b); vh[1] = a; vl[1] = b;
+          split_bf16(v.z, a, b); vh[2] = a; vl[2] = b;
+          split_bf16(v.w, a, b); vh[3] = a; vl[3] = b;
+          const int os = 2 * (ror + j) + (kq & 1);
+          outh[os] = vh; outl[os] = vl;
+        }
+      }
+    }
+  };
+  // one step: barrier (everything written in the previous step is visible; nothing read in it is overwritten before),
+  // pair n of x into its ring, the queue slot refilled with pair n+4, this wave's stage on pair n - 2 cst.  Steps past
+  // the last one (the count is rounded up to the unrolled four) find no pair to make and commit zero rows.
+#define MSF_ST_STEP(q_, n_)                                                                       \
+  {                                                                                               \
+    __syncthreads();                                                                              \
+    if (kLd) {                                                                                    \
+      MSF_ST_COMMIT(q_, n_)                                                                       \
+      MSF_ST_ISSUE(q_, (n_) + 4)                                                                  \
+    }                                                                                             \
+    const int p_ = (n_) - 2 * cst;                                                                \
+    if (p_ >= 0 && p_ <= npairs) stage(p_);                                                       \
+  }
+  const int nsteps = (npairs + 2 * NS + 3) & ~3;   // the last stage's last pair is made at step npairs - 1 + 2 NS
+  auto run = [&](auto is_loader) {
+    constexpr bool kLd = decltype(is_loader)::value;
+    float q0[8], q1[8], q2[8], q3[8];
+    if (kLd) {
+      MSF_ST_ISSUE(q0, 0)
+      MSF_ST_ISSUE(q1, 1)
+      MSF_ST_ISSUE(q2, 2)
+      MSF_ST_ISSUE(q3, 3)
+    }
+    for (int n = 0; n < nsteps; n += 4) {
+      MSF_ST_STEP(q0, n)
+      MSF_ST_STEP(q1, n + 1)
+      MSF_ST_STEP(q2, n + 2)
+      MSF_ST_STEP(q3, n + 3)
+    }
+  };
+  if (ldwave) run(std::true_type{});
+  else run(std::false_type{});
+#undef MSF_ST_ISSUE
+#undef MSF_ST_COMMIT
+#undef MSF_ST_STEP
 }
 
 // ------------------------------------------------------------------ fused BasicBlock, 16 channels, split-bf16 MFMA
@@ -1736,6 +1950,7 @@ struct LoftrPipeline::Impl {
   bool dense_head = false;
   bool fuse_blocks = true;   // MSF_LOFTR_UNFUSED=1: one kernel per convolution (tests: bit-identical results)
   bool split_bf16 = true;    // MSF_LOFTR_F32=1: every convolution on the f32 MFMA (no split-bf16 kernels)
+  int strip_mode = 1;        // MSF_LOFTR_STRIP: layer1 as streaming strips, 2 = both blocks in one pass, 0 = k_block8x
   bool keep_debug = false;   // MSF_FLAG_KEEP_DEBUG: pair 0's confidence matrix + features for the parity tests
   float* conf_dbg = nullptr; // [1200][1200]
   float* feat_dbg = nullptr; // [2][1200][32]
@@ -1789,6 +2004,7 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
     if (const char* d = getenv("MSF_LOFTR_UNFUSED")) P.fuse_blocks = atoi(d) == 0;
     P.split_bf16 = !f32_convs;
     if (const char* d = getenv("MSF_LOFTR_F32")) P.split_bf16 = atoi(d) == 0;
+    if (const char* d = getenv("MSF_LOFTR_STRIP")) P.strip_mode = atoi(d);
     // pairs per backbone pass (activation working set: 19.7 MB per pair).  Whole launches of 512 images fill the 512
     // workgroup slots of the fused block kernels in whole rounds (64 pairs: conv stack 8.41 ms, 128: 8.15, 256: 8.07)
     const char* e = getenv("MSF_LOFTR_CHUNK");
@@ -2065,6 +2281,23 @@ void launch_block8x(const ConvDesc& ca, const ConvDesc& cb, const float* in, flo
                      out, ca.hout, ca.wout, n_bands);
 }
 
+// NB chained 8-channel BasicBlocks as one streaming pass (k_strip8x): convolutions cv[0 .. 2 NB)
+template <int NB>
+void launch_strip8x(const ConvDesc* cv, const float* in, float* out, int n_img, hipStream_t st) {
+  auto kern = k_strip8x<NB>;
+  constexpr int lds = strip8::lds_bytes<NB>();
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  StripW sw{};
+  for (int c = 0; c < 2 * NB; c++) { sw.wx[c] = cv[c].d_wx; sw.b[c] = cv[c].d_b; }
+  const int n_strips = cv[0].wout / strip8::S;
+  hipLaunchKernelGGL(kern, dim3(n_strips * n_img), dim3(64 * strip8::WAVES), lds, st, in, sw, out, cv[0].hout, cv[0].wout,
+                     n_strips);
+}
+
 // the 16-channel BasicBlock on split-bf16 MFMAs (k_block16x)
 void launch_block16x(const ConvDesc& ca, const ConvDesc& cb, const float* in, float* out, int n_img, hipStream_t st) {
   static bool attr_set = false;
@@ -2180,7 +2413,13 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
   if (nB) launch_conv<1, 8, 7, 2, 64, true, false, true, 2>(c[0], srcB, frame_stride, row_stride, nullptr, a + (long long)nA * s8, nB, st);
   // layer1 @240x320, 8 ch
   if (P.fuse_blocks) {   // each BasicBlock in one kernel: the intermediate activation stays in LDS
-    if (P.split_bf16) {
+    if (P.split_bf16 && P.strip_mode == 2) {
+      launch_strip8x<2>(c + 1, a, cc, ni, st);                                                       // both blocks in one pass
+      std::swap(a, cc);                                                                              // a = 196
+    } else if (P.split_bf16 && P.strip_mode == 1) {
+      launch_strip8x<1>(c + 1, a, cc, ni, st);
+      launch_strip8x<1>(c + 3, cc, a, ni, st);                                                       // a = 196
+    } else if (P.split_bf16) {
       launch_block8x(c[1], c[2], a, cc, ni, st);
       launch_block8x(c[3], c[4], cc, a, ni, st);                                                     // a = 196
     } else {
