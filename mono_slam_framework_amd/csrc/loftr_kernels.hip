@@ -791,30 +791,31 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_strip8x(const float* __r
       split_bf16(ok ? q_[c] : 0.f, a, b);                                                         \
       vh[c] = a; vl[c] = b;                                                                       \
     }                                                                                             \
-    const int slot = ring_row(2 * (n_) + lr) * XP + lc;                                           \
-    ring[slot] = vh; ring[RING + slot] = vl;                                                      \
+    bf16x8* dst = ring + (crow + lc);                                                             \
+    dst[0] = vh; dst[RING] = vl;                                                                  \
   }
   // this wave's stage makes pair p of ring cst (or of the output) from pairs p-1 .. p+1 of ring cst-1
   const bf16x8* inh = ring + (cst - 1) * 2 * RING;
-  const bf16x8* inl = inh + RING;
   const bf16x4* resh = reinterpret_cast<const bf16x4*>(ring + (has_res ? cst - 2 : 0) * 2 * RING);
-  const bf16x4* resl = resh + 2 * RING;
   bf16x4* outh = reinterpret_cast<bf16x4*>(ring + (last ? 0 : cst) * 2 * RING);
-  bf16x4* outl = outh + 2 * RING;
+  // Ring rows advance by two per step: the row cursors (row * XP, modulo the ring) are carried from step to step
+  // instead of being re-derived (a multiply-shift modulo per cursor and step showed in the VALU-bound profile).
+  constexpr int RWRAP = RROWS * XP;
+  int crow = ring_row(lr) * XP;                    // loader: row 2n + lr
+  int rin = ring_row(-4 * cst - 1 + kq) * XP;      // stage: fragment row 2p - 1 + kq, p = n - 2 cst
+  int ror = ring_row(-4 * cst + (kq >> 1)) * XP;   // stage: output row 2p + (kq >> 1)
+  const bool edge = X0 == 0 || X0 + S == W;        // wave-uniform: only the outer strips have columns outside the image
   auto stage = [&](int p) {
-    const int rin = ring_row(2 * p - 1 + kq) * XP;        // fragment row of this lane group
-    const int orow = 2 * p + (kq >> 1);                    // D[channel + 8 row][pixel]: this lane's output row
-    const int ror = ring_row(orow) * XP;
     f32x4 acc[MAXJOBS];
 #pragma unroll
     for (int jb = 0; jb < MAXJOBS; jb++) {
-      acc[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[jb] = bias;
       const int q = ws + WPS * jb;
       if (q < MT && p < npairs) {
-        const int rb = rin + 16 * q + i;
+        const bf16x8* src = inh + (rin + 16 * q + i);
 #pragma unroll
         for (int g = 0; g < 3; g++) {
-          const bf16x8 ph = inh[rb + g], pl = inl[rb + g];
+          const bf16x8 ph = src[g], pl = src[RING + g];
           acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[g], ph, acc[jb], 0, 0, 0);
           acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g], pl, acc[jb], 0, 0, 0);
           acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g], ph, acc[jb], 0, 0, 0);
@@ -826,16 +827,17 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_strip8x(const float* __r
       const int q = ws + WPS * jb;
       if (q >= MT) continue;
       const int j = 16 * q + i;                    // this lane's pixel slot in the stage's output geometry
-      f32x4 v = acc[jb] + bias;
+      f32x4 v = acc[jb];
       if (has_res) {                               // second convolution of a block: + block input (ring cst-2, slot j + 2)
-        const int rs = 2 * (ror + j + 2) + (kq & 1);
-        const bf16x4 a = resh[rs], b = resl[rs];
+        const bf16x4* rp = resh + (2 * (ror + j + 2) + (kq & 1));
+        const bf16x4 a = rp[0], b = rp[2 * RING];
         v.x += (float)a[0] + (float)b[0]; v.y += (float)a[1] + (float)b[1];
         v.z += (float)a[2] + (float)b[2]; v.w += (float)a[3] + (float)b[3];
       }
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       if (last) {
         if (p < npairs) {
+          const int orow = 2 * p + (kq >> 1);
           const uint32_t oo = 4u * (uint32_t)((4 * (kq & 1) * H + orow) * W + X0 + j);   // byte offset from the SGPR base
           char* ob = reinterpret_cast<char*>(outf);
           *reinterpret_cast<float*>(ob + oo) = v.x;
@@ -844,8 +846,11 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_strip8x(const float* __r
           *reinterpret_cast<float*>(ob + (oo + 12u * (uint32_t)HW)) = v.w;
         }
       } else {
-        const int gx = X0 - (NS - cst) + j;        // image column of slot j of ring cst
-        if (p >= npairs || gx < 0 || gx >= W) v = f32x4{0.f, 0.f, 0.f, 0.f};   // the next stage's zero padding
+        if (p >= npairs) v = f32x4{0.f, 0.f, 0.f, 0.f};               // rows below the image: the next stage's zero padding
+        if (edge) {
+          const int gx = X0 - (NS - cst) + j;      // image column of slot j of ring cst
+          if (gx < 0 || gx >= W) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         if (j < XP) {
           bf16x4 vh, vl;
           __bf16 a, b;
@@ -853,8 +858,8 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_strip8x(const float* __r
           split_bf16(v.y, a, b); vh[1] = a; vl[1] = b;
           split_bf16(v.z, a, b); vh[2] = a; vl[2] = b;
           split_bf16(v.w, a, b); vh[3] = a; vl[3] = b;
-          const int os = 2 * (ror + j) + (kq & 1);
-          outh[os] = vh; outl[os] = vl;
+          bf16x4* op = outh + (2 * (ror + j) + (kq & 1));
+          op[0] = vh; op[2 * RING] = vl;
         }
       }
     }
@@ -871,6 +876,9 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_strip8x(const float* __r
     }                                                                                             \
     const int p_ = (n_) - 2 * cst;                                                                \
     if (p_ >= 0 && p_ <= npairs) stage(p_);                                                       \
+    crow += 2 * XP; crow = crow >= RWRAP ? crow - RWRAP : crow;                                   \
+    rin += 2 * XP; rin = rin >= RWRAP ? rin - RWRAP : rin;                                        \
+    ror += 2 * XP; ror = ror >= RWRAP ? ror - RWRAP : ror;                                        \
   }
   const int nsteps = (npairs + 2 * NS + 3) & ~3;   // the last stage's last pair is made at step npairs - 1 + 2 NS
   auto run = [&](auto is_loader) {
