@@ -904,6 +904,207 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_strip8x(const float* __r
 #undef MSF_ST_STEP
 }
 
+// ------------------------------------------------------------------ stem + first BasicBlock as one streaming pass
+// k_strip8x<1> with the stem (ConvertImageToFloat + 7x7 stride-2 convolution, 1 -> 8 channels, + ReLU) as stage 0: ring 0
+// is no longer fetched as f32 activations but computed from the u8 frame, of which 4 rows x 148 bytes arrive per step
+// (the stem's output, 2.46 MB per image, is neither written nor read back).  Stage 0 keeps 16 image rows in LDS as bf16
+// (0..255 are exact in bf16: no lo plane) and runs the same transposed, row-packed MFMA form: K = 32 of one MFMA = 4
+// image rows x 8 consecutive pixels (7 taps of a row + one with zero weight); an output row pair spans 9 image rows,
+// i.e. 3 MFMA groups x 2 products (weights hi and lo; the 1 / 255 of ConvertImageToFloat is folded into them).  A
+// fragment starts at pixel 2 j of the image ring row, i.e. on a 4-byte boundary: four dword reads.
+// Pipeline lags: stage 0 makes pair n - 2 of x at step n (its last image row arrived at step n - 1), stage c >= 1 pair
+// n - 2 - 2c.  Waves 0-2 run the stem, 3-5 the first convolution, 6-7 the second; the image loader lives in waves 5-7.
+namespace stem8 {
+using namespace strip8;
+constexpr int NS = 2;                              // one BasicBlock behind the stem
+constexpr int XW = S + 2 * NS;                     // 68 columns of x (ring 0)
+constexpr int IROWS = 16, IP = 160;                // image ring: 16 rows of 160 bf16 pixels; row pitch = 80 dwords == 16 (mod 32)
+constexpr int IDW = 37;                            // aligned dwords fetched per image row: tile pixels -1 .. 146
+constexpr int NLOAD = 4 * IDW;                     // loader threads (4 image rows per step)
+constexpr int LDS_BYTES = 16 * (NS * 2 * RING + TAIL) + 2 * IROWS * IP + 64;
+constexpr int WFRAG = 2 * 3 * 64 * 8;              // stem fragments [hi | lo][row group][lane][8]
+}  // namespace stem8
+
+__global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8_t* __restrict__ frames, long long frame_stride,
+                                                                     int row_stride, const uint16_t* __restrict__ wx0,
+                                                                     const float* __restrict__ b0, StripW sw,
+                                                                     float* __restrict__ out, int H, int W, int n_strips) {
+  using namespace stem8;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  bf16x8* ring = reinterpret_cast<bf16x8*>(lds);
+  __bf16* iring = reinterpret_cast<__bf16*>(ring + NS * 2 * RING + TAIL);
+  const int nwg = gridDim.x, per = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7;
+  const int unit = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);     // XCD-contiguous (image, strip) order
+  const int img = __builtin_amdgcn_readfirstlane(unit / n_strips);
+  const int X0 = __builtin_amdgcn_readfirstlane((unit - img * n_strips) * S);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int HW = H * W, Hin = 2 * H, Win = 2 * W;
+  const uint8_t* fr = frames + (long long)img * frame_stride;
+  float* outf = out + (long long)img * 8 * HW;
+  const int npairs = H / 2;
+  // this wave's stage: 0 = stem (waves 0-2), 1 / 2 = the block's convolutions (waves 3-5 / 6-7)
+  const int sid = __builtin_amdgcn_readfirstlane(wave < 3 ? 0 : wave < 6 ? 1 : 2);
+  const int ws = __builtin_amdgcn_readfirstlane(wave < 3 ? wave : wave < 6 ? wave - 3 : wave - 6);
+  const int wps = sid == 2 ? 2 : 3;
+  const bool last = sid == NS, has_res = sid == 2;
+  const int MT = last ? 4 : 5;
+
+  bf16x8 wh[3], wl[3];
+  {
+    const bf16x8* pw = reinterpret_cast<const bf16x8*>(sid == 0 ? wx0 : sw.wx[sid - 1]);
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+      wh[g] = pw[g * 64 + lane];
+      wl[g] = pw[(3 + g) * 64 + lane];
+    }
+  }
+  const f32x4 bias = *reinterpret_cast<const f32x4*>((sid == 0 ? b0 : sw.b[sid - 1]) + 4 * (kq & 1));
+  {  // rings and image rows above the frame read as zero
+    uint32_t* z = reinterpret_cast<uint32_t*>(lds);
+    for (int idx = tid; idx < LDS_BYTES / 4; idx += 64 * WAVES) z[idx] = 0u;
+  }
+  // image loader (the last NLOAD threads): thread (row r4 of the step's four, aligned dword d) fetches 4 pixels.  The
+  // tile's pixel 0 is image column CB = 2 (X0 - NS) - 3 == 1 (mod 4): the dword at CB - 1 + 4d holds tile pixels 4d-1 .. 4d+2.
+  const int ltid = tid - (64 * WAVES - NLOAD);
+  const bool ld = ltid >= 0;
+  const int r4 = ld ? ltid / IDW : 0, dd = ld ? ltid - r4 * IDW : 0;
+  const int cx = 2 * (X0 - NS) - 4 + 4 * dd;                      // image column of the dword (a multiple of 4)
+  const bool colok = ld && cx >= 0 && cx < Win;
+  const uint32_t lofs = colok ? (uint32_t)cx : 0u;
+  const bool ldwave = wave >= (64 * WAVES - NLOAD) / 64;
+#define MSF_SS_ISSUE(q_, n_)                                                                      \
+  {                                                                                               \
+    const int gy = 4 * (n_) + r4;                                                                 \
+    const uint32_t so = (colok && gy < Hin) ? lofs + (uint32_t)(gy * row_stride) : 0u;            \
+    q_ = *reinterpret_cast<const uint32_t*>(fr + so);                                             \
+  }
+#define MSF_SS_COMMIT(q_, n_)                                                                     \
+  if (ld) {                                                                                       \
+    const int gy = 4 * (n_) + r4;                                                                 \
+    const uint32_t v = (colok && gy < Hin) ? q_ : 0u;                                             \
+    __bf16* dst = iring + ((gy & (IROWS - 1)) * IP + 4 * dd);                                     \
+    const __bf16 p0 = (__bf16)(float)(v & 0xFFu), p1 = (__bf16)(float)((v >> 8) & 0xFFu);         \
+    const __bf16 p2 = (__bf16)(float)((v >> 16) & 0xFFu), p3 = (__bf16)(float)(v >> 24);          \
+    if (dd > 0) dst[-1] = p0;                                                                     \
+    dst[0] = p1; dst[1] = p2; dst[2] = p3;                                                        \
+  }
+  const bf16x8* inh = ring + (sid > 0 ? sid - 1 : 0) * 2 * RING;
+  const bf16x4* resh = reinterpret_cast<const bf16x4*>(ring);
+  bf16x4* outh = reinterpret_cast<bf16x4*>(ring + (last ? 0 : sid) * 2 * RING);
+  constexpr int RWRAP = RROWS * XP;
+  // row cursors of this wave's stage; its pair at step n is p = n - 2 - 2 sid
+  int rin = ring_row(-4 - 4 * sid - 1 + kq) * XP;
+  int ror = ring_row(-4 - 4 * sid + (kq >> 1)) * XP;
+  const bool edge = X0 == 0 || X0 + S == W;
+  auto stage = [&](int p) {
+    f32x4 acc[2];
+#pragma unroll
+    for (int jb = 0; jb < 2; jb++) {
+      acc[jb] = bias;
+      const int q = ws + wps * jb;
+      if (q < MT && p < npairs) {
+        if (sid == 0) {
+          // stem: image rows 4p - 3 + 4g + kq, pixels 2j .. 2j + 7 of the tile
+#pragma unroll
+          for (int g = 0; g < 3; g++) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(iring + (((4 * p - 3 + 4 * g + kq) & (IROWS - 1)) * IP + 2 * (16 * q + i)));
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 raw = u32x4{src[0], src[1], src[2], src[3]};
+            const bf16x8 px = __builtin_bit_cast(bf16x8, raw);
+            acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[g], px, acc[jb], 0, 0, 0);
+            acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g], px, acc[jb], 0, 0, 0);
+          }
+        } else {
+          const bf16x8* src = inh + (rin + 16 * q + i);
+#pragma unroll
+          for (int g = 0; g < 3; g++) {
+            const bf16x8 ph = src[g], pl = src[RING + g];
+            acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[g], ph, acc[jb], 0, 0, 0);
+            acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g], pl, acc[jb], 0, 0, 0);
+            acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g], ph, acc[jb], 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int jb = 0; jb < 2; jb++) {
+      const int q = ws + wps * jb;
+      if (q >= MT) continue;
+      const int j = 16 * q + i;
+      f32x4 v = acc[jb];
+      if (has_res) {
+        const bf16x4* rp = resh + (2 * (ror + j + 2) + (kq & 1));
+        const bf16x4 a = rp[0], b = rp[2 * RING];
+        v.x += (float)a[0] + (float)b[0]; v.y += (float)a[1] + (float)b[1];
+        v.z += (float)a[2] + (float)b[2]; v.w += (float)a[3] + (float)b[3];
+      }
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      if (last) {
+        if (p < npairs) {
+          const int orow = 2 * p + (kq >> 1);
+          const uint32_t oo = 4u * (uint32_t)((4 * (kq & 1) * H + orow) * W + X0 + j);
+          char* ob = reinterpret_cast<char*>(outf);
+          *reinterpret_cast<float*>(ob + oo) = v.x;
+          *reinterpret_cast<float*>(ob + (oo + 4u * (uint32_t)HW)) = v.y;
+          *reinterpret_cast<float*>(ob + (oo + 8u * (uint32_t)HW)) = v.z;
+          *reinterpret_cast<float*>(ob + (oo + 12u * (uint32_t)HW)) = v.w;
+        }
+      } else {
+        if (p >= npairs) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (edge) {
+          const int gx = X0 - (NS - sid) + j;      // image column of slot j of ring sid
+          if (gx < 0 || gx >= W) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (j < XP) {
+          bf16x4 vh, vl;
+          __bf16 a, b;
+          split_bf16(v.x, a, b); vh[0] = a; vl[0] = b;
+          split_bf16(v.y, a, b); vh[1] = a; vl[1] = b;
+          split_bf16(v.z, a, b); vh[2] = a; vl[2] = b;
+          split_bf16(v.w, a, b); vh[3] = a; vl[3] = b;
+          bf16x4* op = outh + (2 * (ror + j) + (kq & 1));
+          op[0] = vh; op[2 * RING] = vl;
+        }
+      }
+    }
+  };
+#define MSF_SS_STEP(q_, n_)                                                                       \
+  {                                                                                               \
+    __syncthreads();                                                                              \
+    if (kLd) {                                                                                    \
+      MSF_SS_COMMIT(q_, n_)                                                                       \
+      MSF_SS_ISSUE(q_, (n_) + 4)                                                                  \
+    }                                                                                             \
+    const int p_ = (n_) - 2 - 2 * sid;                                                            \
+    if (p_ >= 0 && p_ <= npairs) stage(p_);                                                       \
+    rin += 2 * XP; rin = rin >= RWRAP ? rin - RWRAP : rin;                                        \
+    ror += 2 * XP; ror = ror >= RWRAP ? ror - RWRAP : ror;                                        \
+  }
+  const int nsteps = (npairs + 2 * NS + 2 + 3) & ~3;
+  auto run = [&](auto is_loader) {
+    constexpr bool kLd = decltype(is_loader)::value;
+    uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    if (kLd) {
+      MSF_SS_ISSUE(q0, 0)
+      MSF_SS_ISSUE(q1, 1)
+      MSF_SS_ISSUE(q2, 2)
+      MSF_SS_ISSUE(q3, 3)
+    }
+    for (int n = 0; n < nsteps; n += 4) {
+      MSF_SS_STEP(q0, n)
+      MSF_SS_STEP(q1, n + 1)
+      MSF_SS_STEP(q2, n + 2)
+      MSF_SS_STEP(q3, n + 3)
+    }
+  };
+  if (ldwave) run(std::true_type{});
+  else run(std::false_type{});
+#undef MSF_SS_ISSUE
+#undef MSF_SS_COMMIT
+#undef MSF_SS_STEP
+}
+
 // ------------------------------------------------------------------ fused BasicBlock, 16 channels, split-bf16 MFMA
 // k_block16's tiling (bands of 8 rows, x tiles of 32 columns, wave = (M tile, row half), conv2 one tile behind conv1)
 // with the arithmetic and LDS layout of k_block8x / k_convx: planes [hi | lo][channel block of 8][row][pixel] x 16 B.
@@ -2100,6 +2301,22 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
       P.allocs.push_back(reinterpret_cast<float*>(*d));
       return hipMemcpy(*d, h.data(), h.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
     };
+    if (c.cin == 1 && c.ks == 7) {
+      // k_stem_strip8x stage 0: fragment (hi | lo, row group g): element j = kx of lane (idx = co + 8 rs, kq) is
+      // w[co][ky = 4 g + kq - 2 rs][kx] / 255 (0 outside the 7 x 7 window); an output row pair spans image rows s = 0 .. 8
+      const float k255 = (float)(1.0 / 255.0);
+      std::vector<uint16_t> wx(stem8::WFRAG, 0);
+      for (int g = 0; g < 3; g++)
+        for (int l = 0; l < 64; l++)
+          for (int j = 0; j < 8; j++) {
+            const int co = l & 7, rs = (l >> 3) & 1, ky = 4 * g + (l >> 4) - 2 * rs;
+            const float v = (ky >= 0 && ky <= 6 && j <= 6) ? (*w)[((size_t)co * 7 + ky) * 7 + j] * k255 : 0.f;
+            const uint16_t hi = to_bf16(v), lo = to_bf16(v - from_bf16(hi));
+            wx[((size_t)(0 * 3 + g) * 64 + l) * 8 + j] = hi;
+            wx[((size_t)(1 * 3 + g) * 64 + l) * 8 + j] = lo;
+          }
+      LF_TRY(upload16(wx, &c.d_wx));
+    }
     if (c.cout == 8 && c.cin == 8 && c.stride == 1) {
       // k_block8x: element j of lane (idx = co + 8 rs, input row s) of fragment kx is w[co][ci = j][ky = s - rs][kx]
       // (0 where output row rs does not see input row s), as hi = bf16(w) and lo = bf16(w - hi)
@@ -2306,6 +2523,21 @@ void launch_strip8x(const ConvDesc* cv, const float* in, float* out, int n_img, 
                      n_strips);
 }
 
+// stem + first 8-channel BasicBlock as one streaming pass over u8 frames (k_stem_strip8x): convolutions cv[0 .. 3)
+void launch_stem_strip8x(const ConvDesc* cv, const uint8_t* frames, long long frame_stride, int row_stride, float* out,
+                         int n_img, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_stem_strip8x), hipFuncAttributeMaxDynamicSharedMemorySize, stem8::LDS_BYTES);
+    attr_set = true;
+  }
+  StripW sw{};
+  for (int c = 0; c < 2; c++) { sw.wx[c] = cv[1 + c].d_wx; sw.b[c] = cv[1 + c].d_b; }
+  const int n_strips = cv[1].wout / strip8::S;
+  hipLaunchKernelGGL(k_stem_strip8x, dim3(n_strips * n_img), dim3(64 * strip8::WAVES), stem8::LDS_BYTES, st, frames, frame_stride,
+                     row_stride, cv[0].d_wx, cv[0].d_b, sw, out, cv[1].hout, cv[1].wout, n_strips);
+}
+
 // the 16-channel BasicBlock on split-bf16 MFMAs (k_block16x)
 void launch_block16x(const ConvDesc& ca, const ConvDesc& cb, const float* in, float* out, int n_img, hipStream_t st) {
   static bool attr_set = false;
@@ -2417,11 +2649,19 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
   float *a = P.bufA, *b = P.bufB, *cc = P.bufC, *d = P.bufD;
   const long long s8 = 8LL * 240 * 320;
   // the stem reads u8 frames from up to two arrays: launch it per array
-  if (nA) launch_conv<1, 8, 7, 2, 64, true, false, true, 2>(c[0], srcA, frame_stride, row_stride, nullptr, a, nA, st);
-  if (nB) launch_conv<1, 8, 7, 2, 64, true, false, true, 2>(c[0], srcB, frame_stride, row_stride, nullptr, a + (long long)nA * s8, nB, st);
+  const bool stem_fused = P.fuse_blocks && P.split_bf16 && P.strip_mode == 3;   // stem + block 1 in one pass -> cc
+  if (stem_fused) {
+    if (nA) launch_stem_strip8x(c, srcA, frame_stride, row_stride, cc, nA, st);
+    if (nB) launch_stem_strip8x(c, srcB, frame_stride, row_stride, cc + (long long)nA * s8, nB, st);
+  } else {
+    if (nA) launch_conv<1, 8, 7, 2, 64, true, false, true, 2>(c[0], srcA, frame_stride, row_stride, nullptr, a, nA, st);
+    if (nB) launch_conv<1, 8, 7, 2, 64, true, false, true, 2>(c[0], srcB, frame_stride, row_stride, nullptr, a + (long long)nA * s8, nB, st);
+  }
   // layer1 @240x320, 8 ch
   if (P.fuse_blocks) {   // each BasicBlock in one kernel: the intermediate activation stays in LDS
-    if (P.split_bf16 && P.strip_mode == 2) {
+    if (stem_fused) {
+      launch_strip8x<1>(c + 3, cc, a, ni, st);                                                       // a = 196
+    } else if (P.split_bf16 && P.strip_mode == 2) {
       launch_strip8x<2>(c + 1, a, cc, ni, st);                                                       // both blocks in one pass
       std::swap(a, cc);                                                                              // a = 196
     } else if (P.split_bf16 && P.strip_mode == 1) {
