@@ -513,6 +513,27 @@ __device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
   lo = (__bf16)(v - (float)hi);
 }
 
+// The streaming kernels are bound by VALU issue, so their epilogues spell the cheapest sequences out.  Left to the
+// compiler, ReLU is two instructions (fmaxf canonicalises its operand first) and the split converts every value twice.
+__device__ __forceinline__ float relu1(float x) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {   // (bf16(a), bf16(b)) round-to-nearest-even, a in the low half
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split4(f32x4 v, bf16x4& vh, bf16x4& vl) {   // 12 instructions for four values
+  const uint32_t h0 = cvt_pk_bf16(v.x, v.y), h1 = cvt_pk_bf16(v.z, v.w);
+  const float rx = v.x - __uint_as_float(h0 << 16), ry = v.y - __uint_as_float(h0 & 0xffff0000u);
+  const float rz = v.z - __uint_as_float(h1 << 16), rw = v.w - __uint_as_float(h1 & 0xffff0000u);
+  vh = __builtin_bit_cast(bf16x4, u32x2v{h0, h1});
+  vl = __builtin_bit_cast(bf16x4, u32x2v{cvt_pk_bf16(rx, ry), cvt_pk_bf16(rz, rw)});
+}
+
 __global__ __launch_bounds__(256, 2) void k_block8x(const float* __restrict__ in, const uint16_t* __restrict__ wx1,
                                                     const float* __restrict__ b1, const uint16_t* __restrict__ wx2,
                                                     const float* __restrict__ b2, float* __restrict__ out, int H, int W,
@@ -785,14 +806,11 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_strip8x(const float* __r
 #define MSF_ST_COMMIT(q_, n_)                                                                     \
   if (ld) {                                                                                       \
     const bool ok = colok && 2 * (n_) + lr < H;   /* outside the image: the (valid-address) load is discarded */ \
-    bf16x8 vh, vl;                                                                                \
-    _Pragma("unroll") for (int c = 0; c < 8; c++) {                                               \
-      __bf16 a, b;                                                                                \
-      split_bf16(ok ? q_[c] : 0.f, a, b);                                                         \
-      vh[c] = a; vl[c] = b;                                                                       \
-    }                                                                                             \
-    bf16x8* dst = ring + (crow + lc);                                                             \
-    dst[0] = vh; dst[RING] = vl;                                                                  \
+    bf16x4 h0, l0, h1, l1;                                                                        \
+    split4(ok ? f32x4{q_[0], q_[1], q_[2], q_[3]} : f32x4{0.f, 0.f, 0.f, 0.f}, h0, l0);           \
+    split4(ok ? f32x4{q_[4], q_[5], q_[6], q_[7]} : f32x4{0.f, 0.f, 0.f, 0.f}, h1, l1);           \
+    bf16x4* dst = reinterpret_cast<bf16x4*>(ring + (crow + lc));                                  \
+    dst[0] = h0; dst[1] = h1; dst[2 * RING] = l0; dst[2 * RING + 1] = l1;                         \
   }
   // this wave's stage makes pair p of ring cst (or of the output) from pairs p-1 .. p+1 of ring cst-1
   const bf16x8* inh = ring + (cst - 1) * 2 * RING;
@@ -806,12 +824,27 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_strip8x(const float* __r
   int ror = ring_row(-4 * cst + (kq >> 1)) * XP;   // stage: output row 2p + (kq >> 1)
   const bool edge = X0 == 0 || X0 + S == W;        // wave-uniform: only the outer strips have columns outside the image
   auto stage = [&](int p) {
+    if (p >= npairs) {                             // the pair below the image: the next stage's zero padding, nothing to compute
+      if (!last) {
+        bf16x4 z;
+        z[0] = z[1] = z[2] = z[3] = (__bf16)0.f;
+#pragma unroll
+        for (int jb = 0; jb < MAXJOBS; jb++) {
+          const int j = 16 * (ws + WPS * jb) + i;
+          if (ws + WPS * jb < MT && j < XP) {
+            bf16x4* op = outh + (2 * (ror + j) + (kq & 1));
+            op[0] = z; op[2 * RING] = z;
+          }
+        }
+      }
+      return;
+    }
     f32x4 acc[MAXJOBS];
 #pragma unroll
     for (int jb = 0; jb < MAXJOBS; jb++) {
       acc[jb] = bias;
       const int q = ws + WPS * jb;
-      if (q < MT && p < npairs) {
+      if (q < MT) {
         const bf16x8* src = inh + (rin + 16 * q + i);
 #pragma unroll
         for (int g = 0; g < 3; g++) {
@@ -834,9 +867,9 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_strip8x(const float* __r
         v.x += (float)a[0] + (float)b[0]; v.y += (float)a[1] + (float)b[1];
         v.z += (float)a[2] + (float)b[2]; v.w += (float)a[3] + (float)b[3];
       }
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w);
       if (last) {
-        if (p < npairs) {
+        {
           const int orow = 2 * p + (kq >> 1);
           const uint32_t oo = 4u * (uint32_t)((4 * (kq & 1) * H + orow) * W + X0 + j);   // byte offset from the SGPR base
           char* ob = reinterpret_cast<char*>(outf);
@@ -846,18 +879,13 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_strip8x(const float* __r
           *reinterpret_cast<float*>(ob + (oo + 12u * (uint32_t)HW)) = v.w;
         }
       } else {
-        if (p >= npairs) v = f32x4{0.f, 0.f, 0.f, 0.f};               // rows below the image: the next stage's zero padding
         if (edge) {
           const int gx = X0 - (NS - cst) + j;      // image column of slot j of ring cst
           if (gx < 0 || gx >= W) v = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (j < XP) {
           bf16x4 vh, vl;
-          __bf16 a, b;
-          split_bf16(v.x, a, b); vh[0] = a; vl[0] = b;
-          split_bf16(v.y, a, b); vh[1] = a; vl[1] = b;
-          split_bf16(v.z, a, b); vh[2] = a; vl[2] = b;
-          split_bf16(v.w, a, b); vh[3] = a; vl[3] = b;
+          split4(v, vh, vl);
           bf16x4* op = outh + (2 * (ror + j) + (kq & 1));
           op[0] = vh; op[2 * RING] = vl;
         }
@@ -998,12 +1026,27 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8
   int ror = ring_row(-4 - 4 * sid + (kq >> 1)) * XP;
   const bool edge = X0 == 0 || X0 + S == W;
   auto stage = [&](int p) {
+    if (p >= npairs) {                             // the pair below the image: the next stage's zero padding, nothing to compute
+      if (!last) {
+        bf16x4 z;
+        z[0] = z[1] = z[2] = z[3] = (__bf16)0.f;
+#pragma unroll
+        for (int jb = 0; jb < 2; jb++) {
+          const int j = 16 * (ws + wps * jb) + i;
+          if (ws + wps * jb < MT && j < XP) {
+            bf16x4* op = outh + (2 * (ror + j) + (kq & 1));
+            op[0] = z; op[2 * RING] = z;
+          }
+        }
+      }
+      return;
+    }
     f32x4 acc[2];
 #pragma unroll
     for (int jb = 0; jb < 2; jb++) {
       acc[jb] = bias;
       const int q = ws + wps * jb;
-      if (q < MT && p < npairs) {
+      if (q < MT) {
         if (sid == 0) {
           // stem: image rows 4p - 3 + 4g + kq, pixels 2j .. 2j + 7 of the tile
 #pragma unroll
@@ -1039,9 +1082,9 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8
         v.x += (float)a[0] + (float)b[0]; v.y += (float)a[1] + (float)b[1];
         v.z += (float)a[2] + (float)b[2]; v.w += (float)a[3] + (float)b[3];
       }
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w);
       if (last) {
-        if (p < npairs) {
+        {
           const int orow = 2 * p + (kq >> 1);
           const uint32_t oo = 4u * (uint32_t)((4 * (kq & 1) * H + orow) * W + X0 + j);
           char* ob = reinterpret_cast<char*>(outf);
@@ -1051,18 +1094,13 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8
           *reinterpret_cast<float*>(ob + (oo + 12u * (uint32_t)HW)) = v.w;
         }
       } else {
-        if (p >= npairs) v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (edge) {
           const int gx = X0 - (NS - sid) + j;      // image column of slot j of ring sid
           if (gx < 0 || gx >= W) v = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (j < XP) {
           bf16x4 vh, vl;
-          __bf16 a, b;
-          split_bf16(v.x, a, b); vh[0] = a; vl[0] = b;
-          split_bf16(v.y, a, b); vh[1] = a; vl[1] = b;
-          split_bf16(v.z, a, b); vh[2] = a; vl[2] = b;
-          split_bf16(v.w, a, b); vh[3] = a; vl[3] = b;
+          split4(v, vh, vl);
           bf16x4* op = outh + (2 * (ror + j) + (kq & 1));
           op[0] = vh; op[2 * RING] = vl;
         }
@@ -2159,7 +2197,8 @@ struct LoftrPipeline::Impl {
   bool dense_head = false;
   bool fuse_blocks = true;   // MSF_LOFTR_UNFUSED=1: one kernel per convolution (tests: bit-identical results)
   bool split_bf16 = true;    // MSF_LOFTR_F32=1: every convolution on the f32 MFMA (no split-bf16 kernels)
-  int strip_mode = 1;        // MSF_LOFTR_STRIP: layer1 as streaming strips, 2 = both blocks in one pass, 0 = k_block8x
+  int strip_mode = 3;        // MSF_LOFTR_STRIP: layer1 as streaming strips: 3 = stem + block 1 in one pass, then block 2
+                             // (default); 1 = stem kernel, one pass per block; 2 = both blocks in one pass; 0 = k_block8x
   bool keep_debug = false;   // MSF_FLAG_KEEP_DEBUG: pair 0's confidence matrix + features for the parity tests
   float* conf_dbg = nullptr; // [1200][1200]
   float* feat_dbg = nullptr; // [2][1200][32]
