@@ -2197,6 +2197,7 @@ struct LoftrPipeline::Impl {
   bool dense_head = false;
   bool fuse_blocks = true;   // MSF_LOFTR_UNFUSED=1: one kernel per convolution (tests: bit-identical results)
   bool split_bf16 = true;    // MSF_LOFTR_F32=1: every convolution on the f32 MFMA (no split-bf16 kernels)
+  int strip_min_images = 64; // backbone passes of fewer images use the banded kernels (run_backbone)
   int strip_mode = 3;        // MSF_LOFTR_STRIP: layer1 as streaming strips: 3 = stem + block 1 in one pass, then block 2
                              // (default); 1 = stem kernel, one pass per block; 2 = both blocks in one pass; 0 = k_block8x
   bool keep_debug = false;   // MSF_FLAG_KEEP_DEBUG: pair 0's confidence matrix + features for the parity tests
@@ -2253,6 +2254,7 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
     P.split_bf16 = !f32_convs;
     if (const char* d = getenv("MSF_LOFTR_F32")) P.split_bf16 = atoi(d) == 0;
     if (const char* d = getenv("MSF_LOFTR_STRIP")) P.strip_mode = atoi(d);
+    if (const char* d = getenv("MSF_LOFTR_STRIP_MIN")) P.strip_min_images = atoi(d);   // tests: strips for a single pair
     // pairs per backbone pass (activation working set: 19.7 MB per pair).  Whole launches of 512 images fill the 512
     // workgroup slots of the fused block kernels in whole rounds (64 pairs: conv stack 8.41 ms, 128: 8.15, 256: 8.07)
     const char* e = getenv("MSF_LOFTR_CHUNK");
@@ -2688,7 +2690,10 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
   float *a = P.bufA, *b = P.bufB, *cc = P.bufC, *d = P.bufD;
   const long long s8 = 8LL * 240 * 320;
   // the stem reads u8 frames from up to two arrays: launch it per array
-  const bool stem_fused = P.fuse_blocks && P.split_bf16 && P.strip_mode == 3;   // stem + block 1 in one pass -> cc
+  // A streaming workgroup walks a whole 240-row strip (~70 us however few images there are): calls of fewer than 64
+  // images -- the single-pair drop-in path -- keep the short banded workgroups (stateless pair: 0.84 vs 1.06 ms).
+  const int strip_mode = ni >= P.strip_min_images ? P.strip_mode : 0;
+  const bool stem_fused = P.fuse_blocks && P.split_bf16 && strip_mode == 3;   // stem + block 1 in one pass -> cc
   if (stem_fused) {
     if (nA) launch_stem_strip8x(c, srcA, frame_stride, row_stride, cc, nA, st);
     if (nB) launch_stem_strip8x(c, srcB, frame_stride, row_stride, cc + (long long)nA * s8, nB, st);
@@ -2700,10 +2705,10 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
   if (P.fuse_blocks) {   // each BasicBlock in one kernel: the intermediate activation stays in LDS
     if (stem_fused) {
       launch_strip8x<1>(c + 3, cc, a, ni, st);                                                       // a = 196
-    } else if (P.split_bf16 && P.strip_mode == 2) {
+    } else if (P.split_bf16 && strip_mode == 2) {
       launch_strip8x<2>(c + 1, a, cc, ni, st);                                                       // both blocks in one pass
       std::swap(a, cc);                                                                              // a = 196
-    } else if (P.split_bf16 && P.strip_mode == 1) {
+    } else if (P.split_bf16 && strip_mode == 1) {
       launch_strip8x<1>(c + 1, a, cc, ni, st);
       launch_strip8x<1>(c + 3, cc, a, ni, st);                                                       // a = 196
     } else if (P.split_bf16) {

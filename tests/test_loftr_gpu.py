@@ -236,15 +236,28 @@ def test_fused_basic_blocks_equal_the_layer_by_layer_path():
     np.testing.assert_array_equal(outs[0]["conf"].view(np.uint32), outs[1]["conf"].view(np.uint32))
 
 
-def test_split_bf16_blocks_stay_within_a_tenth_of_the_tolerance():
-    """Default path: the fused blocks run on bf16 MFMAs with every f32 operand split into hi + lo (three products,
-    f32 accumulation).  Against the all-f32 path (MSF_LOFTR_F32=1) confidences must agree to 1e-4 -- a tenth of the
-    north-star tolerance -- and the match lists wherever the f32 confidence is not within 1e-4 of the threshold."""
-    for seed in (41, 7):
-        x, f = _run_child({}, seed), _run_child({"MSF_LOFTR_F32": "1"}, seed)
+_F32_RUNS = {}
+
+
+def _f32_run(seed):
+    if seed not in _F32_RUNS:
+        _F32_RUNS[seed] = _run_child({"MSF_LOFTR_F32": "1"}, seed)
+    return _F32_RUNS[seed]
+
+
+@pytest.mark.parametrize("strip,seeds", [("3", (41, 7)), ("2", (41,)), ("1", (41,)), ("0", (41,))])
+def test_split_bf16_blocks_stay_within_a_tenth_of_the_tolerance(strip, seeds):
+    """Default path: the ResNet blocks run on bf16 MFMAs with every f32 operand split into hi + lo (three products,
+    f32 accumulation); layer1 is a streaming pass (MSF_LOFTR_STRIP: 3 = stem fused with the first block (default), 2 =
+    both blocks chained, 1 = one pass per block, 0 = the banded k_block8x, which calls of fewer than 64 images always take:
+    MSF_LOFTR_STRIP_MIN=1 lifts that for the test).  Against the all-f32 path (MSF_LOFTR_F32=1)
+    confidences must agree to 1e-4 -- a tenth of the north-star tolerance -- and the match lists wherever the f32
+    confidence is not within 1e-4 of the threshold."""
+    for seed in seeds:
+        x, f = _run_child({"MSF_LOFTR_STRIP": strip, "MSF_LOFTR_STRIP_MIN": "1"}, seed), _f32_run(seed)
         dconf = np.abs(x["conf"] - f["conf"]).max()
         dfeat = np.abs(x["feat"] - f["feat"]).max()
-        print("split-bf16 vs f32: max |dconf| %.3g, max |dfeat| %.3g" % (dconf, dfeat))
+        print("split-bf16 (strip mode %s) vs f32: max |dconf| %.3g, max |dfeat| %.3g" % (strip, dconf, dfeat))
         assert dconf <= 1e-4 and dfeat <= 1e-3
         # every ResNet stage's activation (MSF_DBG_LOFTR_ACT): a split product drops terms below 2^-16 of |x w|
         for l in range(4):

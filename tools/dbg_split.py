@@ -23,7 +23,7 @@ def run(env):
     return out
 
 
-x, f = run({}), run({"MSF_LOFTR_F32": "1"})
+x, f = run({"MSF_LOFTR_STRIP_MIN": "1"}), run({"MSF_LOFTR_F32": "1"})
 np.set_printoptions(precision=2, linewidth=250, suppress=False)
 for k in ("a0", "a1", "a2", "a3", "conf"):
     d = np.abs(x[k] - f[k])
