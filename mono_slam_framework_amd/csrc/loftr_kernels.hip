@@ -513,13 +513,11 @@ __device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
   lo = (__bf16)(v - (float)hi);
 }
 
-// The streaming kernels are bound by VALU issue, so their epilogues spell the cheapest sequences out.  Left to the
-// compiler, ReLU is two instructions (fmaxf canonicalises its operand first) and the split converts every value twice.
-__device__ __forceinline__ float relu1(float x) {
-  float r;
-  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-  return r;
-}
+// The streaming kernels are bound by VALU issue, so their epilogues spell the cheapest split sequence out (left to the
+// compiler, every value is converted twice).  Inline assembly must never read an MFMA result directly: the hazard
+// recogniser does not pad the MFMA -> VALU read latency for it (measured: stale accumulators).  Every value that
+// reaches cvt_pk_bf16 below has gone through a compiler-visible f32 add (bias / residual) first -- which also makes
+// fmaxf a single v_max_f32, because the result of an add needs no canonicalisation.
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {   // (bf16(a), bf16(b)) round-to-nearest-even, a in the low half
   uint32_t r;
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -842,7 +840,7 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_strip8x(const float* __r
     f32x4 acc[MAXJOBS];
 #pragma unroll
     for (int jb = 0; jb < MAXJOBS; jb++) {
-      acc[jb] = bias;
+      acc[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int q = ws + WPS * jb;
       if (q < MT) {
         const bf16x8* src = inh + (rin + 16 * q + i);
@@ -860,14 +858,14 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_strip8x(const float* __r
       const int q = ws + WPS * jb;
       if (q >= MT) continue;
       const int j = 16 * q + i;                    // this lane's pixel slot in the stage's output geometry
-      f32x4 v = acc[jb];
+      f32x4 v = acc[jb] + bias;
       if (has_res) {                               // second convolution of a block: + block input (ring cst-2, slot j + 2)
         const bf16x4* rp = resh + (2 * (ror + j + 2) + (kq & 1));
         const bf16x4 a = rp[0], b = rp[2 * RING];
         v.x += (float)a[0] + (float)b[0]; v.y += (float)a[1] + (float)b[1];
         v.z += (float)a[2] + (float)b[2]; v.w += (float)a[3] + (float)b[3];
       }
-      v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w);
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       if (last) {
         {
           const int orow = 2 * p + (kq >> 1);
@@ -1044,7 +1042,7 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8
     f32x4 acc[2];
 #pragma unroll
     for (int jb = 0; jb < 2; jb++) {
-      acc[jb] = bias;
+      acc[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int q = ws + wps * jb;
       if (q < MT) {
         if (sid == 0) {
@@ -1075,14 +1073,14 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8
       const int q = ws + wps * jb;
       if (q >= MT) continue;
       const int j = 16 * q + i;
-      f32x4 v = acc[jb];
+      f32x4 v = acc[jb] + bias;
       if (has_res) {
         const bf16x4* rp = resh + (2 * (ror + j + 2) + (kq & 1));
         const bf16x4 a = rp[0], b = rp[2 * RING];
         v.x += (float)a[0] + (float)b[0]; v.y += (float)a[1] + (float)b[1];
         v.z += (float)a[2] + (float)b[2]; v.w += (float)a[3] + (float)b[3];
       }
-      v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w);
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       if (last) {
         {
           const int orow = 2 * p + (kq >> 1);
@@ -1141,6 +1139,255 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8
 #undef MSF_SS_ISSUE
 #undef MSF_SS_COMMIT
 #undef MSF_SS_STEP
+}
+
+// ------------------------------------------------------------------ streaming down-sampling BasicBlock 8 -> 16 (layer2, block 1)
+// u = relu(conv3x3(relu(conv3x3_s2(x))) + conv1x1_s2(x)) as one pass in the style of k_strip8x: a workgroup owns 32 output
+// columns (64 + 5 input columns) of one image and walks down two output rows (four input rows) per step.
+//   ring X: 12 input rows, 8 channels, columns de-interleaved (even | odd halves), so the stride-2 fragments of 16
+//           neighbouring output pixels are 16 consecutive slots;
+//   stage 1 (waves 0-5, one (row, M tile) job each): t = relu(conv3x3 stride 2) and the shortcut sc = conv1x1 stride 2
+//           of the same output pixels -- the shortcut's input pixel is the centre tap, i.e. the fragment of kx = 1 in
+//           the ky = 1 group, so it costs three more MFMAs and no LDS read.  K = 32 of an MFMA = the 3 kx of one ky x 8
+//           channels (+ one zero block).  Both results go to rings (16 channels = 2 channel-block planes, hi | lo);
+//   stage 2 (waves 6-7, two jobs each): u = relu(conv3x3(t) + sc) with k_block16x's K grouping (two taps x two channel
+//           blocks per MFMA, five groups), stored to global memory (dwords, 64 contiguous bytes per channel row).
+// Pipeline: input rows 4n .. 4n+3 arrive at step n (fetched four steps ahead), stage 1 makes row pair n - 1, stage 2
+// pair n - 3; one barrier per step.  Moves x once and u once instead of x, t, sc twice and u (4.9 -> 1.9 GB per step).
+namespace down16 {
+constexpr int S = 32;                              // output columns per strip
+constexpr int TW = S + 2;                          // t / sc columns (stage 2's halo)
+constexpr int IROWS = 12, IPX = 76, IODD = 38;     // input ring: rows, pitch, first slot of the odd-column half
+constexpr int INW = 2 * TW + 1;                    // 69 input columns: 2 X0 - 3 .. 2 X0 + 65
+constexpr int IPLANE = IROWS * IPX;                // slots per plane (hi, lo)
+constexpr int TROWS = 8, TPX = 36;                 // t / sc rings: four row pairs, 34 columns
+constexpr int TCB = TROWS * TPX;                   // 288 = 18 x 16 slots per channel-block plane
+constexpr int TRING = 4 * TCB;                     // [hi | lo][channel block]
+static_assert(TCB % 16 == 0, "channel-block planes must be multiples of 16 pixel slots");
+constexpr int WAVES = 8;
+constexpr int NLOAD = 4 * INW;                     // loader threads: one input pixel (8 channel dwords) each per step
+constexpr int LDS_BYTES = 16 * (2 * IPLANE + 2 * TRING + 16);
+constexpr int W1FRAG = 2 * 3 * 64 * 8;             // conv3x3 stride 2: [hi | lo][ky][lane][8]
+constexpr int WSFRAG = 2 * 64 * 8;                 // shortcut: [hi | lo][lane][8]
+}  // namespace down16
+
+struct DownW {
+  const uint16_t *w1, *wsc, *w2;
+  const float *b1, *bsc, *b2;
+  int dbg;   // 1 / 2: the kernel outputs t / sc instead of u (debugging aid, MSF_DBG_DOWN)
+};
+
+__global__ __launch_bounds__(64 * down16::WAVES) void k_down16x(const float* __restrict__ in, DownW dw, float* __restrict__ out,
+                                                                int H, int W, int n_strips) {
+  using namespace down16;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  bf16x8* xr = reinterpret_cast<bf16x8*>(lds);     // input ring: hi plane, lo plane IPLANE behind it
+  bf16x8* tr = xr + 2 * IPLANE;                    // t ring: [hi | lo][cb]
+  bf16x8* sr = tr + TRING;                         // sc ring
+  const int nwg = gridDim.x, per = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7;
+  const int unit = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+  const int img = __builtin_amdgcn_readfirstlane(unit / n_strips);
+  const int X0 = __builtin_amdgcn_readfirstlane((unit - img * n_strips) * S);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int Hin = 2 * H, Win = 2 * W, HWin = Hin * Win, HW = H * W;
+  const float* inf = in + (long long)img * 8 * HWin;
+  float* outf = out + (long long)img * 16 * HW;
+  const int npairs = H / 2;
+  const bool st1 = wave < 6;                       // wave-uniform: stage 1 (one job) or stage 2 (two jobs)
+  const int jr = st1 ? wave / 3 : wave - 6;        // row of the pair this wave works on
+  const int jq = st1 ? wave - 3 * jr : 0;          // stage 1: M tile
+
+  // weight fragments: stage 1 waves hold the stride-2 convolution and the shortcut, stage 2 waves the 3x3 convolution
+  bf16x8 wa[5], wb[5], wsh, wsl;
+  f32x4 bias, bias_sc;
+  if (st1) {
+    const bf16x8* p1 = reinterpret_cast<const bf16x8*>(dw.w1);
+    const bf16x8* ps = reinterpret_cast<const bf16x8*>(dw.wsc);
+#pragma unroll
+    for (int g = 0; g < 3; g++) { wa[g] = p1[g * 64 + lane]; wb[g] = p1[(3 + g) * 64 + lane]; }
+    wa[3] = wa[4] = wb[3] = wb[4] = wa[0];
+    wsh = ps[lane]; wsl = ps[64 + lane];
+    bias = *reinterpret_cast<const f32x4*>(dw.b1 + 4 * kq);
+    bias_sc = *reinterpret_cast<const f32x4*>(dw.bsc + 4 * kq);
+  } else {
+    const bf16x8* p2 = reinterpret_cast<const bf16x8*>(dw.w2);
+#pragma unroll
+    for (int g = 0; g < 5; g++) { wa[g] = p2[g * 64 + lane]; wb[g] = p2[(5 + g) * 64 + lane]; }
+    wsh = wsl = wa[0];
+    bias = *reinterpret_cast<const f32x4*>(dw.b2 + 4 * kq);
+    bias_sc = bias;
+  }
+  {
+    uint32_t* z = reinterpret_cast<uint32_t*>(lds);
+    for (int idx = tid; idx < LDS_BYTES / 4; idx += 64 * WAVES) z[idx] = 0u;
+  }
+  // loader (threads 0 .. NLOAD-1): thread (row r4 of the step's four, tile column lc) fetches one pixel = 8 channel dwords
+  const bool ld = tid < NLOAD;
+  const int r4 = ld ? tid / INW : 0, lc = ld ? tid - r4 * INW : 0;
+  const int lgx = 2 * X0 - 3 + lc;
+  const bool colok = ld && lgx >= 0 && lgx < Win;
+  const uint32_t lofs = colok ? (uint32_t)lgx : 0u;
+  const int lslot = (lc & 1) ? IODD + (lc >> 1) : (lc >> 1);
+  const bool ldwave = wave <= (NLOAD - 1) / 64;
+#define MSF_DN_ISSUE(q_, n_)                                                                      \
+  {                                                                                               \
+    const int gy = 4 * (n_) + r4;                                                                 \
+    const uint32_t so = (colok && gy < Hin) ? 4u * (lofs + (uint32_t)(gy * Win)) : 0u;            \
+    _Pragma("unroll") for (int c = 0; c < 8; c++)                                                 \
+      q_[c] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(inf) + (so + 4u * (uint32_t)(c * HWin))); \
+  }
+#define MSF_DN_COMMIT(q_, n_)                                                                     \
+  if (ld) {                                                                                       \
+    const bool ok = colok && 4 * (n_) + r4 < Hin;                                                 \
+    bf16x4 h0, l0, h1, l1;                                                                        \
+    split4(ok ? f32x4{q_[0], q_[1], q_[2], q_[3]} : f32x4{0.f, 0.f, 0.f, 0.f}, h0, l0);           \
+    split4(ok ? f32x4{q_[4], q_[5], q_[6], q_[7]} : f32x4{0.f, 0.f, 0.f, 0.f}, h1, l1);           \
+    bf16x4* dst = reinterpret_cast<bf16x4*>(xr + (irow + r4 * IPX + lslot));                      \
+    dst[0] = h0; dst[1] = h1; dst[2 * IPLANE] = l0; dst[2 * IPLANE + 1] = l1;                     \
+  }
+  int irow = 0;                                    // loader cursor: (4n mod 12) * IPX (a step's four rows never wrap inside)
+  constexpr int IWRAP = IROWS * IPX;
+  const bool edge = X0 == 0 || X0 + S == W;
+  // ---- stage 1: out row Y = 2p + jr, t / sc slots 16 jq + i
+  auto stage1 = [&](int p) {
+    const int jt = 16 * jq + i;
+    const int Y = 2 * p + jr;
+    bf16x4* th4 = reinterpret_cast<bf16x4*>(tr);
+    bf16x4* sh4 = reinterpret_cast<bf16x4*>(sr);
+    const int os = 2 * ((kq >> 1) * TCB + (Y & (TROWS - 1)) * TPX + jt) + (kq & 1);   // channels 4 kq .. +3: block kq >> 1, half kq & 1
+    if (p >= npairs) {                             // the row pair below the image: zero padding for stage 2
+      if (jt < TW) {
+        bf16x4 z;
+        z[0] = z[1] = z[2] = z[3] = (__bf16)0.f;
+        th4[os] = z; th4[os + 4 * TCB] = z;
+      }
+      return;
+    }
+    const int ja = jt < TW + 2 ? jt : TW + 1;      // lanes past the strip's columns compute nothing useful: keep their reads inside the row
+    const int col = kq == 1 ? IODD + ja : kq == 0 ? ja : ja + 1;   // kx = kq (kq = 3: zero weights)
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, asc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+      // input row 2Y - 1 + g = 4p + 2 jr - 1 + g; ring rows are input rows modulo 12
+      int rr = 4 * p + 2 * jr - 1 + g + IROWS;
+      rr = rr - IROWS * ((rr * 2731) >> 15);
+      const bf16x8* src = xr + (rr * IPX + col);
+      const bf16x8 ph = src[0], pl = src[IPLANE];
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[g], ph, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], pl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], ph, acc, 0, 0, 0);
+      if (g == 1) {
+        asc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsl, ph, asc, 0, 0, 0);
+        asc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsh, pl, asc, 0, 0, 0);
+        asc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsh, ph, asc, 0, 0, 0);
+      }
+    }
+    acc += bias;
+    asc += bias_sc;
+    acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+    if (edge) {
+      const int gx = X0 - 1 + jt;
+      if (gx < 0 || gx >= W) acc = f32x4{0.f, 0.f, 0.f, 0.f};   // stage 2 pads t with zeros
+    }
+    if (jt < TW) {
+      bf16x4 vh, vl;
+      split4(acc, vh, vl);
+      th4[os] = vh; th4[os + 4 * TCB] = vl;
+      split4(asc, vh, vl);
+      sh4[os] = vh; sh4[os + 4 * TCB] = vl;
+    }
+  };
+  // ---- stage 2: out row Y = 2p + jr, pixels 16 q + i (q = 0, 1): tap 2g + (kq >> 1) (the tenth has zero weights), block kq & 1
+  int toff[5];
+#pragma unroll
+  for (int g = 0; g < 5; g++) {
+    int t = 2 * g + (kq >> 1);
+    t = t < 9 ? t : 8;
+    const int ky = t / 3, kx = t - 3 * ky;
+    toff[g] = (kq & 1) * TCB + kx + ky * TPX;      // + ((Y - 1) mod 8) * TPX, row wrap handled below
+  }
+  auto stage2 = [&](int p) {
+    if (p >= npairs) return;
+    const int Y = 2 * p + jr;
+    f32x4 acc[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 5; g++) {
+        int t = 2 * g + (kq >> 1);
+        t = t < 9 ? t : 8;
+        const int ky = t / 3, kx = t - 3 * ky;
+        const bf16x8* src = tr + ((kq & 1) * TCB + ((Y - 1 + ky) & (TROWS - 1)) * TPX + 16 * q + i + kx);
+        const bf16x8 ah = src[0], al = src[2 * TCB];
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[g], ah, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], al, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], ah, acc[q], 0, 0, 0);
+      }
+    }
+    const bf16x4* sh4 = reinterpret_cast<const bf16x4*>(sr);
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int j = 16 * q + i;
+      const int rs = 2 * ((kq >> 1) * TCB + (Y & (TROWS - 1)) * TPX + j + 1) + (kq & 1);
+      const bf16x4 a = sh4[rs], b = sh4[rs + 4 * TCB];
+      f32x4 v = acc[q] + bias;
+      v.x += (float)a[0] + (float)b[0]; v.y += (float)a[1] + (float)b[1];
+      v.z += (float)a[2] + (float)b[2]; v.w += (float)a[3] + (float)b[3];
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      if (dw.dbg) {
+        const bf16x4* dh4 = reinterpret_cast<const bf16x4*>(dw.dbg == 1 ? tr : sr);
+        const bf16x4 da = dh4[rs], db = dh4[rs + 4 * TCB];
+        v = f32x4{(float)da[0] + (float)db[0], (float)da[1] + (float)db[1], (float)da[2] + (float)db[2], (float)da[3] + (float)db[3]};
+      }
+      const uint32_t oo = 4u * (uint32_t)((4 * kq * H + Y) * W + X0 + j);
+      char* ob = reinterpret_cast<char*>(outf);
+      *reinterpret_cast<float*>(ob + oo) = v.x;
+      *reinterpret_cast<float*>(ob + (oo + 4u * (uint32_t)HW)) = v.y;
+      *reinterpret_cast<float*>(ob + (oo + 8u * (uint32_t)HW)) = v.z;
+      *reinterpret_cast<float*>(ob + (oo + 12u * (uint32_t)HW)) = v.w;
+    }
+  };
+  (void)toff;
+#define MSF_DN_STEP(q_, n_)                                                                       \
+  {                                                                                               \
+    __syncthreads();                                                                              \
+    if (kLd) {                                                                                    \
+      MSF_DN_COMMIT(q_, n_)                                                                       \
+      MSF_DN_ISSUE(q_, (n_) + 4)                                                                  \
+    }                                                                                             \
+    if (st1) {                                                                                    \
+      const int p_ = (n_) - 1;                                                                    \
+      if (p_ >= 0 && p_ <= npairs) stage1(p_);                                                    \
+    } else {                                                                                      \
+      const int p_ = (n_) - 3;                                                                    \
+      if (p_ >= 0) stage2(p_);                                                                    \
+    }                                                                                             \
+    irow += 4 * IPX; irow = irow >= IWRAP ? irow - IWRAP : irow;                                  \
+  }
+  const int nsteps = (npairs + 3 + 3) & ~3;
+  auto run = [&](auto is_loader) {
+    constexpr bool kLd = decltype(is_loader)::value;
+    float q0[8], q1[8], q2[8], q3[8];
+    if (kLd) {
+      MSF_DN_ISSUE(q0, 0)
+      MSF_DN_ISSUE(q1, 1)
+      MSF_DN_ISSUE(q2, 2)
+      MSF_DN_ISSUE(q3, 3)
+    }
+    for (int n = 0; n < nsteps; n += 4) {
+      MSF_DN_STEP(q0, n)
+      MSF_DN_STEP(q1, n + 1)
+      MSF_DN_STEP(q2, n + 2)
+      MSF_DN_STEP(q3, n + 3)
+    }
+  };
+  if (ldwave) run(std::true_type{});
+  else run(std::false_type{});
+#undef MSF_DN_ISSUE
+#undef MSF_DN_COMMIT
+#undef MSF_DN_STEP
 }
 
 // ------------------------------------------------------------------ fused BasicBlock, 16 channels, split-bf16 MFMA
@@ -2197,6 +2444,7 @@ struct LoftrPipeline::Impl {
   bool dense_head = false;
   bool fuse_blocks = true;   // MSF_LOFTR_UNFUSED=1: one kernel per convolution (tests: bit-identical results)
   bool split_bf16 = true;    // MSF_LOFTR_F32=1: every convolution on the f32 MFMA (no split-bf16 kernels)
+  bool down_stream = true;   // MSF_LOFTR_DOWN=0: layer2's first block as two kernels instead of the streaming k_down16x
   int strip_min_images = 64; // backbone passes of fewer images use the banded kernels (run_backbone)
   int strip_mode = 3;        // MSF_LOFTR_STRIP: layer1 as streaming strips: 3 = stem + block 1 in one pass, then block 2
                              // (default); 1 = stem kernel, one pass per block; 2 = both blocks in one pass; 0 = k_block8x
@@ -2254,6 +2502,7 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
     P.split_bf16 = !f32_convs;
     if (const char* d = getenv("MSF_LOFTR_F32")) P.split_bf16 = atoi(d) == 0;
     if (const char* d = getenv("MSF_LOFTR_STRIP")) P.strip_mode = atoi(d);
+    if (const char* d = getenv("MSF_LOFTR_DOWN")) P.down_stream = atoi(d) != 0;
     if (const char* d = getenv("MSF_LOFTR_STRIP_MIN")) P.strip_min_images = atoi(d);   // tests: strips for a single pair
     // pairs per backbone pass (activation working set: 19.7 MB per pair).  Whole launches of 512 images fill the 512
     // workgroup slots of the fused block kernels in whole rounds (64 pairs: conv stack 8.41 ms, 128: 8.15, 256: 8.07)
@@ -2371,6 +2620,36 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
             wx[((size_t)(0 * 3 + g) * 64 + l) * 8 + j] = hi;
             wx[((size_t)(1 * 3 + g) * 64 + l) * 8 + j] = lo;
           }
+      LF_TRY(upload16(wx, &c.d_wx));
+    }
+    if (c.cout == 16 && c.cin == 8 && c.stride == 2 && c.ks == 3) {
+      // k_down16x stage 1: fragment (hi | lo, ky): element j = ci of lane (cout l & 15, kx = l >> 4) is w[cout][ci][ky][kx]
+      // (kx = 3: zero)
+      std::vector<uint16_t> wx(down16::W1FRAG, 0);
+      for (int g = 0; g < 3; g++)
+        for (int l = 0; l < 64; l++)
+          for (int j = 0; j < 8; j++) {
+            const int co = l & 15, kx = l >> 4;
+            float v = kx < 3 ? (*w)[(((size_t)co * 8 + j) * 3 + g) * 3 + kx] : 0.f;
+            if (const char* only = getenv("MSF_DBG_W1"))   // debugging aid: keep one tap "ky,kx"
+              if (only[0] - '0' != g || only[2] - '0' != kx) v = 0.f;
+            const uint16_t hi = to_bf16(v), lo = to_bf16(v - from_bf16(hi));
+            wx[((size_t)(0 * 3 + g) * 64 + l) * 8 + j] = hi;
+            wx[((size_t)(1 * 3 + g) * 64 + l) * 8 + j] = lo;
+          }
+      LF_TRY(upload16(wx, &c.d_wx));
+    }
+    if (c.cout == 16 && c.cin == 8 && c.stride == 2 && c.ks == 1) {
+      // k_down16x shortcut: rides on the ky = 1 fragments, whose kx = 1 block is the pixel (2Y, 2X): other blocks zero
+      std::vector<uint16_t> wx(down16::WSFRAG, 0);
+      for (int l = 0; l < 64; l++)
+        for (int j = 0; j < 8; j++) {
+          const int co = l & 15, kx = l >> 4;
+          const float v = kx == 1 ? (*w)[(size_t)co * 8 + j] : 0.f;
+          const uint16_t hi = to_bf16(v), lo = to_bf16(v - from_bf16(hi));
+          wx[((size_t)0 * 64 + l) * 8 + j] = hi;
+          wx[((size_t)1 * 64 + l) * 8 + j] = lo;
+        }
       LF_TRY(upload16(wx, &c.d_wx));
     }
     if (c.cout == 16 && c.cin == 16 && c.stride == 1) {
@@ -2579,6 +2858,20 @@ void launch_stem_strip8x(const ConvDesc* cv, const uint8_t* frames, long long fr
                      row_stride, cv[0].d_wx, cv[0].d_b, sw, out, cv[1].hout, cv[1].wout, n_strips);
 }
 
+// down-sampling block 8 -> 16 as one streaming pass (k_down16x): cs2 = 3x3 stride 2, csc = 1x1 stride 2, c2 = 3x3
+void launch_down16x(const ConvDesc& cs2, const ConvDesc& csc, const ConvDesc& c2, const float* in, float* out, int n_img,
+                    hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_down16x), hipFuncAttributeMaxDynamicSharedMemorySize, down16::LDS_BYTES);
+    attr_set = true;
+  }
+  DownW dw{cs2.d_wx, csc.d_wx, c2.d_wx, cs2.d_b, csc.d_b, c2.d_b, getenv("MSF_DBG_DOWN") ? atoi(getenv("MSF_DBG_DOWN")) : 0};
+  const int n_strips = c2.wout / down16::S;
+  hipLaunchKernelGGL(k_down16x, dim3(n_strips * n_img), dim3(64 * down16::WAVES), down16::LDS_BYTES, st, in, dw, out, c2.hout,
+                     c2.wout, n_strips);
+}
+
 // the 16-channel BasicBlock on split-bf16 MFMAs (k_block16x)
 void launch_block16x(const ConvDesc& ca, const ConvDesc& cb, const float* in, float* out, int n_img, hipStream_t st) {
   static bool attr_set = false;
@@ -2730,8 +3023,13 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
   keep(0, a, 8u * 240 * 320);
   // layer2 @120x160, 16 ch
   const long long s16 = 16LL * 120 * 160;
-  launch_conv<8, 16, 3, 2, 32, true, false, false, 1, true>(c[5], a, s8, 0, nullptr, b, ni, st, &c[7], d);   // + shortcut -> d
-  launch_conv<16, 16, 3, 1, 32, true, true, false>(c[6], b, s16, 0, d, cc, ni, st);              // cc = 205
+  if (P.fuse_blocks && P.split_bf16 && strip_mode != 0 && P.down_stream) {
+    launch_down16x(c[5], c[7], c[6], a, cc, ni, st);                                               // cc = 205
+  } else {
+    launch_conv<8, 16, 3, 2, 32, true, false, false, 1, true>(c[5], a, s8, 0, nullptr, b, ni, st, &c[7], d);   // + shortcut -> d
+    launch_conv<16, 16, 3, 1, 32, true, true, false>(c[6], b, s16, 0, d, cc, ni, st);              // cc = 205
+  }
+  if (getenv("MSF_DBG_ACT1_CC")) keep(1, cc, 16u * 120 * 160);   // debugging aid: stage 1 = the down block's output
   if (P.fuse_blocks) {
     if (P.split_bf16) launch_block16x(c[8], c[9], cc, a, ni, st);                                  // a = 212
     else launch_block16(c[8], c[9], cc, a, ni, st);
@@ -2739,7 +3037,7 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
     launch_conv<16, 16, 3, 1, 32, true, false, false>(c[8], cc, s16, 0, nullptr, b, ni, st);
     launch_conv<16, 16, 3, 1, 32, true, true, false>(c[9], b, s16, 0, cc, a, ni, st);              // a = 212
   }
-  keep(1, a, 16u * 120 * 160);
+  if (!getenv("MSF_DBG_ACT1_CC")) keep(1, a, 16u * 120 * 160);
   // layer3 @60x80, 32 ch
   const long long s32 = 32LL * 60 * 80;
   launch_conv<16, 32, 3, 2, 16, true, false, false, 1, true>(c[10], a, s16, 0, nullptr, b, ni, st, &c[12], d);

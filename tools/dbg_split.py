@@ -23,16 +23,18 @@ def run(env):
     return out
 
 
-x, f = run({"MSF_LOFTR_STRIP_MIN": "1"}), run({"MSF_LOFTR_F32": "1"})
-np.set_printoptions(precision=2, linewidth=250, suppress=False)
-for k in ("a0", "a1", "a2", "a3", "conf"):
-    d = np.abs(x[k] - f[k])
-    print(k, "scale %.3g  |d| median %.3g p99 %.3g max %.3g" % (np.abs(f[k]).mean(), np.median(d), np.percentile(d, 99), d.max()))
-d = np.abs(x["a0"] - f["a0"])
-print("a0 per-channel max", d.max(axis=(1, 2)))
-pm = d.max(axis=0)
-print("a0 row-max by 8-row band:", pm.reshape(30, 8, 320).max(axis=(1, 2)))
-print("a0 row-max by row mod 8:", pm.reshape(30, 8, 320).max(axis=(0, 2)))
-print("a0 col-max by 64-col tile:", pm.reshape(240, 5, 64).max(axis=(0, 2)))
-print("a0 col-max by col mod 16:", pm.reshape(240, 20, 16).max(axis=(0, 1)))
-print("a0 col-max by col mod 64 (first/last 3):", pm.reshape(240, 5, 64).max(axis=(0, 1))[[0, 1, 2, 61, 62, 63]])
+if __name__ == "__main__":
+    x, f = run({"MSF_LOFTR_STRIP_MIN": "1"}), run({"MSF_LOFTR_F32": "1"})
+    np.set_printoptions(precision=2, linewidth=250, suppress=False)
+    for k in ("a0", "a1", "a2", "a3", "conf"):
+        d = np.abs(x[k] - f[k])
+        print(k, "scale %.3g  |d| median %.3g p99 %.3g max %.3g" % (np.abs(f[k]).mean(), np.median(d), np.percentile(d, 99), d.max()))
+    d = np.abs(x["a0"] - f["a0"])
+    print("a0 per-channel max", d.max(axis=(1, 2)))
+    pm = d.max(axis=0)
+    print("a0 row-max by 8-row band:", pm.reshape(30, 8, 320).max(axis=(1, 2)))
+    print("a0 row-max by row mod 8:", pm.reshape(30, 8, 320).max(axis=(0, 2)))
+    print("a0 col-max by 64-col tile:", pm.reshape(240, 5, 64).max(axis=(0, 2)))
+    print("a0 col-max by col mod 16:", pm.reshape(240, 20, 16).max(axis=(0, 1)))
+    print("a0 col-max by col mod 64 (first/last 3):", pm.reshape(240, 5, 64).max(axis=(0, 1))[[0, 1, 2, 61, 62, 63]])
+
