@@ -2,7 +2,10 @@
 //
 // Reference entry point: ::DNNFeatureMatcher::MatchFrames (src/dnnfeaturematcher.cpp:44-102):
 //   ConvertImageToFloat (:5-9)  -> fused into the stem convolution's tile load
-//   Ort::Session::Run (:62-64)  -> k_conv (21 convolutions as implicit GEMM on v_mfma_f32_16x16x4_f32, exact f32),
+//   Ort::Session::Run (:62-64)  -> the 21 convolutions: default k_stem_strip8x / k_strip8x / k_down16x (streaming
+//                                  strips), k_block16x, k_convx on split-bf16 MFMAs (three bf16 products of hi/lo-split
+//                                  f32 operands, f32 accumulation) + three f32 k_conv; MSF_FLAG_LOFTR_F32: k_conv /
+//                                  k_block8 / k_block16 on v_mfma_f32_16x16x4_f32 (exact f32) throughout;
 //                                  k_tokens (PE add + layout), k_attn_kv / k_attn_update (8 linear-attention
 //                                  encoder blocks), k_sim_stats / k_conf_mask (similarity + dual softmax)
 //   '> threshold' + findNonZero + decode (:75-99) -> k_conf_mask (bit mask, conf never written to HBM) + k_decode
