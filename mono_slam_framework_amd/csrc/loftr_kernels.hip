@@ -2145,9 +2145,24 @@ __global__ __launch_bounds__(256) void k_attn_update(const float* __restrict__ x
 
 // ------------------------------------------------------------------ matching head (MFMA)
 // s_ij = ((f0_i / sqrt(32)) . (f1_j / sqrt(32))) / 0.1 on 16x16 tiles, P8 slot order on both operands.
-__global__ __launch_bounds__(256) void k_scale_feats(const float* __restrict__ in, float* __restrict__ out, long long n) {
+// planes (split path): the scaled features also as three bf16 planes per pair, v = h + m + l exactly (24 significand
+// bits in 3 x 8): [pair][3][1200 * 32].  k_sim_stats<.., true> then forms s = f0 . f1 from six bf16 MFMAs
+// (h.h, h.m, m.h, h.l, l.h, m.m: everything above 2^-24 of the product) with no split arithmetic in its inner loop.
+__global__ __launch_bounds__(256) void k_scale_feats(const float* __restrict__ in, float* __restrict__ out, long long n,
+                                                     __bf16* __restrict__ planes, long long ts) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) out[i] = in[i] / 5.656854f;
+  if (i >= n) return;
+  const float v = in[i] / 5.656854f;
+  out[i] = v;
+  if (planes) {
+    const long long pair = i / ts, e = i - pair * ts;
+    const __bf16 h = (__bf16)v;
+    const float r1 = v - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const __bf16 l = (__bf16)(r1 - (float)m);
+    __bf16* dst = planes + pair * 3 * ts + e;
+    dst[0] = h; dst[ts] = m; dst[2 * ts] = l;
+  }
 }
 
 // x / 0.1f, correctly rounded, in three instructions: 10.0f is the correctly rounded reciprocal of 0.1f, so one
@@ -2186,18 +2201,28 @@ __global__ __launch_bounds__(256) void k_row_limits(const float* __restrict__ rs
   lim[idx] = rs[i] + __logf(threshold * rs[NTOK + i]) - 1e-2f;
 }
 
-template <bool EMIT>
+template <bool EMIT, bool SPLIT>
 __global__ __launch_bounds__(256) void k_sim_stats(const float* __restrict__ fa, const float* __restrict__ fb,
                                                    long long pair_stride, float* __restrict__ stats /*[pair][2][1200]*/,
                                                    long long stats_stride, const float* __restrict__ lim,
-                                                   SimCand* __restrict__ cand, uint32_t* __restrict__ cand_cnt) {
+                                                   SimCand* __restrict__ cand, uint32_t* __restrict__ cand_cnt,
+                                                   const __bf16* __restrict__ pa, const __bf16* __restrict__ pb) {
   const int pair = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tl = lane & 15, g = lane >> 4;
   const int it = blockIdx.x * 4 + wave;
   if (it >= NTOK / 16) return;
   const float* A = fa + (long long)pair * pair_stride;
   const float* B = fb + (long long)pair * pair_stride;
   float a[8];
-  load8(A + (long long)(it * 16 + tl) * DM + 8 * g, a);
+  bf16x8 a3[3];
+  const bf16x8* PA = reinterpret_cast<const bf16x8*>(pa + (SPLIT ? (long long)pair * 3 * pair_stride : 0));
+  const bf16x8* PB = reinterpret_cast<const bf16x8*>(pb + (SPLIT ? (long long)pair * 3 * pair_stride : 0));
+  constexpr int kPlane = NTOK * DM / 8;                  // bf16x8 fragments per plane
+  if (SPLIT) {
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) a3[pl] = PA[pl * kPlane + (it * 16 + tl) * (DM / 8) + g];
+  } else {
+    load8(A + (long long)(it * 16 + tl) * DM + 8 * g, a);
+  }
   float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, sm[4] = {0.f, 0.f, 0.f, 0.f};
   // three column tiles per step: three independent MFMA chains in flight, and the running (max, sum) of a row is
   // rescaled once per three new entries (4 exponentials per 3 entries, no divergent branch)
@@ -2207,11 +2232,24 @@ __global__ __launch_bounds__(256) void k_sim_stats(const float* __restrict__ fa,
     f32x4 d[TJ];
 #pragma unroll
     for (int u = 0; u < TJ; u++) {
-      float b[8];
-      load8(B + (long long)((jt0 + u) * 16 + tl) * DM + 8 * g, b);
       d[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (SPLIT) {
+        bf16x8 b3[3];
 #pragma unroll
-      for (int sI = 0; sI < 8; sI++) d[u] = mfma4(a[sI], b[sI], d[u]);
+        for (int pl = 0; pl < 3; pl++) b3[pl] = PB[pl * kPlane + ((jt0 + u) * 16 + tl) * (DM / 8) + g];
+        // K = 32 is one MFMA: the six products above 2^-24, smallest first
+        d[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[2], b3[0], d[u], 0, 0, 0);
+        d[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[0], b3[2], d[u], 0, 0, 0);
+        d[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[1], b3[1], d[u], 0, 0, 0);
+        d[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[1], b3[0], d[u], 0, 0, 0);
+        d[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[0], b3[1], d[u], 0, 0, 0);
+        d[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[0], b3[0], d[u], 0, 0, 0);
+      } else {
+        float b[8];
+        load8(B + (long long)((jt0 + u) * 16 + tl) * DM + 8 * g, b);
+#pragma unroll
+        for (int sI = 0; sI < 8; sI++) d[u] = mfma4(a[sI], b[sI], d[u]);
+      }
     }
     float sv[TJ][4];
 #pragma unroll
@@ -2437,6 +2475,7 @@ struct LoftrPipeline::Impl {
   float* tok_cache = nullptr;  // [n_slots][1200][32] backbone tokens per frame slot (extract / match_slots)
   int n_slots = 0;             // 2 * max_pairs caller-visible slots + the handle's transparent frame cache
   float* fsc = nullptr;      // [2][max_pairs][1200][32] features / sqrt(32)
+  __bf16* fsp = nullptr;     // [2][max_pairs][3][1200][32]: the same as three bf16 planes (split path)
   float* kv = nullptr;       // [max_pairs][1056]
   float* rstats = nullptr;   // [max_pairs][2][1200]
   float* cstats = nullptr;
@@ -2751,6 +2790,11 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
   for (int i = 0; i < 4; i++) LF_TRY(dalloc(&P.tok[i], (size_t)max_pairs * NTOK * DM));
   LF_TRY(dalloc(&P.tok_cache, (size_t)P.n_slots * NTOK * DM));
   LF_TRY(dalloc(&P.fsc, (size_t)2 * max_pairs * NTOK * DM));
+  {
+    float* m = nullptr;
+    LF_TRY(dalloc(&m, (size_t)3 * max_pairs * NTOK * DM));   // 2 x 3 bf16 planes = 3 floats per feature
+    P.fsp = reinterpret_cast<__bf16*>(m);
+  }
   LF_TRY(dalloc(&P.kv, (size_t)max_pairs * (DM * DM + DM)));
   LF_TRY(dalloc(&P.rstats, (size_t)max_pairs * 2 * NTOK));
   LF_TRY(dalloc(&P.cstats, (size_t)max_pairs * 2 * NTOK));
@@ -3093,18 +3137,24 @@ hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf
   // ---- matching head on (f0, f1)
   float* f0s = P.fsc;
   float* f1s = P.fsc + (long long)P.max_pairs * ts;
-  hipLaunchKernelGGL(k_scale_feats, dim3((unsigned)((n * ts + 255) / 256)), dim3(256), 0, st, f0, f0s, n * ts);
-  hipLaunchKernelGGL(k_scale_feats, dim3((unsigned)((n * ts + 255) / 256)), dim3(256), 0, st, f1, f1s, n * ts);
+  __bf16* p0 = P.split_bf16 ? P.fsp : nullptr;      // split path: the scaled features also as three bf16 planes
+  __bf16* p1 = P.split_bf16 ? P.fsp + (long long)P.max_pairs * 3 * ts : nullptr;
+  hipLaunchKernelGGL(k_scale_feats, dim3((unsigned)((n * ts + 255) / 256)), dim3(256), 0, st, f0, f0s, n * ts, p0, ts);
+  hipLaunchKernelGGL(k_scale_feats, dim3((unsigned)((n * ts + 255) / 256)), dim3(256), 0, st, f1, f1s, n * ts, p1, ts);
   const int head_blocks = (NTOK / 16 + 3) / 4;
-  hipLaunchKernelGGL(k_sim_stats<false>, dim3(head_blocks, n), dim3(256), 0, st, f0s, f1s, ts, P.rstats, 2LL * NTOK, nullptr,
-                     nullptr, nullptr);
+  if (p0) hipLaunchKernelGGL((k_sim_stats<false, true>), dim3(head_blocks, n), dim3(256), 0, st, f0s, f1s, ts, P.rstats, 2LL * NTOK,
+                             nullptr, nullptr, nullptr, p0, p1);
+  else hipLaunchKernelGGL((k_sim_stats<false, false>), dim3(head_blocks, n), dim3(256), 0, st, f0s, f1s, ts, P.rstats, 2LL * NTOK,
+                          nullptr, nullptr, nullptr, nullptr, nullptr);
   if (threshold >= kCandMinThreshold && !P.dense_head) {
     // sparse path: the column pass lists the few entries per row that can pass, k_conf_cand evaluates them exactly
     hipMemsetAsync(P.cand_cnt, 0, (size_t)n * sizeof(uint32_t), st);
     hipMemsetAsync(P.mask, 0, (size_t)n * NTOK * MASK_WORDS * sizeof(uint32_t), st);
     hipLaunchKernelGGL(k_row_limits, dim3((n * NTOK + 255) / 256), dim3(256), 0, st, P.rstats, 2LL * NTOK, threshold, P.lim, n);
-    hipLaunchKernelGGL(k_sim_stats<true>, dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats, 2LL * NTOK, P.lim,
-                       P.cand, P.cand_cnt);
+    if (p0) hipLaunchKernelGGL((k_sim_stats<true, true>), dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats, 2LL * NTOK,
+                               P.lim, P.cand, P.cand_cnt, p1, p0);
+    else hipLaunchKernelGGL((k_sim_stats<true, false>), dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats, 2LL * NTOK,
+                            P.lim, P.cand, P.cand_cnt, nullptr, nullptr);
     // pair 0's confidence matrix (+ its mask, densely) is kept for the parity tests
     if (P.keep_debug)
       hipLaunchKernelGGL(k_conf_mask, dim3(head_blocks, 1), dim3(256), 0, st, f0s, f1s, ts, P.rstats, P.cstats, 2LL * NTOK,
@@ -3112,8 +3162,10 @@ hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf
     hipLaunchKernelGGL(k_conf_cand, dim3(8, n), dim3(256), 0, st, P.cand, P.cand_cnt, P.rstats, P.cstats, 2LL * NTOK, threshold,
                        P.mask);
   } else {
-    hipLaunchKernelGGL(k_sim_stats<false>, dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats, 2LL * NTOK, nullptr,
-                       nullptr, nullptr);
+    if (p0) hipLaunchKernelGGL((k_sim_stats<false, true>), dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats,
+                               2LL * NTOK, nullptr, nullptr, nullptr, p1, p0);
+    else hipLaunchKernelGGL((k_sim_stats<false, false>), dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats,
+                            2LL * NTOK, nullptr, nullptr, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(k_conf_mask, dim3(head_blocks, n), dim3(256), 0, st, f0s, f1s, ts, P.rstats, P.cstats, 2LL * NTOK,
                        threshold, P.mask, P.keep_debug ? P.conf_dbg : nullptr, 0);
   }
