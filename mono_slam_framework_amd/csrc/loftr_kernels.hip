@@ -1745,6 +1745,165 @@ __global__ __launch_bounds__(256, 2) void k_convx(const float* __restrict__ in, 
 #undef MSF_CX_ISSUE
 }
 
+// ------------------------------------------------------------------ 3x3 stride-2 convolution CIN -> 32 + 1x1 stride-2 shortcut, split-bf16
+// The entry convolutions of layer3 (16 -> 32) and layer4 (32 -> 32) in k_convx's form: a workgroup walks the 16-pixel x
+// tiles of a band of output rows, input tile in LDS as [hi | lo][channel block][row][column] planes of 16-byte pixels
+// with the columns de-interleaved (even | odd), so the fragment of 16 neighbouring stride-2 pixels is 16 consecutive
+// slots.  K = 32 of an MFMA: CIN = 32: the 4 channel blocks of one tap (9 groups); CIN = 16: two taps x 2 channel blocks
+// (5 groups, the tenth tap has zero weights).  The shortcut's input pixel is the centre tap: its fragment is already in
+// registers, three more MFMAs per output-channel tile into a second accumulator (weights in registers).
+// Output rows per wave: 2 (CIN = 16, band of 8) or 1 (CIN = 32, band of 4: the tile has twice the planes).
+namespace cvx2 {
+constexpr int OTW = 16;
+constexpr int IN_W = 2 * OTW + 1;                  // 33 columns: 2 ox0 - 1 .. 2 ox0 + 31
+constexpr int PITCH = 36, IODD = 18;               // even columns in slots 0 .. 16, odd columns in slots 18 .. 33
+template <int CIN>
+struct Cfg {
+  static_assert(CIN == 16 || CIN == 32, "k_convx2: 16 or 32 input channels");
+  static constexpr int NCB = CIN / 8, NT = 2;
+  static constexpr int RPW = CIN == 16 ? 2 : 1;    // output rows per wave
+  static constexpr int OTH = 4 * RPW;
+  static constexpr int IN_H = 2 * OTH + 1;
+  static constexpr int G = CIN == 32 ? 9 : 5;
+  static constexpr int GC = CIN == 32 ? 4 : 2;     // the MFMA group that holds the centre tap
+  static constexpr int CBPLANE = IN_H * PITCH;
+  static constexpr int HLPLANE = NCB * CBPLANE;
+  static constexpr int XSLOTS = 2 * HLPLANE;
+  static constexpr int WSLOTS = G * NT * 2 * 64;   // [g][cout tile][hi | lo][lane]
+  static constexpr int SCSLOTS = NT * 2 * 64;      // shortcut: [cout tile][hi | lo][lane]
+  static constexpr int LDS_BYTES = 16 * (XSLOTS + WSLOTS);
+  static constexpr int NITEMS = NCB * IN_H * IN_W;
+  static constexpr int NLD = (NITEMS + 255) / 256;
+};
+}  // namespace cvx2
+
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void k_convx2(const float* __restrict__ in, const uint16_t* __restrict__ wx,
+                                                   const float* __restrict__ bias, const uint16_t* __restrict__ wsc,
+                                                   const float* __restrict__ bias_sc, float* __restrict__ out,
+                                                   float* __restrict__ out_sc, int Hin, int Win, int H, int W, int n_bands) {
+  using namespace cvx2;
+  using F = Cfg<CIN>;
+  constexpr int COUT = 32;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  bf16x8* xs = reinterpret_cast<bf16x8*>(lds);
+  bf16x8* ws = xs + F::XSLOTS;
+  const int nwg = gridDim.x, per = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7;
+  const int unit = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+  const int img = unit / n_bands;
+  const int oy0 = (unit - img * n_bands) * F::OTH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const long long HWin = (long long)Hin * Win;
+  const float* inf = in + (long long)img * CIN * HWin;
+  {
+    const bf16x8* src = reinterpret_cast<const bf16x8*>(wx);
+    for (int idx = tid; idx < F::WSLOTS; idx += 256) ws[idx] = src[idx];
+  }
+  bf16x8 sch[F::NT], scl[F::NT];                   // shortcut fragments stay in registers
+#pragma unroll
+  for (int n = 0; n < F::NT; n++) {
+    sch[n] = reinterpret_cast<const bf16x8*>(wsc)[(n * 2 + 0) * 64 + lane];
+    scl[n] = reinterpret_cast<const bf16x8*>(wsc)[(n * 2 + 1) * 64 + lane];
+  }
+  // staging items: (channel block, tile row, tile column) -> 8 channel dwords of one pixel
+  constexpr int kNoRow = -(1 << 30);
+  float pre[F::NLD][8];
+  int goff[F::NLD], lslot[F::NLD], col[F::NLD];
+#pragma unroll
+  for (int u = 0; u < F::NLD; u++) {
+    const int idx = tid + 256 * u;
+    const int cb = idx / (F::IN_H * IN_W), rm = idx - cb * (F::IN_H * IN_W);
+    const int r = rm / IN_W, c = rm - r * IN_W;
+    const int gy = 2 * oy0 - 1 + r;
+    col[u] = c - 1;
+    lslot[u] = idx < F::NITEMS ? cb * F::CBPLANE + r * PITCH + ((c & 1) ? IODD + (c >> 1) : (c >> 1)) : -1;
+    goff[u] = (idx < F::NITEMS && gy >= 0 && gy < Hin) ? (8 * cb * Hin + gy) * Win + c - 1 : kNoRow;
+  }
+#define MSF_C2_ISSUE(ox0_)                                                                        \
+  {                                                                                               \
+    _Pragma("unroll") for (int u = 0; u < F::NLD; u++) {                                          \
+      const int gx = 2 * (ox0_) + col[u];                                                         \
+      const bool ok = goff[u] != kNoRow && gx >= 0 && gx < Win;                                   \
+      const float* src = inf + (ok ? goff[u] + 2 * (ox0_) : 0);                                   \
+      _Pragma("unroll") for (int c = 0; c < 8; c++) pre[u][c] = ok ? src[c * HWin] : 0.f;         \
+    }                                                                                             \
+  }
+  // this lane's K block of MFMA group g: CIN = 32: tap g, channel block kq; CIN = 16: tap 2g + (kq >> 1), block kq & 1
+  int foff[F::G];
+#pragma unroll
+  for (int g = 0; g < F::G; g++) {
+    int t = CIN == 32 ? g : 2 * g + (kq >> 1);
+    t = t < 9 ? t : 8;
+    const int ky = t / 3, kx = t - 3 * ky;
+    const int cb = CIN == 32 ? kq : (kq & 1);
+    foff[g] = cb * F::CBPLANE + ky * PITCH + (kx == 1 ? IODD + i : kx == 0 ? i : i + 1);
+  }
+  const int ntx = (W + OTW - 1) / OTW;
+  MSF_C2_ISSUE(0)
+  for (int tx = 0; tx < ntx; tx++) {
+    const int ox0 = tx * OTW;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < F::NLD; u++) {
+      if (lslot[u] < 0) continue;
+      bf16x4 h0, l0, h1, l1;
+      split4(f32x4{pre[u][0], pre[u][1], pre[u][2], pre[u][3]}, h0, l0);
+      split4(f32x4{pre[u][4], pre[u][5], pre[u][6], pre[u][7]}, h1, l1);
+      bf16x4* dst = reinterpret_cast<bf16x4*>(xs + lslot[u]);
+      dst[0] = h0; dst[1] = h1; dst[2 * F::HLPLANE] = l0; dst[2 * F::HLPLANE + 1] = l1;
+    }
+    __syncthreads();
+    if (tx + 1 < ntx) MSF_C2_ISSUE(ox0 + OTW)
+
+    f32x4 acc[F::RPW][F::NT], asc[F::RPW][F::NT];
+#pragma unroll
+    for (int u = 0; u < F::RPW; u++)
+#pragma unroll
+      for (int n = 0; n < F::NT; n++) { acc[u][n] = f32x4{0.f, 0.f, 0.f, 0.f}; asc[u][n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int g = 0; g < F::G; g++) {
+      bf16x8 bh[F::NT], bl[F::NT];
+#pragma unroll
+      for (int n = 0; n < F::NT; n++) {
+        bh[n] = ws[((g * F::NT + n) * 2 + 0) * 64 + lane];
+        bl[n] = ws[((g * F::NT + n) * 2 + 1) * 64 + lane];
+      }
+#pragma unroll
+      for (int u = 0; u < F::RPW; u++) {
+        const int slot = foff[g] + 2 * (wave + 4 * u) * PITCH;     // output row wave + 4u: input rows 2 (wave + 4u) + ky
+        const bf16x8 ah = xs[slot], al = xs[F::HLPLANE + slot];
+#pragma unroll
+        for (int n = 0; n < F::NT; n++) {
+          acc[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[u][n], 0, 0, 0);
+          acc[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[u][n], 0, 0, 0);
+          acc[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[u][n], 0, 0, 0);
+          if (g == F::GC) {
+            asc[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, scl[n], asc[u][n], 0, 0, 0);
+            asc[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, sch[n], asc[u][n], 0, 0, 0);
+            asc[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, sch[n], asc[u][n], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // epilogue: D[pixel 4 kq + r][cout 16 n + i] -> out (bias, ReLU) and out_sc (bias, no ReLU), 4 consecutive px
+#pragma unroll
+    for (int u = 0; u < F::RPW; u++)
+#pragma unroll
+      for (int n = 0; n < F::NT; n++) {
+        const int oy = oy0 + wave + 4 * u, px = ox0 + 4 * kq, co = 16 * n + i;
+        if (oy >= H || px >= W) continue;
+        const float bv = bias[co], bs = bias_sc[co];
+        f32x4 v = acc[u][n] + f32x4{bv, bv, bv, bv};
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        const long long o = (((long long)img * COUT + co) * H + oy) * W + px;
+        *reinterpret_cast<f32x4*>(out + o) = v;
+        *reinterpret_cast<f32x4*>(out_sc + o) = asc[u][n] + f32x4{bs, bs, bs, bs};
+      }
+  }
+#undef MSF_C2_ISSUE
+}
+
 // ------------------------------------------------------------------ fused BasicBlock, 16 channels, stride 1 (layer2 @ 120 x 160)
 // The same scheme as k_block8 without row packing (the 16 MFMA columns are the 16 output channels): a workgroup owns a
 // band of R = 8 output rows and walks its x tiles of 32 columns; wave w takes M tile w & 1 (16 columns) of the t rows
@@ -2709,6 +2868,41 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
           }
       LF_TRY(upload16(wx, &c.d_wx));
     }
+    if (c.cout == 32 && c.stride == 2 && c.ks == 3) {
+      // k_convx2<CIN>: fragment (g, cout tile n, hi | lo): lane (cout 16 n + (l & 15), kq = l >> 4), element j:
+      //   CIN = 32: w[cout][ci = 8 kq + j][tap g];  CIN = 16: w[cout][ci = 8 (kq & 1) + j][tap 2 g + (kq >> 1)] (tenth tap: 0)
+      const int G = c.cin == 32 ? 9 : 5;
+      std::vector<uint16_t> wx((size_t)G * 2 * 2 * 64 * 8, 0);
+      for (int g = 0; g < G; g++)
+        for (int n = 0; n < 2; n++)
+          for (int l = 0; l < 64; l++)
+            for (int j = 0; j < 8; j++) {
+              const int co = 16 * n + (l & 15), q = l >> 4;
+              const int t = c.cin == 32 ? g : 2 * g + (q >> 1), ci = c.cin == 32 ? 8 * q + j : 8 * (q & 1) + j;
+              const float v = t < 9 ? (*w)[(((size_t)co * c.cin + ci) * 3 + t / 3) * 3 + t % 3] : 0.f;
+              const uint16_t hi = to_bf16(v), lo = to_bf16(v - from_bf16(hi));
+              wx[((size_t)((g * 2 + n) * 2 + 0) * 64 + l) * 8 + j] = hi;
+              wx[((size_t)((g * 2 + n) * 2 + 1) * 64 + l) * 8 + j] = lo;
+            }
+      LF_TRY(upload16(wx, &c.d_wx));
+    }
+    if (c.cout == 32 && c.stride == 2 && c.ks == 1) {
+      // k_convx2 shortcut: rides on the centre tap's fragment: CIN = 32: every K block (channel block kq);
+      // CIN = 16: the blocks of tap 4 = kq 0, 1 of group 2 (kq 2, 3 hold tap 5: zero)
+      std::vector<uint16_t> wx((size_t)2 * 2 * 64 * 8, 0);
+      for (int n = 0; n < 2; n++)
+        for (int l = 0; l < 64; l++)
+          for (int j = 0; j < 8; j++) {
+            const int co = 16 * n + (l & 15), q = l >> 4;
+            const bool live = c.cin == 32 || q < 2;
+            const int ci = c.cin == 32 ? 8 * q + j : 8 * (q & 1) + j;
+            const float v = live ? (*w)[(size_t)co * c.cin + ci] : 0.f;
+            const uint16_t hi = to_bf16(v), lo = to_bf16(v - from_bf16(hi));
+            wx[((size_t)(n * 2 + 0) * 64 + l) * 8 + j] = hi;
+            wx[((size_t)(n * 2 + 1) * 64 + l) * 8 + j] = lo;
+          }
+      LF_TRY(upload16(wx, &c.d_wx));
+    }
     if (c.cout == 32 && c.cin == 32 && c.stride == 1 && c.ks == 3) {
       // k_convx<32>: fragment (tap g, cout tile n, hi | lo): element j of lane (cout 16 n + (l & 15), channel block l >> 4)
       // is w[cout][ci = 8 (l >> 4) + j][ky = g / 3][kx = g % 3]
@@ -2946,6 +3140,21 @@ void launch_convx(const ConvDesc& c, const float* in, const float* res, float* o
                      n_bands);
 }
 
+// 3x3 stride-2 CIN -> 32 convolution + ReLU with its 1x1 stride-2 shortcut on split-bf16 MFMAs (k_convx2)
+template <int CIN>
+void launch_convx2(const ConvDesc& c, const ConvDesc& sc, const float* in, float* out, float* out_sc, int n_img, hipStream_t st) {
+  using F = cvx2::Cfg<CIN>;
+  auto kern = k_convx2<CIN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, F::LDS_BYTES);
+    attr_set = true;
+  }
+  const int n_bands = (c.hout + F::OTH - 1) / F::OTH;
+  hipLaunchKernelGGL(kern, dim3(n_bands * n_img), dim3(256), F::LDS_BYTES, st, in, c.d_wx, c.d_b, sc.d_wx, sc.d_b, out, out_sc,
+                     c.hin, c.win, c.hout, c.wout, n_bands);
+}
+
 // the same for a 16-channel, stride-1 BasicBlock at 120 x 160 (k_block16)
 void launch_block16(const ConvDesc& ca, const ConvDesc& cb, const float* in, float* out, int n_img, hipStream_t st) {
   const size_t lds = (size_t)blk16::LDS_FLOATS * sizeof(float);
@@ -3087,7 +3296,8 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
   if (!getenv("MSF_DBG_ACT1_CC")) keep(1, a, 16u * 120 * 160);
   // layer3 @60x80, 32 ch
   const long long s32 = 32LL * 60 * 80;
-  launch_conv<16, 32, 3, 2, 16, true, false, false, 1, true>(c[10], a, s16, 0, nullptr, b, ni, st, &c[12], d);
+  if (P.split_bf16) launch_convx2<16>(c[10], c[12], a, b, d, ni, st);
+  else launch_conv<16, 32, 3, 2, 16, true, false, false, 1, true>(c[10], a, s16, 0, nullptr, b, ni, st, &c[12], d);
   if (P.split_bf16) {
     launch_convx<32, true>(c[11], b, d, cc, ni, st);                                               // cc = 221
     launch_convx<32, false>(c[13], cc, nullptr, b, ni, st);
@@ -3100,7 +3310,8 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
   keep(2, a, 32u * 60 * 80);
   // layer4 @30x40, 32 ch
   const long long s40 = 32LL * 30 * 40;
-  launch_conv<32, 32, 3, 2, 16, true, false, false, 1, true>(c[15], a, s32, 0, nullptr, b, ni, st, &c[17], d);
+  if (P.split_bf16) launch_convx2<32>(c[15], c[17], a, b, d, ni, st);
+  else launch_conv<32, 32, 3, 2, 16, true, false, false, 1, true>(c[15], a, s32, 0, nullptr, b, ni, st, &c[17], d);
   if (P.split_bf16) {
     launch_convx<32, true>(c[16], b, d, cc, ni, st);                                               // cc = 237
     launch_convx<32, false>(c[18], cc, nullptr, b, ni, st);
