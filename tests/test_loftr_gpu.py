@@ -74,6 +74,21 @@ def test_batch_equals_single_and_chunks():
         np.testing.assert_array_equal(r, g)
 
 
+def test_streaming_batch_matches_the_oracle_per_pair():
+    """A batch of 40 pairs = 80 images takes the streaming layer-1 / layer-2 kernels (backbone passes of >= 64 images;
+    single pairs take the banded ones).  Spot-checked pairs must give the oracle's list wherever no confidence is
+    within the tolerance of the threshold, and the batch must agree with single calls under the same rule."""
+    n = 40
+    A, B = synth.synth_batch(4100, n, 640, 480, mode=1)
+    batched = _dm(0.15, pairs=n).match_batch(list(A), list(B), cap=8192)
+    single = _dm(0.15)
+    for k in (0, 17, 39):
+        full_ref = oracle_loftr.DNNFeatureMatcherOracle(0.15).run(A[k], B[k])["conf"]
+        assert len(batched[k]) > 10
+        _check_lists(batched[k], full_ref, 0.15)
+        _check_lists(single.MatchFrames(A[k], B[k], cap=8192), full_ref, 0.15)
+
+
 def test_low_threshold_capacity_and_count():
     a, b = G["img0_ii"], G["img1_ii"]
     dm = _dm(1e-4)
