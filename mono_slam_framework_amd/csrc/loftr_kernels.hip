@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256, 2) void k_block8x(const float* __restrict__ in
       const int xb = kq * XP + 16 * q + i;
 #pragma unroll
       for (int u = 0; u < 5; u++) {
-        if (u >= nu) break;
+        if (u >= nu) continue;                       // wave-uniform
         const int uu = pass == 0 ? u : (u == 0 ? m : 4);
 #pragma unroll
         for (int g = 0; g < 3; g++) {
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256, 2) void k_block8x(const float* __restrict__ in
       const int gx = TW * k - 1 + tc;
 #pragma unroll
       for (int u = 0; u < 5; u++) {
-        if (u >= nu) break;
+        if (u >= nu) continue;
         const int uu = pass == 0 ? u : (u == 0 ? m : 4);
         const int tr = 2 * uu + (kq >> 1), gy = oy0 - 1 + tr;
         f32x4 v = acc[u] + bias1;
@@ -946,7 +946,6 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_strip8x(const float* __r
 namespace stem8 {
 using namespace strip8;
 constexpr int NS = 2;                              // one BasicBlock behind the stem
-constexpr int XW = S + 2 * NS;                     // 68 columns of x (ring 0)
 constexpr int IROWS = 16, IP = 160;                // image ring: 16 rows of 160 bf16 pixels; row pitch = 80 dwords == 16 (mod 32)
 constexpr int IDW = 37;                            // aligned dwords fetched per image row: tile pixels -1 .. 146
 constexpr int NLOAD = 4 * IDW;                     // loader threads (4 image rows per step)
@@ -1177,7 +1176,6 @@ constexpr int WSFRAG = 2 * 64 * 8;                 // shortcut: [hi | lo][lane][
 struct DownW {
   const uint16_t *w1, *wsc, *w2;
   const float *b1, *bsc, *b2;
-  int dbg;   // 1 / 2: the kernel outputs t / sc instead of u (debugging aid, MSF_DBG_DOWN)
 };
 
 __global__ __launch_bounds__(64 * down16::WAVES) void k_down16x(const float* __restrict__ in, DownW dw, float* __restrict__ out,
@@ -1302,14 +1300,6 @@ __global__ __launch_bounds__(64 * down16::WAVES) void k_down16x(const float* __r
     }
   };
   // ---- stage 2: out row Y = 2p + jr, pixels 16 q + i (q = 0, 1): tap 2g + (kq >> 1) (the tenth has zero weights), block kq & 1
-  int toff[5];
-#pragma unroll
-  for (int g = 0; g < 5; g++) {
-    int t = 2 * g + (kq >> 1);
-    t = t < 9 ? t : 8;
-    const int ky = t / 3, kx = t - 3 * ky;
-    toff[g] = (kq & 1) * TCB + kx + ky * TPX;      // + ((Y - 1) mod 8) * TPX, row wrap handled below
-  }
   auto stage2 = [&](int p) {
     if (p >= npairs) return;
     const int Y = 2 * p + jr;
@@ -1339,11 +1329,6 @@ __global__ __launch_bounds__(64 * down16::WAVES) void k_down16x(const float* __r
       v.x += (float)a[0] + (float)b[0]; v.y += (float)a[1] + (float)b[1];
       v.z += (float)a[2] + (float)b[2]; v.w += (float)a[3] + (float)b[3];
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-      if (dw.dbg) {
-        const bf16x4* dh4 = reinterpret_cast<const bf16x4*>(dw.dbg == 1 ? tr : sr);
-        const bf16x4 da = dh4[rs], db = dh4[rs + 4 * TCB];
-        v = f32x4{(float)da[0] + (float)db[0], (float)da[1] + (float)db[1], (float)da[2] + (float)db[2], (float)da[3] + (float)db[3]};
-      }
       const uint32_t oo = 4u * (uint32_t)((4 * kq * H + Y) * W + X0 + j);
       char* ob = reinterpret_cast<char*>(outf);
       *reinterpret_cast<float*>(ob + oo) = v.x;
@@ -1352,7 +1337,6 @@ __global__ __launch_bounds__(64 * down16::WAVES) void k_down16x(const float* __r
       *reinterpret_cast<float*>(ob + (oo + 12u * (uint32_t)HW)) = v.w;
     }
   };
-  (void)toff;
 #define MSF_DN_STEP(q_, n_)                                                                       \
   {                                                                                               \
     __syncthreads();                                                                              \
@@ -2831,9 +2815,7 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
         for (int l = 0; l < 64; l++)
           for (int j = 0; j < 8; j++) {
             const int co = l & 15, kx = l >> 4;
-            float v = kx < 3 ? (*w)[(((size_t)co * 8 + j) * 3 + g) * 3 + kx] : 0.f;
-            if (const char* only = getenv("MSF_DBG_W1"))   // debugging aid: keep one tap "ky,kx"
-              if (only[0] - '0' != g || only[2] - '0' != kx) v = 0.f;
+            const float v = kx < 3 ? (*w)[(((size_t)co * 8 + j) * 3 + g) * 3 + kx] : 0.f;
             const uint16_t hi = to_bf16(v), lo = to_bf16(v - from_bf16(hi));
             wx[((size_t)(0 * 3 + g) * 64 + l) * 8 + j] = hi;
             wx[((size_t)(1 * 3 + g) * 64 + l) * 8 + j] = lo;
@@ -3107,7 +3089,7 @@ void launch_down16x(const ConvDesc& cs2, const ConvDesc& csc, const ConvDesc& c2
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_down16x), hipFuncAttributeMaxDynamicSharedMemorySize, down16::LDS_BYTES);
     attr_set = true;
   }
-  DownW dw{cs2.d_wx, csc.d_wx, c2.d_wx, cs2.d_b, csc.d_b, c2.d_b, getenv("MSF_DBG_DOWN") ? atoi(getenv("MSF_DBG_DOWN")) : 0};
+  DownW dw{cs2.d_wx, csc.d_wx, c2.d_wx, cs2.d_b, csc.d_b, c2.d_b};
   const int n_strips = c2.wout / down16::S;
   hipLaunchKernelGGL(k_down16x, dim3(n_strips * n_img), dim3(64 * down16::WAVES), down16::LDS_BYTES, st, in, dw, out, c2.hout,
                      c2.wout, n_strips);
@@ -3285,7 +3267,6 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
     launch_conv<8, 16, 3, 2, 32, true, false, false, 1, true>(c[5], a, s8, 0, nullptr, b, ni, st, &c[7], d);   // + shortcut -> d
     launch_conv<16, 16, 3, 1, 32, true, true, false>(c[6], b, s16, 0, d, cc, ni, st);              // cc = 205
   }
-  if (getenv("MSF_DBG_ACT1_CC")) keep(1, cc, 16u * 120 * 160);   // debugging aid: stage 1 = the down block's output
   if (P.fuse_blocks) {
     if (P.split_bf16) launch_block16x(c[8], c[9], cc, a, ni, st);                                  // a = 212
     else launch_block16(c[8], c[9], cc, a, ni, st);
@@ -3293,7 +3274,7 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
     launch_conv<16, 16, 3, 1, 32, true, false, false>(c[8], cc, s16, 0, nullptr, b, ni, st);
     launch_conv<16, 16, 3, 1, 32, true, true, false>(c[9], b, s16, 0, cc, a, ni, st);              // a = 212
   }
-  if (!getenv("MSF_DBG_ACT1_CC")) keep(1, a, 16u * 120 * 160);
+  keep(1, a, 16u * 120 * 160);
   // layer3 @60x80, 32 ch
   const long long s32 = 32LL * 60 * 80;
   if (P.split_bf16) launch_convx2<16>(c[10], c[12], a, b, d, ni, st);
