@@ -1377,6 +1377,212 @@ __global__ __launch_bounds__(64 * down16::WAVES) void k_down16x(const float* __r
 #undef MSF_DN_STEP
 }
 
+// ------------------------------------------------------------------ streaming 16-channel BasicBlock (layer2, block 2)
+// k_down16x's layout with a stride-1 first stage: a workgroup owns 32 output columns of one image and walks down two rows
+// per step; ring X holds 12 rows of the block input (16 channels = 2 channel-block planes, hi | lo), stage A (waves 0-5,
+// one (row, M tile) job each) makes t = relu(conv3x3(x)), stage B (waves 6-7, two jobs each) y = relu(conv3x3(t) + x)
+// with the residual read from ring X (hi + lo) -- no halo rows, no separately fetched residual (1.95 -> 1.3 GB per step
+// against the banded k_block16x).  K = 32 of an MFMA = two taps x two channel blocks (five groups, k_block16x's packing).
+// Pipeline: rows 2n, 2n+1 of x arrive at step n, stage A makes pair n - 2, stage B pair n - 4; one barrier per step.
+namespace strip16 {
+constexpr int S = 32;
+constexpr int XROWS = 12, XPX = 40;                // x ring: columns X0-2 .. X0+33 in slots 0 .. 35
+constexpr int XW = S + 4;
+constexpr int XCB = XROWS * XPX;                   // 480 = 30 x 16
+constexpr int XRING = 4 * XCB;                     // [hi | lo][channel block]
+constexpr int TROWS = 8, TPX = 36, TW = S + 2;     // t ring: four row pairs, columns X0-1 .. X0+32
+constexpr int TCB = TROWS * TPX;
+constexpr int TRING = 4 * TCB;
+static_assert(XCB % 16 == 0 && TCB % 16 == 0, "channel-block planes must be multiples of 16 pixel slots");
+constexpr int WAVES = 8;
+constexpr int NLOAD = 2 * 2 * XW;                  // loader threads: (channel block, row of the pair, column)
+constexpr int LDS_BYTES = 16 * (XRING + TRING + 16);
+}  // namespace strip16
+
+__global__ __launch_bounds__(64 * strip16::WAVES) void k_strip16x(const float* __restrict__ in, const uint16_t* __restrict__ wx1,
+                                                                  const float* __restrict__ b1, const uint16_t* __restrict__ wx2,
+                                                                  const float* __restrict__ b2, float* __restrict__ out, int H,
+                                                                  int W, int n_strips) {
+  using namespace strip16;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  bf16x8* xr = reinterpret_cast<bf16x8*>(lds);     // x ring: [hi cb0][hi cb1][lo cb0][lo cb1]
+  bf16x8* tr = xr + XRING;                         // t ring, same order
+  const int nwg = gridDim.x, per = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7;
+  const int unit = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+  const int img = __builtin_amdgcn_readfirstlane(unit / n_strips);
+  const int X0 = __builtin_amdgcn_readfirstlane((unit - img * n_strips) * S);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int HW = H * W;
+  const float* inf = in + (long long)img * 16 * HW;
+  float* outf = out + (long long)img * 16 * HW;
+  const int npairs = H / 2;
+  const bool stA = wave < 6;
+  const int jr = stA ? wave / 3 : wave - 6;        // row of the pair this wave works on
+  const int jq = stA ? wave - 3 * jr : 0;          // stage A: M tile
+
+  bf16x8 wa[5], wb[5];                             // this wave's stage: fragments hi (wa) and lo (wb) of its convolution
+  {
+    const bf16x8* pw = reinterpret_cast<const bf16x8*>(stA ? wx1 : wx2);
+#pragma unroll
+    for (int g = 0; g < 5; g++) { wa[g] = pw[g * 64 + lane]; wb[g] = pw[(5 + g) * 64 + lane]; }
+  }
+  const f32x4 bias = *reinterpret_cast<const f32x4*>((stA ? b1 : b2) + 4 * kq);   // lane = channels 4 kq .. +3 of one pixel
+  {
+    uint32_t* z = reinterpret_cast<uint32_t*>(lds);
+    for (int idx = tid; idx < LDS_BYTES / 4; idx += 64 * WAVES) z[idx] = 0u;
+  }
+  // loader (threads 0 .. NLOAD-1): thread (channel block lcb, row lr of the pair, ring column lc) fetches 8 channel dwords
+  const bool ld = tid < NLOAD;
+  const int lcb = ld ? tid / (2 * XW) : 0, lrm = ld ? tid - lcb * 2 * XW : 0;
+  const int lr = lrm / XW, lc = lrm - lr * XW;
+  const int lgx = X0 - 2 + lc;
+  const bool colok = ld && lgx >= 0 && lgx < W;
+  const uint32_t lofs = colok ? (uint32_t)(8 * lcb * HW + lgx) : 0u;
+  const bool ldwave = wave <= (NLOAD - 1) / 64;
+#define MSF_S16_ISSUE(q_, n_)                                                                     \
+  {                                                                                               \
+    const int gy = 2 * (n_) + lr;                                                                 \
+    const uint32_t so = (colok && gy < H) ? 4u * (lofs + (uint32_t)(gy * W)) : 0u;                \
+    _Pragma("unroll") for (int c = 0; c < 8; c++)                                                 \
+      q_[c] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(inf) + (so + 4u * (uint32_t)(c * HW))); \
+  }
+#define MSF_S16_COMMIT(q_, n_)                                                                    \
+  if (ld) {                                                                                       \
+    const bool ok = colok && 2 * (n_) + lr < H;                                                   \
+    bf16x4 h0, l0, h1, l1;                                                                        \
+    split4(ok ? f32x4{q_[0], q_[1], q_[2], q_[3]} : f32x4{0.f, 0.f, 0.f, 0.f}, h0, l0);           \
+    split4(ok ? f32x4{q_[4], q_[5], q_[6], q_[7]} : f32x4{0.f, 0.f, 0.f, 0.f}, h1, l1);           \
+    bf16x4* dst = reinterpret_cast<bf16x4*>(xr + (lcb * XCB + crow + lr * XPX + lc));             \
+    dst[0] = h0; dst[1] = h1; dst[4 * XCB] = l0; dst[4 * XCB + 1] = l1;                           \
+  }
+  int crow = 0;                                    // loader cursor: (2n mod 12) * XPX
+  constexpr int XWRAP = XROWS * XPX;
+  const bool edge = X0 == 0 || X0 + S == W;
+  // this lane's K block of MFMA group g: tap 2g + (kq >> 1) (the tenth has zero weights), channel block kq & 1
+  int tky[5], tkx[5];
+#pragma unroll
+  for (int g = 0; g < 5; g++) {
+    int t = 2 * g + (kq >> 1);
+    t = t < 9 ? t : 8;
+    tky[g] = t / 3;
+    tkx[g] = t - 3 * tky[g];
+  }
+  // ---- stage A: t row Y = 2p + jr, t slots 16 jq + i (columns X0 - 1 + slot)
+  auto stageA = [&](int p) {
+    const int jt = 16 * jq + i;
+    const int Y = 2 * p + jr;
+    bf16x4* th4 = reinterpret_cast<bf16x4*>(tr);
+    const int os = 2 * ((kq >> 1) * TCB + (Y & (TROWS - 1)) * TPX + jt) + (kq & 1);
+    if (p >= npairs) {                             // the row pair below the image: zero padding for stage B
+      if (jt < TW) {
+        bf16x4 z;
+        z[0] = z[1] = z[2] = z[3] = (__bf16)0.f;
+        th4[os] = z; th4[os + 4 * TCB] = z;
+      }
+      return;
+    }
+    const int ja = jt < TW + 2 ? jt : TW + 1;      // lanes past the strip's columns: keep their reads inside the row
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 5; g++) {
+      int rr = Y - 1 + tky[g] + XROWS;             // x rows are ring rows modulo 12
+      rr = rr - XROWS * ((rr * 2731) >> 15);
+      const bf16x8* src = xr + ((kq & 1) * XCB + rr * XPX + ja + tkx[g]);
+      const bf16x8 ph = src[0], pl = src[2 * XCB];
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[g], ph, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], pl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], ph, acc, 0, 0, 0);
+    }
+    acc += bias;
+    acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+    if (edge) {
+      const int gx = X0 - 1 + jt;
+      if (gx < 0 || gx >= W) acc = f32x4{0.f, 0.f, 0.f, 0.f};   // stage B pads t with zeros
+    }
+    if (jt < TW) {
+      bf16x4 vh, vl;
+      split4(acc, vh, vl);
+      th4[os] = vh; th4[os + 4 * TCB] = vl;
+    }
+  };
+  // ---- stage B: out row Y = 2p + jr, pixels 16 q + i (q = 0, 1)
+  auto stageB = [&](int p) {
+    if (p >= npairs) return;
+    const int Y = 2 * p + jr;
+    f32x4 acc[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 5; g++) {
+        const bf16x8* src = tr + ((kq & 1) * TCB + ((Y - 1 + tky[g]) & (TROWS - 1)) * TPX + 16 * q + i + tkx[g]);
+        const bf16x8 ah = src[0], al = src[2 * TCB];
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[g], ah, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], al, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], ah, acc[q], 0, 0, 0);
+      }
+    }
+    int ry = Y + XROWS;                            // residual: x row Y, slot j + 2
+    ry = ry - XROWS * ((ry * 2731) >> 15);
+    const bf16x4* xh4 = reinterpret_cast<const bf16x4*>(xr);
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int j = 16 * q + i;
+      const int rs = 2 * ((kq >> 1) * XCB + ry * XPX + j + 2) + (kq & 1);
+      const bf16x4 a = xh4[rs], b = xh4[rs + 4 * XCB];
+      f32x4 v = acc[q] + bias;
+      v.x += (float)a[0] + (float)b[0]; v.y += (float)a[1] + (float)b[1];
+      v.z += (float)a[2] + (float)b[2]; v.w += (float)a[3] + (float)b[3];
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      const uint32_t oo = 4u * (uint32_t)((4 * kq * H + Y) * W + X0 + j);
+      char* ob = reinterpret_cast<char*>(outf);
+      *reinterpret_cast<float*>(ob + oo) = v.x;
+      *reinterpret_cast<float*>(ob + (oo + 4u * (uint32_t)HW)) = v.y;
+      *reinterpret_cast<float*>(ob + (oo + 8u * (uint32_t)HW)) = v.z;
+      *reinterpret_cast<float*>(ob + (oo + 12u * (uint32_t)HW)) = v.w;
+    }
+  };
+#define MSF_S16_STEP(q_, n_)                                                                      \
+  {                                                                                               \
+    __syncthreads();                                                                              \
+    if (kLd) {                                                                                    \
+      MSF_S16_COMMIT(q_, n_)                                                                      \
+      MSF_S16_ISSUE(q_, (n_) + 4)                                                                 \
+    }                                                                                             \
+    if (stA) {                                                                                    \
+      const int p_ = (n_) - 2;                                                                    \
+      if (p_ >= 0 && p_ <= npairs) stageA(p_);                                                    \
+    } else {                                                                                      \
+      const int p_ = (n_) - 4;                                                                    \
+      if (p_ >= 0) stageB(p_);                                                                    \
+    }                                                                                             \
+    crow += 2 * XPX; crow = crow >= XWRAP ? crow - XWRAP : crow;                                  \
+  }
+  const int nsteps = (npairs + 4 + 3) & ~3;
+  auto run = [&](auto is_loader) {
+    constexpr bool kLd = decltype(is_loader)::value;
+    float q0[8], q1[8], q2[8], q3[8];
+    if (kLd) {
+      MSF_S16_ISSUE(q0, 0)
+      MSF_S16_ISSUE(q1, 1)
+      MSF_S16_ISSUE(q2, 2)
+      MSF_S16_ISSUE(q3, 3)
+    }
+    for (int n = 0; n < nsteps; n += 4) {
+      MSF_S16_STEP(q0, n)
+      MSF_S16_STEP(q1, n + 1)
+      MSF_S16_STEP(q2, n + 2)
+      MSF_S16_STEP(q3, n + 3)
+    }
+  };
+  if (ldwave) run(std::true_type{});
+  else run(std::false_type{});
+#undef MSF_S16_ISSUE
+#undef MSF_S16_COMMIT
+#undef MSF_S16_STEP
+}
+
 // ------------------------------------------------------------------ fused BasicBlock, 16 channels, split-bf16 MFMA
 // k_block16's tiling (bands of 8 rows, x tiles of 32 columns, wave = (M tile, row half), conv2 one tile behind conv1)
 // with the arithmetic and LDS layout of k_block8x / k_convx: planes [hi | lo][channel block of 8][row][pixel] x 16 B.
@@ -3107,6 +3313,18 @@ void launch_block16x(const ConvDesc& ca, const ConvDesc& cb, const float* in, fl
                      out, ca.hout, ca.wout, n_bands);
 }
 
+// the 16-channel BasicBlock as one streaming pass (k_strip16x)
+void launch_strip16x(const ConvDesc& ca, const ConvDesc& cb, const float* in, float* out, int n_img, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_strip16x), hipFuncAttributeMaxDynamicSharedMemorySize, strip16::LDS_BYTES);
+    attr_set = true;
+  }
+  const int n_strips = ca.wout / strip16::S;
+  hipLaunchKernelGGL(k_strip16x, dim3(n_strips * n_img), dim3(64 * strip16::WAVES), strip16::LDS_BYTES, st, in, ca.d_wx, ca.d_b,
+                     cb.d_wx, cb.d_b, out, ca.hout, ca.wout, n_strips);
+}
+
 // 3x3 stride-1 C -> C convolution (+ residual) + ReLU on split-bf16 MFMAs (k_convx)
 template <int C, bool RES>
 void launch_convx(const ConvDesc& c, const float* in, const float* res, float* out, int n_img, hipStream_t st) {
@@ -3268,7 +3486,8 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
     launch_conv<16, 16, 3, 1, 32, true, true, false>(c[6], b, s16, 0, d, cc, ni, st);              // cc = 205
   }
   if (P.fuse_blocks) {
-    if (P.split_bf16) launch_block16x(c[8], c[9], cc, a, ni, st);                                  // a = 212
+    if (P.split_bf16 && strip_mode != 0 && P.down_stream) launch_strip16x(c[8], c[9], cc, a, ni, st);   // a = 212
+    else if (P.split_bf16) launch_block16x(c[8], c[9], cc, a, ni, st);
     else launch_block16(c[8], c[9], cc, a, ni, st);
   } else {
     launch_conv<16, 16, 3, 1, 32, true, false, false>(c[8], cc, s16, 0, nullptr, b, ni, st);
