@@ -1583,6 +1583,212 @@ __global__ __launch_bounds__(64 * strip16::WAVES) void k_strip16x(const float* _
 #undef MSF_S16_STEP
 }
 
+// ------------------------------------------------------------------ streaming 32-channel BasicBlock (layer3 / layer4, block 2)
+// k_strip16x for 32 channels: a workgroup owns 16 output columns of one image and walks down two rows per step; ring X
+// holds 12 rows of the block input (4 channel-block planes, hi | lo), ring T 8 rows of t.  K = 32 of an MFMA = the 4
+// channel blocks of one tap (9 groups, k_convx's packing); the 32 output channels are two MFMA tiles, and a wave holds
+// the fragments of ONE (convolution, output tile): 72 VGPRs.  Stage A (waves 0-3: (tile, row), two M-tile jobs each)
+// makes t = relu(conv3x3(x)), stage B (waves 4-7: (tile, row), one job each) y = relu(conv3x3(t) + x), residual from
+// ring X.  The image loader lives in the stage-B waves.  Replaces two k_convx passes (x, t and the residual through
+// HBM with 1.4 x halos) by one read and one write.
+namespace strip32 {
+constexpr int S = 16;
+constexpr int XROWS = 12, XPX = 24, XW = S + 4;    // x ring: columns X0-2 .. X0+17 in slots 0 .. 19
+constexpr int XCB = XROWS * XPX;                   // 288 = 18 x 16
+constexpr int XRING = 8 * XCB;                     // [hi | lo][4 channel blocks]
+constexpr int TROWS = 8, TPX = 20, TW = S + 2;     // t ring: columns X0-1 .. X0+16
+constexpr int TCB = TROWS * TPX;                   // 160 = 10 x 16
+constexpr int TRING = 8 * TCB;
+static_assert(XCB % 16 == 0 && TCB % 16 == 0, "channel-block planes must be multiples of 16 pixel slots");
+constexpr int WAVES = 8;
+constexpr int NLOAD = 4 * 2 * XW;                  // loader threads: (channel block, row of the pair, column)
+constexpr int LDS_BYTES = 16 * (XRING + TRING + 16);
+}  // namespace strip32
+
+__global__ __launch_bounds__(64 * strip32::WAVES) void k_strip32x(const float* __restrict__ in, const uint16_t* __restrict__ wx1,
+                                                                  const float* __restrict__ b1, const uint16_t* __restrict__ wx2,
+                                                                  const float* __restrict__ b2, float* __restrict__ out, int H,
+                                                                  int W, int n_strips) {
+  using namespace strip32;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  bf16x8* xr = reinterpret_cast<bf16x8*>(lds);     // x ring: [hi cb0..3][lo cb0..3]
+  bf16x8* tr = xr + XRING;
+  const int nwg = gridDim.x, per = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7;
+  const int unit = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+  const int img = __builtin_amdgcn_readfirstlane(unit / n_strips);
+  const int X0 = __builtin_amdgcn_readfirstlane((unit - img * n_strips) * S);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int HW = H * W;
+  const float* inf = in + (long long)img * 32 * HW;
+  float* outf = out + (long long)img * 32 * HW;
+  const int npairs = H / 2;
+  const bool stA = wave < 4;
+  const int nt = wave & 1, jr = (wave >> 1) & 1;   // output-channel tile, row of the pair
+
+  bf16x8 wa[9], wb[9];                             // fragments hi / lo of (this wave's convolution, tile nt): k_convx's [g][nt][hl][lane]
+  {
+    const bf16x8* pw = reinterpret_cast<const bf16x8*>(stA ? wx1 : wx2);
+#pragma unroll
+    for (int g = 0; g < 9; g++) { wa[g] = pw[((g * 2 + nt) * 2 + 0) * 64 + lane]; wb[g] = pw[((g * 2 + nt) * 2 + 1) * 64 + lane]; }
+  }
+  const f32x4 bias = *reinterpret_cast<const f32x4*>((stA ? b1 : b2) + 16 * nt + 4 * kq);   // lane = channels 16 nt + 4 kq .. +3
+  const int cbp = 2 * nt + (kq >> 1);              // channel-block plane of those four channels (half kq & 1)
+  {
+    uint32_t* z = reinterpret_cast<uint32_t*>(lds);
+    for (int idx = tid; idx < LDS_BYTES / 4; idx += 64 * WAVES) z[idx] = 0u;
+  }
+  // loader (the last NLOAD threads): thread (channel block lcb, row lr of the pair, ring column lc) fetches 8 channel dwords
+  const int ltid = tid - (64 * WAVES - NLOAD);
+  const bool ld = ltid >= 0;
+  const int lcb = ld ? ltid / (2 * XW) : 0, lrm = ld ? ltid - lcb * 2 * XW : 0;
+  const int lr = lrm / XW, lc = lrm - lr * XW;
+  const int lgx = X0 - 2 + lc;
+  const bool colok = ld && lgx >= 0 && lgx < W;
+  const uint32_t lofs = colok ? (uint32_t)(8 * lcb * HW + lgx) : 0u;
+  const bool ldwave = wave >= (64 * WAVES - NLOAD) / 64;
+#define MSF_S32_ISSUE(q_, n_)                                                                     \
+  {                                                                                               \
+    const int gy = 2 * (n_) + lr;                                                                 \
+    const uint32_t so = (colok && gy < H) ? 4u * (lofs + (uint32_t)(gy * W)) : 0u;                \
+    _Pragma("unroll") for (int c = 0; c < 8; c++)                                                 \
+      q_[c] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(inf) + (so + 4u * (uint32_t)(c * HW))); \
+  }
+#define MSF_S32_COMMIT(q_, n_)                                                                    \
+  if (ld) {                                                                                       \
+    const bool ok = colok && 2 * (n_) + lr < H;                                                   \
+    bf16x4 h0, l0, h1, l1;                                                                        \
+    split4(ok ? f32x4{q_[0], q_[1], q_[2], q_[3]} : f32x4{0.f, 0.f, 0.f, 0.f}, h0, l0);           \
+    split4(ok ? f32x4{q_[4], q_[5], q_[6], q_[7]} : f32x4{0.f, 0.f, 0.f, 0.f}, h1, l1);           \
+    bf16x4* dst = reinterpret_cast<bf16x4*>(xr + (lcb * XCB + crow + lr * XPX + lc));             \
+    dst[0] = h0; dst[1] = h1; dst[8 * XCB] = l0; dst[8 * XCB + 1] = l1;                           \
+  }
+  int crow = 0;                                    // loader cursor: (2n mod 12) * XPX
+  constexpr int XWRAP = XROWS * XPX;
+  const bool edge = X0 == 0 || X0 + S >= W;        // the last strip may be partial (W = 40: columns 32 .. 39)
+  // ---- stage A: t row Y = 2p + jr, channels of tile nt, t slots 16 q + i (q = 0, 1; columns X0 - 1 + slot, 18 valid)
+  auto stageA = [&](int p) {
+    const int Y = 2 * p + jr;
+    bf16x4* th4 = reinterpret_cast<bf16x4*>(tr);
+    if (p >= npairs) {                             // the row pair below the image: zero padding for stage B
+      bf16x4 z;
+      z[0] = z[1] = z[2] = z[3] = (__bf16)0.f;
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int jt = 16 * q + i;
+        if (jt < TW) {
+          const int os = 2 * (cbp * TCB + (Y & (TROWS - 1)) * TPX + jt) + (kq & 1);
+          th4[os] = z; th4[os + 8 * TCB] = z;
+        }
+      }
+      return;
+    }
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int g = 0; g < 9; g++) {
+      const int ky = g / 3, kx = g - 3 * ky;
+      int rr = Y - 1 + ky + XROWS;                 // x rows are ring rows modulo 12
+      rr = rr - XROWS * ((rr * 2731) >> 15);
+      const bf16x8* row = xr + (kq * XCB + rr * XPX + kx);
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int jt = 16 * q + i;
+        const bf16x8* src = row + (jt < TW + 2 ? jt : TW + 1);   // lanes past the strip's columns stay inside the row
+        const bf16x8 ph = src[0], pl = src[4 * XCB];
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[g], ph, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], pl, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], ph, acc[q], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int jt = 16 * q + i;
+      f32x4 v = acc[q] + bias;
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      if (edge) {
+        const int gx = X0 - 1 + jt;
+        if (gx < 0 || gx >= W) v = f32x4{0.f, 0.f, 0.f, 0.f};    // stage B pads t with zeros
+      }
+      if (jt < TW) {
+        bf16x4 vh, vl;
+        split4(v, vh, vl);
+        const int os = 2 * (cbp * TCB + (Y & (TROWS - 1)) * TPX + jt) + (kq & 1);
+        th4[os] = vh; th4[os + 8 * TCB] = vl;
+      }
+    }
+  };
+  // ---- stage B: out row Y = 2p + jr, channels of tile nt, pixels X0 + i
+  auto stageB = [&](int p) {
+    if (p >= npairs) return;
+    const int Y = 2 * p + jr;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 9; g++) {
+      const int ky = g / 3, kx = g - 3 * ky;
+      const bf16x8* src = tr + (kq * TCB + ((Y - 1 + ky) & (TROWS - 1)) * TPX + i + kx);
+      const bf16x8 ah = src[0], al = src[4 * TCB];
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[g], ah, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], al, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], ah, acc, 0, 0, 0);
+    }
+    int ry = Y + XROWS;                            // residual: x row Y, slot i + 2
+    ry = ry - XROWS * ((ry * 2731) >> 15);
+    const bf16x4* xh4 = reinterpret_cast<const bf16x4*>(xr);
+    const int rs = 2 * (cbp * XCB + ry * XPX + i + 2) + (kq & 1);
+    const bf16x4 a = xh4[rs], b = xh4[rs + 8 * XCB];
+    f32x4 v = acc + bias;
+    v.x += (float)a[0] + (float)b[0]; v.y += (float)a[1] + (float)b[1];
+    v.z += (float)a[2] + (float)b[2]; v.w += (float)a[3] + (float)b[3];
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    if (X0 + i < W) {
+      const uint32_t oo = 4u * (uint32_t)(((16 * nt + 4 * kq) * H + Y) * W + X0 + i);
+      char* ob = reinterpret_cast<char*>(outf);
+      *reinterpret_cast<float*>(ob + oo) = v.x;
+      *reinterpret_cast<float*>(ob + (oo + 4u * (uint32_t)HW)) = v.y;
+      *reinterpret_cast<float*>(ob + (oo + 8u * (uint32_t)HW)) = v.z;
+      *reinterpret_cast<float*>(ob + (oo + 12u * (uint32_t)HW)) = v.w;
+    }
+  };
+#define MSF_S32_STEP(q_, n_)                                                                      \
+  {                                                                                               \
+    __syncthreads();                                                                              \
+    if (kLd) {                                                                                    \
+      MSF_S32_COMMIT(q_, n_)                                                                      \
+      MSF_S32_ISSUE(q_, (n_) + 4)                                                                 \
+    }                                                                                             \
+    if (stA) {                                                                                    \
+      const int p_ = (n_) - 2;                                                                    \
+      if (p_ >= 0 && p_ <= npairs) stageA(p_);                                                    \
+    } else {                                                                                      \
+      const int p_ = (n_) - 4;                                                                    \
+      if (p_ >= 0) stageB(p_);                                                                    \
+    }                                                                                             \
+    crow += 2 * XPX; crow = crow >= XWRAP ? crow - XWRAP : crow;                                  \
+  }
+  const int nsteps = (npairs + 4 + 3) & ~3;
+  auto run = [&](auto is_loader) {
+    constexpr bool kLd = decltype(is_loader)::value;
+    float q0[8], q1[8], q2[8], q3[8];
+    if (kLd) {
+      MSF_S32_ISSUE(q0, 0)
+      MSF_S32_ISSUE(q1, 1)
+      MSF_S32_ISSUE(q2, 2)
+      MSF_S32_ISSUE(q3, 3)
+    }
+    for (int n = 0; n < nsteps; n += 4) {
+      MSF_S32_STEP(q0, n)
+      MSF_S32_STEP(q1, n + 1)
+      MSF_S32_STEP(q2, n + 2)
+      MSF_S32_STEP(q3, n + 3)
+    }
+  };
+  if (ldwave) run(std::true_type{});
+  else run(std::false_type{});
+#undef MSF_S32_ISSUE
+#undef MSF_S32_COMMIT
+#undef MSF_S32_STEP
+}
+
 // ------------------------------------------------------------------ fused BasicBlock, 16 channels, split-bf16 MFMA
 // k_block16's tiling (bands of 8 rows, x tiles of 32 columns, wave = (M tile, row half), conv2 one tile behind conv1)
 // with the arithmetic and LDS layout of k_block8x / k_convx: planes [hi | lo][channel block of 8][row][pixel] x 16 B.
@@ -3325,6 +3531,18 @@ void launch_strip16x(const ConvDesc& ca, const ConvDesc& cb, const float* in, fl
                      cb.d_wx, cb.d_b, out, ca.hout, ca.wout, n_strips);
 }
 
+// a 32-channel BasicBlock as one streaming pass (k_strip32x)
+void launch_strip32x(const ConvDesc& ca, const ConvDesc& cb, const float* in, float* out, int n_img, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_strip32x), hipFuncAttributeMaxDynamicSharedMemorySize, strip32::LDS_BYTES);
+    attr_set = true;
+  }
+  const int n_strips = (ca.wout + strip32::S - 1) / strip32::S;
+  hipLaunchKernelGGL(k_strip32x, dim3(n_strips * n_img), dim3(64 * strip32::WAVES), strip32::LDS_BYTES, st, in, ca.d_wx, ca.d_b,
+                     cb.d_wx, cb.d_b, out, ca.hout, ca.wout, n_strips);
+}
+
 // 3x3 stride-1 C -> C convolution (+ residual) + ReLU on split-bf16 MFMAs (k_convx)
 template <int C, bool RES>
 void launch_convx(const ConvDesc& c, const float* in, const float* res, float* out, int n_img, hipStream_t st) {
@@ -3500,8 +3718,12 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
   else launch_conv<16, 32, 3, 2, 16, true, false, false, 1, true>(c[10], a, s16, 0, nullptr, b, ni, st, &c[12], d);
   if (P.split_bf16) {
     launch_convx<32, true>(c[11], b, d, cc, ni, st);                                               // cc = 221
-    launch_convx<32, false>(c[13], cc, nullptr, b, ni, st);
-    launch_convx<32, true>(c[14], b, cc, a, ni, st);                                               // a = 228
+    if (strip_mode != 0 && P.down_stream) {
+      launch_strip32x(c[13], c[14], cc, a, ni, st);                                                // a = 228
+    } else {
+      launch_convx<32, false>(c[13], cc, nullptr, b, ni, st);
+      launch_convx<32, true>(c[14], b, cc, a, ni, st);                                             // a = 228
+    }
   } else {
     launch_conv<32, 32, 3, 1, 16, true, true, false>(c[11], b, s32, 0, d, cc, ni, st);             // cc = 221
     launch_conv<32, 32, 3, 1, 16, true, false, false>(c[13], cc, s32, 0, nullptr, b, ni, st);
@@ -3514,6 +3736,7 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
   else launch_conv<32, 32, 3, 2, 16, true, false, false, 1, true>(c[15], a, s32, 0, nullptr, b, ni, st, &c[17], d);
   if (P.split_bf16) {
     launch_convx<32, true>(c[16], b, d, cc, ni, st);                                               // cc = 237
+    // (k_strip32x at 30 x 40: 167 us against 165 for these two -- 2.5 strips of 16 columns, a third of the workgroups half empty)
     launch_convx<32, false>(c[18], cc, nullptr, b, ni, st);
     launch_convx<32, true>(c[19], b, cc, a, ni, st);                                               // a = 244
   } else {
