@@ -1789,6 +1789,234 @@ __global__ __launch_bounds__(64 * strip32::WAVES) void k_strip32x(const float* _
 #undef MSF_S32_STEP
 }
 
+// ------------------------------------------------------------------ streaming down-sampling BasicBlock 16 -> 32 (layer3, block 1)
+// k_down16x for 16 input / 32 output channels with k_strip32x's wave layout: a workgroup owns 16 output columns (37 input
+// columns, de-interleaved even | odd, 2 channel-block planes) and walks down two output rows (four input rows) per
+// step.  Stage 1 (waves 0-3: (output tile, row), two M-tile jobs each): t = relu(conv3x3 stride 2) with K = 32 = two
+// taps x two channel blocks (5 groups, k_convx2<16>'s packing), and the shortcut sc = conv1x1 stride 2 on the centre
+// tap's fragment (group 2, K blocks 0 and 1); stage 2 (waves 4-7): u = relu(conv3x3(t) + sc) with K = 32 = 4 channel
+// blocks of one tap (9 groups, k_convx's packing).  Replaces k_convx2<16> + k_convx<32, true>.
+namespace down32 {
+constexpr int S = 16, TW = S + 2;
+constexpr int IROWS = 12, IPX = 40, IODD = 20;     // input ring: even columns in slots 0 .. 18, odd columns in 20 .. 37
+constexpr int INW = 2 * TW + 1;                    // 37 input columns: 2 X0 - 3 .. 2 X0 + 33
+constexpr int ICB = IROWS * IPX;                   // 480 = 30 x 16
+constexpr int IRING = 4 * ICB;                     // [hi | lo][2 channel blocks]
+constexpr int TROWS = 8, TPX = 20;
+constexpr int TCB = TROWS * TPX;                   // 160
+constexpr int TRING = 8 * TCB;                     // [hi | lo][4 channel blocks]
+static_assert(ICB % 16 == 0 && TCB % 16 == 0, "channel-block planes must be multiples of 16 pixel slots");
+constexpr int WAVES = 8;
+constexpr int NLOAD = 2 * 4 * INW;                 // loader threads: (channel block, row of the step's four, column)
+constexpr int LDS_BYTES = 16 * (IRING + 2 * TRING + 16);
+}  // namespace down32
+
+__global__ __launch_bounds__(64 * down32::WAVES) void k_down32x(const float* __restrict__ in, DownW dw, float* __restrict__ out,
+                                                                int H, int W, int n_strips) {
+  using namespace down32;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  bf16x8* xr = reinterpret_cast<bf16x8*>(lds);     // input ring: [hi cb0][hi cb1][lo cb0][lo cb1]
+  bf16x8* tr = xr + IRING;                         // t ring: [hi cb0..3][lo cb0..3]
+  bf16x8* sr = tr + TRING;                         // sc ring
+  const int nwg = gridDim.x, per = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7;
+  const int unit = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+  const int img = __builtin_amdgcn_readfirstlane(unit / n_strips);
+  const int X0 = __builtin_amdgcn_readfirstlane((unit - img * n_strips) * S);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int Hin = 2 * H, Win = 2 * W, HWin = Hin * Win, HW = H * W;
+  const float* inf = in + (long long)img * 16 * HWin;
+  float* outf = out + (long long)img * 32 * HW;
+  const int npairs = H / 2;
+  const bool st1 = wave < 4;
+  const int nt = wave & 1, jr = (wave >> 1) & 1;   // output-channel tile, row of the pair
+  const int cbp = 2 * nt + (kq >> 1);              // channel-block plane of this lane's channels 16 nt + 4 kq .. +3 (half kq & 1)
+
+  bf16x8 wa[9], wb[9], wsh, wsl;                   // stage 1 uses 5 groups (+ the shortcut), stage 2 all 9
+  {
+    const bf16x8* pw = reinterpret_cast<const bf16x8*>(st1 ? dw.w1 : dw.w2);
+    const int ng = st1 ? 5 : 9;
+#pragma unroll
+    for (int g = 0; g < 9; g++) {
+      const int gg = g < ng ? g : ng - 1;
+      wa[g] = pw[((gg * 2 + nt) * 2 + 0) * 64 + lane];
+      wb[g] = pw[((gg * 2 + nt) * 2 + 1) * 64 + lane];
+    }
+    const bf16x8* ps = reinterpret_cast<const bf16x8*>(dw.wsc);
+    wsh = ps[(nt * 2 + 0) * 64 + lane];
+    wsl = ps[(nt * 2 + 1) * 64 + lane];
+  }
+  const f32x4 bias = *reinterpret_cast<const f32x4*>((st1 ? dw.b1 : dw.b2) + 16 * nt + 4 * kq);
+  const f32x4 bias_sc = *reinterpret_cast<const f32x4*>(dw.bsc + 16 * nt + 4 * kq);
+  {
+    uint32_t* z = reinterpret_cast<uint32_t*>(lds);
+    for (int idx = tid; idx < LDS_BYTES / 4; idx += 64 * WAVES) z[idx] = 0u;
+  }
+  // loader (threads 0 .. NLOAD-1): thread (channel block lcb, row r4 of the step's four, tile column lc) fetches 8 channel dwords
+  const bool ld = tid < NLOAD;
+  const int lcb = ld ? tid / (4 * INW) : 0, lrm = ld ? tid - lcb * 4 * INW : 0;
+  const int r4 = lrm / INW, lc = lrm - r4 * INW;
+  const int lgx = 2 * X0 - 3 + lc;
+  const bool colok = ld && lgx >= 0 && lgx < Win;
+  const uint32_t lofs = colok ? (uint32_t)(8 * lcb * HWin + lgx) : 0u;
+  const int lslot = (lc & 1) ? IODD + (lc >> 1) : (lc >> 1);
+  const bool ldwave = wave <= (NLOAD - 1) / 64;
+#define MSF_D32_ISSUE(q_, n_)                                                                     \
+  {                                                                                               \
+    const int gy = 4 * (n_) + r4;                                                                 \
+    const uint32_t so = (colok && gy < Hin) ? 4u * (lofs + (uint32_t)(gy * Win)) : 0u;            \
+    _Pragma("unroll") for (int c = 0; c < 8; c++)                                                 \
+      q_[c] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(inf) + (so + 4u * (uint32_t)(c * HWin))); \
+  }
+#define MSF_D32_COMMIT(q_, n_)                                                                    \
+  if (ld) {                                                                                       \
+    const bool ok = colok && 4 * (n_) + r4 < Hin;                                                 \
+    bf16x4 h0, l0, h1, l1;                                                                        \
+    split4(ok ? f32x4{q_[0], q_[1], q_[2], q_[3]} : f32x4{0.f, 0.f, 0.f, 0.f}, h0, l0);           \
+    split4(ok ? f32x4{q_[4], q_[5], q_[6], q_[7]} : f32x4{0.f, 0.f, 0.f, 0.f}, h1, l1);           \
+    bf16x4* dst = reinterpret_cast<bf16x4*>(xr + (lcb * ICB + irow + r4 * IPX + lslot));          \
+    dst[0] = h0; dst[1] = h1; dst[4 * ICB] = l0; dst[4 * ICB + 1] = l1;                           \
+  }
+  int irow = 0;                                    // loader cursor: (4n mod 12) * IPX
+  constexpr int IWRAP = IROWS * IPX;
+  const bool edge = X0 == 0 || X0 + S >= W;
+  // stage 1: this lane's K block of group g: tap 2g + (kq >> 1) (the tenth has zero weights), channel block kq & 1
+  int s1off[5];
+#pragma unroll
+  for (int g = 0; g < 5; g++) {
+    int t = 2 * g + (kq >> 1);
+    t = t < 9 ? t : 8;
+    const int ky = t / 3, kx = t - 3 * ky;
+    s1off[g] = ky * 256 + (kx == 1 ? IODD : kx == 0 ? 0 : 1);     // ky in bits 8.., column offset below
+  }
+  auto stage1 = [&](int p) {
+    const int Y = 2 * p + jr;
+    bf16x4* th4 = reinterpret_cast<bf16x4*>(tr);
+    bf16x4* sh4 = reinterpret_cast<bf16x4*>(sr);
+    if (p >= npairs) {
+      bf16x4 z;
+      z[0] = z[1] = z[2] = z[3] = (__bf16)0.f;
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int jt = 16 * q + i;
+        if (jt < TW) {
+          const int os = 2 * (cbp * TCB + (Y & (TROWS - 1)) * TPX + jt) + (kq & 1);
+          th4[os] = z; th4[os + 8 * TCB] = z;
+        }
+      }
+      return;
+    }
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 asc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int g = 0; g < 5; g++) {
+      const int ky = s1off[g] >> 8, co = s1off[g] & 255;
+      int rr = 4 * p + 2 * jr - 1 + ky + IROWS;    // input row 2Y - 1 + ky, ring rows modulo 12
+      rr = rr - IROWS * ((rr * 2731) >> 15);
+      const bf16x8* row = xr + ((kq & 1) * ICB + rr * IPX + co);
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int jt = 16 * q + i;
+        const bf16x8* src = row + (jt < TW ? jt : TW);           // lanes past the strip's columns stay inside the row
+        const bf16x8 ph = src[0], pl = src[2 * ICB];
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[g], ph, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], pl, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], ph, acc[q], 0, 0, 0);
+        if (g == 2) {                                             // the centre tap: K blocks 0, 1 of this group
+          asc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsl, ph, asc[q], 0, 0, 0);
+          asc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsh, pl, asc[q], 0, 0, 0);
+          asc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsh, ph, asc[q], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int jt = 16 * q + i;
+      f32x4 v = acc[q] + bias, vs = asc[q] + bias_sc;
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      if (edge) {
+        const int gx = X0 - 1 + jt;
+        if (gx < 0 || gx >= W) v = f32x4{0.f, 0.f, 0.f, 0.f};    // stage 2 pads t with zeros
+      }
+      if (jt < TW) {
+        bf16x4 vh, vl;
+        const int os = 2 * (cbp * TCB + (Y & (TROWS - 1)) * TPX + jt) + (kq & 1);
+        split4(v, vh, vl);
+        th4[os] = vh; th4[os + 8 * TCB] = vl;
+        split4(vs, vh, vl);
+        sh4[os] = vh; sh4[os + 8 * TCB] = vl;
+      }
+    }
+  };
+  auto stage2 = [&](int p) {
+    if (p >= npairs) return;
+    const int Y = 2 * p + jr;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 9; g++) {
+      const int ky = g / 3, kx = g - 3 * ky;
+      const bf16x8* src = tr + (kq * TCB + ((Y - 1 + ky) & (TROWS - 1)) * TPX + i + kx);
+      const bf16x8 ah = src[0], al = src[4 * TCB];
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[g], ah, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], al, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], ah, acc, 0, 0, 0);
+    }
+    const bf16x4* sh4 = reinterpret_cast<const bf16x4*>(sr);
+    const int rs = 2 * (cbp * TCB + (Y & (TROWS - 1)) * TPX + i + 1) + (kq & 1);
+    const bf16x4 a = sh4[rs], b = sh4[rs + 8 * TCB];
+    f32x4 v = acc + bias;
+    v.x += (float)a[0] + (float)b[0]; v.y += (float)a[1] + (float)b[1];
+    v.z += (float)a[2] + (float)b[2]; v.w += (float)a[3] + (float)b[3];
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    if (X0 + i < W) {
+      const uint32_t oo = 4u * (uint32_t)(((16 * nt + 4 * kq) * H + Y) * W + X0 + i);
+      char* ob = reinterpret_cast<char*>(outf);
+      *reinterpret_cast<float*>(ob + oo) = v.x;
+      *reinterpret_cast<float*>(ob + (oo + 4u * (uint32_t)HW)) = v.y;
+      *reinterpret_cast<float*>(ob + (oo + 8u * (uint32_t)HW)) = v.z;
+      *reinterpret_cast<float*>(ob + (oo + 12u * (uint32_t)HW)) = v.w;
+    }
+  };
+#define MSF_D32_STEP(q_, n_)                                                                      \
+  {                                                                                               \
+    __syncthreads();                                                                              \
+    if (kLd) {                                                                                    \
+      MSF_D32_COMMIT(q_, n_)                                                                      \
+      MSF_D32_ISSUE(q_, (n_) + 4)                                                                 \
+    }                                                                                             \
+    if (st1) {                                                                                    \
+      const int p_ = (n_) - 1;                                                                    \
+      if (p_ >= 0 && p_ <= npairs) stage1(p_);                                                    \
+    } else {                                                                                      \
+      const int p_ = (n_) - 3;                                                                    \
+      if (p_ >= 0) stage2(p_);                                                                    \
+    }                                                                                             \
+    irow += 4 * IPX; irow = irow >= IWRAP ? irow - IWRAP : irow;                                  \
+  }
+  const int nsteps = (npairs + 3 + 3) & ~3;
+  auto run = [&](auto is_loader) {
+    constexpr bool kLd = decltype(is_loader)::value;
+    float q0[8], q1[8], q2[8], q3[8];
+    if (kLd) {
+      MSF_D32_ISSUE(q0, 0)
+      MSF_D32_ISSUE(q1, 1)
+      MSF_D32_ISSUE(q2, 2)
+      MSF_D32_ISSUE(q3, 3)
+    }
+    for (int n = 0; n < nsteps; n += 4) {
+      MSF_D32_STEP(q0, n)
+      MSF_D32_STEP(q1, n + 1)
+      MSF_D32_STEP(q2, n + 2)
+      MSF_D32_STEP(q3, n + 3)
+    }
+  };
+  if (ldwave) run(std::true_type{});
+  else run(std::false_type{});
+#undef MSF_D32_ISSUE
+#undef MSF_D32_COMMIT
+#undef MSF_D32_STEP
+}
+
 // ------------------------------------------------------------------ fused BasicBlock, 16 channels, split-bf16 MFMA
 // k_block16's tiling (bands of 8 rows, x tiles of 32 columns, wave = (M tile, row half), conv2 one tile behind conv1)
 // with the arithmetic and LDS layout of k_block8x / k_convx: planes [hi | lo][channel block of 8][row][pixel] x 16 B.
@@ -3531,6 +3759,20 @@ void launch_strip16x(const ConvDesc& ca, const ConvDesc& cb, const float* in, fl
                      cb.d_wx, cb.d_b, out, ca.hout, ca.wout, n_strips);
 }
 
+// down-sampling block 16 -> 32 as one streaming pass (k_down32x): cs2 = 3x3 stride 2, csc = 1x1 stride 2, c2 = 3x3
+void launch_down32x(const ConvDesc& cs2, const ConvDesc& csc, const ConvDesc& c2, const float* in, float* out, int n_img,
+                    hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_down32x), hipFuncAttributeMaxDynamicSharedMemorySize, down32::LDS_BYTES);
+    attr_set = true;
+  }
+  DownW dw{cs2.d_wx, csc.d_wx, c2.d_wx, cs2.d_b, csc.d_b, c2.d_b};
+  const int n_strips = (c2.wout + down32::S - 1) / down32::S;
+  hipLaunchKernelGGL(k_down32x, dim3(n_strips * n_img), dim3(64 * down32::WAVES), down32::LDS_BYTES, st, in, dw, out, c2.hout,
+                     c2.wout, n_strips);
+}
+
 // a 32-channel BasicBlock as one streaming pass (k_strip32x)
 void launch_strip32x(const ConvDesc& ca, const ConvDesc& cb, const float* in, float* out, int n_img, hipStream_t st) {
   static bool attr_set = false;
@@ -3714,10 +3956,12 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
   keep(1, a, 16u * 120 * 160);
   // layer3 @60x80, 32 ch
   const long long s32 = 32LL * 60 * 80;
-  if (P.split_bf16) launch_convx2<16>(c[10], c[12], a, b, d, ni, st);
+  const bool down3 = P.split_bf16 && P.fuse_blocks && strip_mode != 0 && P.down_stream;
+  if (down3) launch_down32x(c[10], c[12], c[11], a, cc, ni, st);                                   // cc = 221
+  else if (P.split_bf16) launch_convx2<16>(c[10], c[12], a, b, d, ni, st);
   else launch_conv<16, 32, 3, 2, 16, true, false, false, 1, true>(c[10], a, s16, 0, nullptr, b, ni, st, &c[12], d);
   if (P.split_bf16) {
-    launch_convx<32, true>(c[11], b, d, cc, ni, st);                                               // cc = 221
+    if (!down3) launch_convx<32, true>(c[11], b, d, cc, ni, st);                                   // cc = 221
     if (strip_mode != 0 && P.down_stream) {
       launch_strip32x(c[13], c[14], cc, a, ni, st);                                                // a = 228
     } else {
