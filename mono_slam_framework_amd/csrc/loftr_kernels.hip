@@ -953,7 +953,8 @@ constexpr int LDS_BYTES = 16 * (NS * 2 * RING + TAIL) + 2 * IROWS * IP + 64;
 constexpr int WFRAG = 2 * 3 * 64 * 8;              // stem fragments [hi | lo][row group][lane][8]
 }  // namespace stem8
 
-__global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8_t* __restrict__ frames, long long frame_stride,
+__global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8_t* __restrict__ framesA, int nA,
+                                                                     const uint8_t* __restrict__ framesB, long long frame_stride,
                                                                      int row_stride, const uint16_t* __restrict__ wx0,
                                                                      const float* __restrict__ b0, StripW sw,
                                                                      float* __restrict__ out, int H, int W, int n_strips) {
@@ -968,7 +969,8 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int HW = H * W, Hin = 2 * H, Win = 2 * W;
-  const uint8_t* fr = frames + (long long)img * frame_stride;
+  // images 0 .. nA-1 come from the first frame array, the rest from the second (one launch: whole rounds of workgroups)
+  const uint8_t* fr = img < nA ? framesA + (long long)img * frame_stride : framesB + (long long)(img - nA) * frame_stride;
   float* outf = out + (long long)img * 8 * HW;
   const int npairs = H / 2;
   // this wave's stage: 0 = stem (waves 0-2), 1 / 2 = the block's convolutions (waves 3-5 / 6-7)
@@ -3707,8 +3709,8 @@ void launch_strip8x(const ConvDesc* cv, const float* in, float* out, int n_img, 
 }
 
 // stem + first 8-channel BasicBlock as one streaming pass over u8 frames (k_stem_strip8x): convolutions cv[0 .. 3)
-void launch_stem_strip8x(const ConvDesc* cv, const uint8_t* frames, long long frame_stride, int row_stride, float* out,
-                         int n_img, hipStream_t st) {
+void launch_stem_strip8x(const ConvDesc* cv, const uint8_t* framesA, int nA, const uint8_t* framesB, int nB,
+                         long long frame_stride, int row_stride, float* out, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_stem_strip8x), hipFuncAttributeMaxDynamicSharedMemorySize, stem8::LDS_BYTES);
@@ -3717,8 +3719,8 @@ void launch_stem_strip8x(const ConvDesc* cv, const uint8_t* frames, long long fr
   StripW sw{};
   for (int c = 0; c < 2; c++) { sw.wx[c] = cv[1 + c].d_wx; sw.b[c] = cv[1 + c].d_b; }
   const int n_strips = cv[1].wout / strip8::S;
-  hipLaunchKernelGGL(k_stem_strip8x, dim3(n_strips * n_img), dim3(64 * strip8::WAVES), stem8::LDS_BYTES, st, frames, frame_stride,
-                     row_stride, cv[0].d_wx, cv[0].d_b, sw, out, cv[1].hout, cv[1].wout, n_strips);
+  hipLaunchKernelGGL(k_stem_strip8x, dim3(n_strips * (nA + nB)), dim3(64 * strip8::WAVES), stem8::LDS_BYTES, st, framesA, nA,
+                     framesB, frame_stride, row_stride, cv[0].d_wx, cv[0].d_b, sw, out, cv[1].hout, cv[1].wout, n_strips);
 }
 
 // down-sampling block 8 -> 16 as one streaming pass (k_down16x): cs2 = 3x3 stride 2, csc = 1x1 stride 2, c2 = 3x3
@@ -3904,8 +3906,7 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
   const int strip_mode = ni >= P.strip_min_images ? P.strip_mode : 0;
   const bool stem_fused = P.fuse_blocks && P.split_bf16 && strip_mode == 3;   // stem + block 1 in one pass -> cc
   if (stem_fused) {
-    if (nA) launch_stem_strip8x(c, srcA, frame_stride, row_stride, cc, nA, st);
-    if (nB) launch_stem_strip8x(c, srcB, frame_stride, row_stride, cc + (long long)nA * s8, nB, st);
+    launch_stem_strip8x(c, srcA, nA, srcB, nB, frame_stride, row_stride, cc, st);
   } else {
     if (nA) launch_conv<1, 8, 7, 2, 64, true, false, true, 2>(c[0], srcA, frame_stride, row_stride, nullptr, a, nA, st);
     if (nB) launch_conv<1, 8, 7, 2, 64, true, false, true, 2>(c[0], srcB, frame_stride, row_stride, nullptr, a + (long long)nA * s8, nB, st);

@@ -17,7 +17,8 @@ STAGE = {"k_resize": "pyramid", "k_fast": "fast_nms", "k_fast_tau": "fast_nms", 
          "k_describe": "orient_describe", "k_match": "match", "k_conv": "backbone_convs", "k_tokens": "backbone_convs",
          "k_block8": "backbone_convs", "k_block16": "backbone_convs", "k_block8x": "backbone_convs",
          "k_block16x": "backbone_convs", "k_convx": "backbone_convs", "k_down16x": "backbone_convs",
-         "k_strip8x": "backbone_convs", "k_stem_strip8x": "backbone_convs", "k_convx2": "backbone_convs",
+         "k_strip8x": "backbone_convs", "k_stem_strip8x": "backbone_convs", "k_convx2": "backbone_convs", "k_strip16x": "backbone_convs", "k_strip32x": "backbone_convs",
+         "k_down32x": "backbone_convs",
          "k_attn_kv": "transformer", "k_attn_update": "transformer", "k_scale_feats": "match_head",
          "k_sim_stats": "match_head", "k_conf_mask": "match_head", "k_decode": "match_head"}
 
