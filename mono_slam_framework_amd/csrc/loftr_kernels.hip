@@ -2737,6 +2737,8 @@ __global__ __launch_bounds__(256) void k_tokens(const float* __restrict__ bb, co
 struct BlockW {
   const float *wq_p, *wk_p, *wv_p, *wm_p, *w0_p, *w1_p;   // permuted: [(mtile*KS + slot)*64 + lane]
   const float *n1w, *n1b, *n2w, *n2b;
+  // the same matrices as split-bf16 MFMA fragments (k_attn_update_x): [mtile][K group of 8 slots][hi | lo][lane][8]
+  const uint16_t *wq_x, *wm_x, *w0_x, *w1_x;
 };
 
 __device__ __forceinline__ float elu1(float x) { return (x > 0.f ? x : expf(x) - 1.f) + 1.f; }
@@ -2920,6 +2922,123 @@ __global__ __launch_bounds__(256) void k_attn_update(const float* __restrict__ x
       o[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int sI = 0; sI < 16; sI++) o[m] = mfma4(sW1[(m * 16 + sI) * 64 + lane], h[sI >> 2][sI & 3], o[m]);
+    }
+    layer_norm_cols(o, sLN + 2 * DM, sLN + 3 * DM, g);
+    float* dr = dst + (long long)seq * d_stride + (long long)(tile * 16 + tl) * DM;
+    *reinterpret_cast<f32x4*>(dr + 4 * g) = xd0 + o[0];
+    *reinterpret_cast<f32x4*>(dr + 16 + 4 * g) = xd1 + o[1];
+  }
+}
+
+// The same block on split-bf16 MFMAs.  In k_attn_update's formulation (features on MFMA rows, tokens on columns) the
+// activation operand of every product is the set of 8 registers a lane already holds -- features 8g .. 8g+7 of its
+// token after the load, or the two accumulator tiles of the previous product -- and 4 lane groups x 8 registers are
+// exactly the K = 32 of one v_mfma_f32_16x16x32_bf16.  So each run of 8 f32 MFMAs (K = 4 each) becomes 3 bf16 MFMAs
+// (hi.hi, hi.lo, lo.hi) on the same registers, split in place (24 VALU instructions per 8 values); the weights are
+// pre-split fragments in LDS (one ds_read_b128 per plane instead of 8 ds_read_b32).  144 f32 MFMAs of 32 cycles per
+// 16-token tile -> 54 bf16 MFMAs of 16: the kernel goes from MFMA-bound to VALU-bound (LayerNorms, ELU, splits).
+__device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
+  bf16x4 h0, l0, h1, l1;
+  split4(f32x4{v[0], v[1], v[2], v[3]}, h0, l0);
+  split4(f32x4{v[4], v[5], v[6], v[7]}, h1, l1);
+  hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+  lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ f32x4 mfma3x(bf16x8 wh, bf16x8 wl, bf16x8 xh, bf16x8 xl, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void k_attn_update_x(const float* __restrict__ xsrc, long long x_stride,
+                                                       const float* __restrict__ kv, BlockW w, float* __restrict__ dst,
+                                                       long long d_stride) {
+  // fragments: [mtile][K group][hi | lo][lane]
+  __shared__ bf16x8 sWq[2 * 2 * 64], sKV[2 * 2 * 64], sWm[2 * 2 * 64], sW0[4 * 2 * 2 * 64], sW1[2 * 2 * 2 * 64];
+  __shared__ float sLN[4 * DM], sKs[DM];
+  const int seq = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tl = lane & 15, g = lane >> 4;
+  const float* kvp = kv + (long long)seq * (DM * DM + DM);
+  for (int i = tid; i < 2 * 2 * 64; i += 256) {
+    sWq[i] = reinterpret_cast<const bf16x8*>(w.wq_x)[i];
+    sWm[i] = reinterpret_cast<const bf16x8*>(w.wm_x)[i];
+  }
+  for (int i = tid; i < 4 * 2 * 2 * 64; i += 256) sW0[i] = reinterpret_cast<const bf16x8*>(w.w0_x)[i];
+  for (int i = tid; i < 2 * 2 * 2 * 64; i += 256) sW1[i] = reinterpret_cast<const bf16x8*>(w.w1_x)[i];
+  if (tid < 128) {                                 // this sequence's KV (f32, [(m * 8 + slot) * 64 + lane]) -> fragments
+    const int m = tid >> 6, ln = tid & 63;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = kvp[(m * 8 + j) * 64 + ln];
+    bf16x8 hi, lo;
+    split8(v, hi, lo);
+    sKV[(m * 2 + 0) * 64 + ln] = hi;
+    sKV[(m * 2 + 1) * 64 + ln] = lo;
+  }
+  if (tid < DM) {
+    sLN[tid] = w.n1w[tid]; sLN[DM + tid] = w.n1b[tid]; sLN[2 * DM + tid] = w.n2w[tid]; sLN[3 * DM + tid] = w.n2b[tid];
+    sKs[tid] = kvp[DM * DM + tid];
+  }
+  __syncthreads();
+  for (int it = 0; it < kUpdTilesPerWave; it++) {
+    const int tile = (blockIdx.x * kUpdTilesPerWave + it) * 4 + wave;
+    if (tile >= NTOK / 16) break;
+    const float* xr = xsrc + (long long)seq * x_stride + (long long)(tile * 16 + tl) * DM;
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(xr + 8 * g), b1 = *reinterpret_cast<const f32x4*>(xr + 8 * g + 4);
+    const float xb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};                 // P8 slots
+    const f32x4 xd0 = *reinterpret_cast<const f32x4*>(xr + 4 * g), xd1 = *reinterpret_cast<const f32x4*>(xr + 16 + 4 * g);
+    bf16x8 xh, xl;
+    split8(xb, xh, xl);
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    // q = Wq^T x ; Q = elu(q) + 1 ; Z = 1 / (Q . Ksum + eps)
+    float qv[8];
+    float zp = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+      const f32x4 q = mfma3x(sWq[(m * 2 + 0) * 64 + lane], sWq[(m * 2 + 1) * 64 + lane], xh, xl, zero);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        qv[4 * m + r] = elu1(q[r]);
+        zp += qv[4 * m + r] * sKs[16 * m + 4 * g + r];
+      }
+    }
+    const float z = 1.0f / (quad_sum(zp) + 9.999999974752427e-07f);
+    bf16x8 qh, ql;
+    split8(qv, qh, ql);
+    // msg = (KV^T Q) * Z * 1200
+    float msv[8];
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+      const f32x4 t = mfma3x(sKV[(m * 2 + 0) * 64 + lane], sKV[(m * 2 + 1) * 64 + lane], qh, ql, zero);
+#pragma unroll
+      for (int r = 0; r < 4; r++) msv[4 * m + r] = t[r] * z * 1200.0f;
+    }
+    bf16x8 mh, ml;
+    split8(msv, mh, ml);
+    // merge + LN1
+    f32x4 mg[2];
+#pragma unroll
+    for (int m = 0; m < 2; m++) mg[m] = mfma3x(sWm[(m * 2 + 0) * 64 + lane], sWm[(m * 2 + 1) * 64 + lane], mh, ml, zero);
+    layer_norm_cols(mg, sLN, sLN + DM, g);
+    const float mgv[8] = {mg[0][0], mg[0][1], mg[0][2], mg[0][3], mg[1][0], mg[1][1], mg[1][2], mg[1][3]};
+    bf16x8 gh, gl;
+    split8(mgv, gh, gl);
+    // MLP on [x | mg]: 64 -> 64 (ReLU) -> 32, LN2, residual
+    float hv[16];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      f32x4 t = mfma3x(sW0[((m * 2 + 0) * 2 + 0) * 64 + lane], sW0[((m * 2 + 0) * 2 + 1) * 64 + lane], xh, xl, zero);
+      t = mfma3x(sW0[((m * 2 + 1) * 2 + 0) * 64 + lane], sW0[((m * 2 + 1) * 2 + 1) * 64 + lane], gh, gl, t);
+#pragma unroll
+      for (int r = 0; r < 4; r++) hv[4 * m + r] = fmaxf(t[r], 0.f);
+    }
+    bf16x8 h0h, h0l, h1h, h1l;
+    split8(hv, h0h, h0l);
+    split8(hv + 8, h1h, h1l);
+    f32x4 o[2];
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+      o[m] = mfma3x(sW1[((m * 2 + 0) * 2 + 0) * 64 + lane], sW1[((m * 2 + 0) * 2 + 1) * 64 + lane], h0h, h0l, zero);
+      o[m] = mfma3x(sW1[((m * 2 + 1) * 2 + 0) * 64 + lane], sW1[((m * 2 + 1) * 2 + 1) * 64 + lane], h1h, h1l, o[m]);
     }
     layer_norm_cols(o, sLN + 2 * DM, sLN + 3 * DM, g);
     float* dr = dst + (long long)seq * d_stride + (long long)(tile * 16 + tl) * DM;
@@ -3582,6 +3701,40 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
       float* d = nullptr;
       LF_TRY(upload(pk, &d));
       *it.dst = d;
+      // split-bf16 fragments of the matrices k_attn_update_x multiplies by: element j of lane ln of (mtile, K group kg)
+      // is slot 8 kg + j of the f32 packing above
+      const uint16_t** xdst = !strcmp(it.n, "wq") ? &P.blk[b].wq_x : !strcmp(it.n, "wmerge") ? &P.blk[b].wm_x
+                              : !strcmp(it.n, "wmlp0") ? &P.blk[b].w0_x : !strcmp(it.n, "wmlp1") ? &P.blk[b].w1_x : nullptr;
+      if (xdst) {
+        auto to_bf16 = [](float f) -> uint16_t {
+          uint32_t u;
+          memcpy(&u, &f, 4);
+          u += 0x7FFFu + ((u >> 16) & 1u);
+          return (uint16_t)(u >> 16);
+        };
+        auto from_bf16 = [](uint16_t h) -> float {
+          const uint32_t u = (uint32_t)h << 16;
+          float f;
+          memcpy(&f, &u, 4);
+          return f;
+        };
+        const int kgs = slots / 8;
+        std::vector<uint16_t> fx((size_t)mtiles * kgs * 2 * 64 * 8);
+        for (int mt = 0; mt < mtiles; mt++)
+          for (int kg = 0; kg < kgs; kg++)
+            for (int ln = 0; ln < 64; ln++)
+              for (int j = 0; j < 8; j++) {
+                const float v = pk[((size_t)mt * slots + kg * 8 + j) * 64 + ln];
+                const uint16_t hi = to_bf16(v), lo = to_bf16(v - from_bf16(hi));
+                fx[((((size_t)mt * kgs + kg) * 2 + 0) * 64 + ln) * 8 + j] = hi;
+                fx[((((size_t)mt * kgs + kg) * 2 + 1) * 64 + ln) * 8 + j] = lo;
+              }
+        uint16_t* dx = nullptr;
+        LF_TRY(hipMalloc(reinterpret_cast<void**>(&dx), fx.size() * sizeof(uint16_t)));
+        P.allocs.push_back(reinterpret_cast<float*>(dx));
+        LF_TRY(hipMemcpy(dx, fx.data(), fx.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        *xdst = dx;
+      }
     }
     struct { const char* n; const float** dst; } lns[] = {
         {"n1w", &P.blk[b].n1w}, {"n1b", &P.blk[b].n1b}, {"n2w", &P.blk[b].n2w}, {"n2b", &P.blk[b].n2b}};
@@ -4010,7 +4163,8 @@ hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf
   const int upd_blocks = (NTOK / 16 + 4 * kUpdTilesPerWave - 1) / (4 * kUpdTilesPerWave);
   for (int bi = 0; bi < 8; bi++) {
     hipLaunchKernelGGL(k_attn_kv, dim3(n), dim3(64 * kKvWaves), 0, st, seq[bi].s, ts, P.blk[bi], P.kv);
-    hipLaunchKernelGGL(k_attn_update, dim3(upd_blocks, n), dim3(256), 0, st, seq[bi].x, ts, P.kv, P.blk[bi], seq[bi].o, ts);
+    if (P.split_bf16) hipLaunchKernelGGL(k_attn_update_x, dim3(upd_blocks, n), dim3(256), 0, st, seq[bi].x, ts, P.kv, P.blk[bi], seq[bi].o, ts);
+    else hipLaunchKernelGGL(k_attn_update, dim3(upd_blocks, n), dim3(256), 0, st, seq[bi].x, ts, P.kv, P.blk[bi], seq[bi].o, ts);
   }
   if (ev) hipEventRecord(ev[2], st);
   // ---- matching head on (f0, f1)
