@@ -2823,6 +2823,10 @@ __global__ __launch_bounds__(64 * kKvWaves) void k_attn_kv(const float* __restri
   if (tid < DM) o[DM * DM + tid] = red[0][DM * DM + tid];
 }
 
+// k_attn_kv on split-bf16 MFMAs.  Projections: the lane's 8 loaded features are the K = 32 fragment (as in
+// k_attn_update_x).  KV = sum over tokens of K[tok][d] V[tok][e]: the MFMA's K dimension is the token index, and a lane
+// holds 4 tokens of a tile per accumulator register set, so two token tiles are taken together: 8 registers = one
+// fragment, 3 MFMAs per (d tile, e tile) and tile pair instead of 8.  Defined after split8 / mfma3x below.
 // LayerNorm over the 32 features of a token held as v[2] (rows 16m + 4g + r of column lane & 15)
 __device__ __forceinline__ void layer_norm_cols(f32x4* v, const float* w, const float* b, int g) {
   float sum = 0.f;
@@ -2948,6 +2952,95 @@ __device__ __forceinline__ f32x4 mfma3x(bf16x8 wh, bf16x8 wl, bf16x8 xh, bf16x8 
   c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, c, 0, 0, 0);
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(64 * kKvWaves) void k_attn_kv_x(const float* __restrict__ src, long long seq_stride, BlockW w,
+                                                             float* __restrict__ kv /*[n][1056]: KV in PD order | Ksum*/) {
+  __shared__ bf16x8 sWk[2 * 2 * 64], sWv[2 * 2 * 64];           // fragments [cout tile][hi | lo][lane]
+  __shared__ float red[kKvWaves][DM * DM + DM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tl = lane & 15, g = lane >> 4;
+  const float* s = src + (long long)blockIdx.x * seq_stride;
+  if (tid < 256) {                                               // f32 packing [(n * 8 + slot) * 64 + lane] -> fragments
+    const bool isv = tid >= 128;
+    const int n = (tid >> 6) & 1, ln = tid & 63;
+    const float* wp = isv ? w.wv_p : w.wk_p;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = wp[(n * 8 + j) * 64 + ln];
+    bf16x8 hi, lo;
+    split8(v, hi, lo);
+    (isv ? sWv : sWk)[(n * 2 + 0) * 64 + ln] = hi;
+    (isv ? sWv : sWk)[(n * 2 + 1) * 64 + ln] = lo;
+  }
+  __syncthreads();
+  const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[2][2] = {{zero, zero}, {zero, zero}};
+  float ksum[2] = {0.f, 0.f};
+  constexpr int NT16 = NTOK / 16;                                // 75 token tiles: 37 pairs + one single
+  for (int t0 = 2 * wave; t0 < NT16; t0 += 2 * kKvWaves) {
+    float Kv[2][8], Vv[2][8];                                    // [feature tile][tile of the pair * 4 + r]
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int tile = t0 + h;
+      if (tile < NT16) {
+        const float* xr = s + (long long)(tile * 16 + tl) * DM + 8 * g;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(xr), x1 = *reinterpret_cast<const f32x4*>(xr + 4);
+        const float xa[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        bf16x8 xh, xl;
+        split8(xa, xh, xl);
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+          // projections as k_attn_kv: tokens on MFMA rows (A = x), features on columns (B = weights)
+          const f32x4 K = mfma3x(xh, xl, sWk[(n * 2 + 0) * 64 + lane], sWk[(n * 2 + 1) * 64 + lane], zero);
+          const f32x4 V = mfma3x(xh, xl, sWv[(n * 2 + 0) * 64 + lane], sWv[(n * 2 + 1) * 64 + lane], zero);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            Kv[n][4 * h + r] = elu1(K[r]);
+            Vv[n][4 * h + r] = V[r] / 1200.0f;
+            ksum[n] += Kv[n][4 * h + r];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) { Kv[n][4 * h + r] = 0.f; Vv[n][4 * h + r] = 0.f; }
+      }
+    }
+    bf16x8 Kh[2], Kl[2], Vh[2], Vl[2];
+#pragma unroll
+    for (int n = 0; n < 2; n++) { split8(Kv[n], Kh[n], Kl[n]); split8(Vv[n], Vh[n], Vl[n]); }
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+      for (int n = 0; n < 2; n++) acc[m][n] = mfma3x(Kh[m], Kl[m], Vh[n], Vl[n], acc[m][n]);   // k-slots = the pair's 32 tokens
+  }
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) red[wave][(16 * m + 4 * g + r) * DM + 16 * n + tl] = acc[m][n][r];
+#pragma unroll
+  for (int n = 0; n < 2; n++) {
+    const float t = quad_sum(ksum[n]);
+    if (g == 0) red[wave][DM * DM + 16 * n + tl] = t;
+  }
+  __syncthreads();
+  for (int i = tid; i < DM * DM + DM; i += 64 * kKvWaves) {
+    float t = red[0][i];
+#pragma unroll
+    for (int w2 = 1; w2 < kKvWaves; w2++) t += red[w2][i];
+    red[0][i] = t;
+  }
+  __syncthreads();
+  float* o = kv + (long long)blockIdx.x * (DM * DM + DM);
+  for (int i = tid; i < DM * DM; i += 64 * kKvWaves) {     // KV as the A operand of msg = KV^T Q, PD slot order over d
+    const int ln = i & 63, sl = (i >> 6) & 7, me = i >> 9;
+    const int d = 16 * (sl >> 2) + 4 * (ln >> 4) + (sl & 3), e = 16 * me + (ln & 15);
+    o[i] = red[0][d * DM + e];
+  }
+  if (tid < DM) o[DM * DM + tid] = red[0][DM * DM + tid];
 }
 
 __global__ __launch_bounds__(256) void k_attn_update_x(const float* __restrict__ xsrc, long long x_stride,
@@ -4162,7 +4255,8 @@ hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf
       {f0, f0, t0}, {f1, f1, t1}, {t0, t1, f0}, {t1, f0, f1}, {f0, f0, t0}, {f1, f1, t1}, {t0, t1, f0}, {t1, f0, f1}};
   const int upd_blocks = (NTOK / 16 + 4 * kUpdTilesPerWave - 1) / (4 * kUpdTilesPerWave);
   for (int bi = 0; bi < 8; bi++) {
-    hipLaunchKernelGGL(k_attn_kv, dim3(n), dim3(64 * kKvWaves), 0, st, seq[bi].s, ts, P.blk[bi], P.kv);
+    if (P.split_bf16) hipLaunchKernelGGL(k_attn_kv_x, dim3(n), dim3(64 * kKvWaves), 0, st, seq[bi].s, ts, P.blk[bi], P.kv);
+    else hipLaunchKernelGGL(k_attn_kv, dim3(n), dim3(64 * kKvWaves), 0, st, seq[bi].s, ts, P.blk[bi], P.kv);
     if (P.split_bf16) hipLaunchKernelGGL(k_attn_update_x, dim3(upd_blocks, n), dim3(256), 0, st, seq[bi].x, ts, P.kv, P.blk[bi], seq[bi].o, ts);
     else hipLaunchKernelGGL(k_attn_update, dim3(upd_blocks, n), dim3(256), 0, st, seq[bi].x, ts, P.kv, P.blk[bi], seq[bi].o, ts);
   }
