@@ -19,7 +19,8 @@ STAGE = {"k_resize": "pyramid", "k_fast": "fast_nms", "k_fast_tau": "fast_nms", 
          "k_block16x": "backbone_convs", "k_convx": "backbone_convs", "k_down16x": "backbone_convs",
          "k_strip8x": "backbone_convs", "k_stem_strip8x": "backbone_convs", "k_convx2": "backbone_convs", "k_strip16x": "backbone_convs", "k_strip32x": "backbone_convs",
          "k_down32x": "backbone_convs",
-         "k_attn_kv": "transformer", "k_attn_update": "transformer", "k_scale_feats": "match_head",
+         "k_attn_kv": "transformer", "k_attn_update": "transformer", "k_attn_kv_x": "transformer",
+         "k_attn_update_x": "transformer", "k_scale_feats": "match_head",
          "k_sim_stats": "match_head", "k_conf_mask": "match_head", "k_decode": "match_head"}
 
 
