@@ -205,12 +205,15 @@ def run_workload(args, matcher, W, H, P, ratio_or_thr, rank, world, local_rank, 
                         "hbm_frac": (round(traffic["bytes"] / (stages[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
                                      if traffic and not args.loftr_f32 else None)}
         elif dom:
+            # a batch of >= 256 frames is extracted as two pipelined sub-batches: every batch kernel is launched once per
+            # part, stage times are sums over the parts, and "per launch" below is per part
+            launches = fm.extract_parts(2 * P)
             achieved = P * bpp / (stages[dom] * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom,
                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                        "avg_launch_ms": round(stages[dom], 4),
-                        "algorithmic_bytes_per_launch": P * bpp,
+                        "avg_launch_ms": round(stages[dom] / launches, 4), "launches_per_step": launches,
+                        "algorithmic_bytes_per_launch": P * bpp // launches,
                         "stage_ms": {k: round(v, 4) for k, v in stages.items()},
                         "pipeline_frac": round(value / world * bpp / 1e9 / HBM_PEAK_GBS, 5)}
         if world > 1:
@@ -257,7 +260,8 @@ def traffic_record(matcher, dom, P, W, H):
         return None
     if tj.get("_pairs_per_gpu") != P or tj.get("_width", W) != W or dom not in tj:
         return None
-    return {"bytes": tj[dom], "source": "profiles/traffic_%s.json" % matcher, "measured_at": tj.get("_commit")}
+    return {"bytes": tj[dom], "per": "step (all launches of the stage)", "source": "profiles/traffic_%s.json" % matcher,
+            "measured_at": tj.get("_commit")}
 
 
 def main():

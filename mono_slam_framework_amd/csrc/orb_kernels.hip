@@ -1677,8 +1677,20 @@ void OrbPipeline::destroy() {
   hipFree(d_kp_); hipFree(d_desc_); hipFree(d_kp_cnt_); hipFree(d_status_);
   d_pyr_ = nullptr; d_tab_ = nullptr; d_cand_cnt_ = nullptr; d_cand_ = nullptr; d_cand_sc_ = nullptr; d_qres_ = nullptr; d_done_ = nullptr; d_s1_cnt_ = nullptr;
   d_s1_ = nullptr; d_kp_ = nullptr; d_desc_ = nullptr; d_kp_cnt_ = nullptr; d_status_ = nullptr;
-  if (ev_ok_) for (auto& e : ev_) hipEventDestroy(e);
+  if (ev_ok_) {
+    for (auto& e : ev_) hipEventDestroy(e);
+    for (auto& e : ev2_) if (e) hipEventDestroy(e);
+  }
   ev_ok_ = false;
+  if (split_stream_) {
+    hipStreamSynchronize(split_stream_);
+    for (auto& ev : split_ev_) if (ev) hipEventDestroy(ev);
+    for (auto& ev : split_pyr_) if (ev) hipEventDestroy(ev);
+    hipStreamDestroy(split_stream_);
+    split_stream_ = nullptr;
+    hipFree(d_redo2_);
+    d_redo2_ = nullptr;
+  }
   if (tau_stream_) {
     hipStreamSynchronize(tau_stream_);
     for (auto& e : tau_ev_) hipEventDestroy(e);
@@ -1859,10 +1871,19 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   }
   if (profile_) {
     for (auto& e : ev_) MSF_HIP_TRY(hipEventCreate(&e));
+    for (auto& e : ev2_) MSF_HIP_TRY(hipEventCreate(&e));
     ev_ok_ = true;
   }
   if (!getenv("MSF_ORB_NO_SIDE_STREAM")) {
     MSF_HIP_TRY(hipStreamCreateWithFlags(&tau_stream_, hipStreamNonBlocking));
+    const int parts = getenv("MSF_ORB_SPLIT2") ? atoi(getenv("MSF_ORB_SPLIT2")) : 0;   // opt-in: see orb_pipeline.h
+    if (parts >= 2) {
+      MSF_HIP_TRY(hipStreamCreateWithFlags(&split_stream_, hipStreamNonBlocking));
+      for (auto& ev : split_ev_) MSF_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      for (auto& ev : split_pyr_) MSF_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      split_parts_ = parts < 2 ? 2 : parts > 8 ? 8 : parts;
+      MSF_HIP_TRY(hipMalloc(&d_redo2_, (1 + (size_t)S * kOrbLevels) * sizeof(uint32_t)));
+    }
     for (auto& e : tau_ev_) MSF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   return "";
@@ -1871,13 +1892,52 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
 hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
   if (n <= 0) return hipSuccess;
   if (src.slot0 < 0 || src.slot0 + n > max_slots_) return hipErrorInvalidValue;
-  const OrbGeometry& g = g_;
   last_src_ = src;
+  last_split_ = false;
+  if (split_stream_ && n >= 256) {
+    // K parts, alternately on the caller's stream and the second one; part k's pyramid starts when part k-1's is done
+    last_split_ = true;
+    const int K = ev_ok_ ? 2 : split_parts_;                // stage events exist for two parts
+    hipEvent_t evs0[5] = {ev_[0], ev_[1], ev_[2], ev_[3], ev_[6]};   // ev_[4] = start of the match stage: after the join
+    hipEventRecord(split_ev_[0], st);                       // everything queued on st so far precedes all parts
+    hipStreamWaitEvent(split_stream_, split_ev_[0], 0);
+    int f0 = 0;
+    for (int k = 0; k < K; k++) {
+      const int f1 = (int)((long long)n * (k + 1) / K), cnt = f1 - f0;
+      FrameSrc sk = src;
+      sk.slot0 = src.slot0 + f0;
+      if (f0 <= src.n_a) { sk.a = src.a + (long long)f0 * src.frame_stride; sk.n_a = src.n_a - f0; }
+      else { sk.n_a = 0; sk.b = src.b + (long long)(f0 - src.n_a) * src.frame_stride; }
+      hipStream_t sk_st = (k & 1) ? split_stream_ : st;
+      if (k > 0) hipStreamWaitEvent(sk_st, split_pyr_[(k - 1) & 7], 0);
+      hipEvent_t* evs = !ev_ok_ ? nullptr : k == 0 ? evs0 : k == 1 ? ev2_ : nullptr;
+      hipError_t e = extract_range(sk, cnt, sk_st, (k & 1) ? d_redo2_ : d_redo_, k == 0, evs, split_pyr_[k & 7]);
+      if (e != hipSuccess) return e;
+      f0 = f1;
+    }
+    hipEventRecord(split_ev_[2], split_stream_);
+    hipStreamWaitEvent(st, split_ev_[2], 0);
+    if (ev_ok_) {
+      hipEventRecord(ev_[4], st);
+      ev_extract_pending_ = true;
+    }
+    return hipGetLastError();
+  }
+  const hipError_t e = extract_range(src, n, st, d_redo_, true, ev_ok_ ? ev_ : nullptr, nullptr);
+  if (ev_ok_) ev_extract_pending_ = true;
+  return e;
+}
+
+// one sub-batch: pyramid, FAST, selection, descriptors of frames src[0 .. n) on stream st; evs (or null): five events
+// recorded at the stage boundaries (start, pyramid, FAST, selection, descriptors done)
+hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st, uint32_t* d_redo_, bool allow_side,
+                                      hipEvent_t* evs, hipEvent_t pyramid_done) {
+  const OrbGeometry& g = g_;
   hipError_t e;
   if ((e = hipMemsetAsync(d_cand_cnt_ + (size_t)src.slot0 * kOrbLevels, 0, (size_t)n * kOrbLevels * 4, st))) return e;
   if ((e = hipMemsetAsync(d_status_ + src.slot0, 0, (size_t)n * 4, st))) return e;
   if ((e = hipMemsetAsync(d_redo_, 0, 4, st))) return e;
-  if (ev_ok_) hipEventRecord(ev_[0], st);
+  if (evs) hipEventRecord(evs[0], st);
   // k_fast_tau is a light, latency-bound kernel (one workgroup per (frame, level), scattered loads): for a batch it
   // runs level by level on a side stream underneath the pyramid kernels, each level as soon as it exists
   uint32_t* tau = d_tau_;
@@ -1886,7 +1946,7 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
   // streaming pass walks its strip in ~70 dependent steps, whereas the dense tile kernel is one short workgroup per
   // tile.  Such calls take the dense kernel directly; the result is the same either way.
   const int force_tau = (force_tau_ == 0 && n < stream_min_frames_) ? kFastT : force_tau_;
-  const bool side = tau_stream_ != nullptr && n >= 64 && g.total_tiles > 0 && force_tau != kFastT;
+  const bool side = allow_side && tau_stream_ != nullptr && n >= 64 && g.total_tiles > 0 && force_tau != kFastT;
   if (side) {
     hipEventRecord(tau_ev_[0], st);
     hipStreamWaitEvent(tau_stream_, tau_ev_[0], 0);
@@ -1915,7 +1975,8 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
                          d_redo_, d_redo_ + 1, l);
     }
   }
-  if (ev_ok_) hipEventRecord(ev_[1], st);
+  if (evs) hipEventRecord(evs[1], st);
+  if (pyramid_done) hipEventRecord(pyramid_done, st);
   if (g.total_tiles > 0) {
     if (side) {
       hipEventRecord(tau_ev_[kOrbLevels], tau_stream_);
@@ -1940,12 +2001,12 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
                          g.max_level_tiles, d_cand_cnt_, d_cand_, d_cand_sc_);
     }
   }
-  if (ev_ok_) hipEventRecord(ev_[2], st);
+  if (evs) hipEventRecord(evs[2], st);
   hipLaunchKernelGGL(k_thr_harris, dim3(g.nlevels, n), dim3(force_tau == kFastT ? 256 : 64), 0, st, g, src, d_pyr_,
                      d_cand_cnt_, d_cand_, d_cand_sc_, d_s1_cnt_, d_s1_, d_status_);
   hipLaunchKernelGGL(k_select, dim3(n), dim3(256), 0, st, g, src.slot0, d_s1_cnt_, d_s1_, d_kp_, d_kp_cnt_,
                      d_status_);
-  if (ev_ok_) hipEventRecord(ev_[3], st);
+  if (evs) hipEventRecord(evs[3], st);
   {
     // 4 key points per workgroup pass: 8 workgroups per frame keep a big batch busy; a single pair (the drop-in call)
     // gets up to 128 so that its ~500 key points per frame are one pass instead of sixteen
@@ -1954,10 +2015,7 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
     hipLaunchKernelGGL(k_describe, dim3(bx, n), dim3(256), 0, st, g, src, d_pyr_, d_kp_, d_kp_cnt_, d_desc_,
                        half_up_ ? 1 : 0);
   }
-  if (ev_ok_) {
-    hipEventRecord(ev_[4], st);
-    ev_extract_pending_ = true;
-  }
+  if (evs) hipEventRecord(evs[4], st);
   return hipGetLastError();
 }
 
@@ -1994,7 +2052,14 @@ int OrbPipeline::stage_times(const char** names, float* ms, int cap) {
   int n = 0;
   for (int i = ev_match_only_ ? 4 : 0; i < 5 && n < cap; i++, n++) {
     names[n] = kNames[i];
-    if (hipEventElapsedTime(&ms[n], ev_[i], ev_[i + 1]) != hipSuccess) ms[n] = -1.f;
+    // a split extraction (two sub-batches on two streams): a stage's time is the sum over the two parts (each measured
+    // on its own stream, i.e. with the other part's kernels beside it); part 0's descriptors end at ev_[6]
+    hipEvent_t e1 = (last_split_ && !ev_match_only_ && i == 3) ? ev_[6] : ev_[i + 1];
+    if (hipEventElapsedTime(&ms[n], ev_[i], e1) != hipSuccess) ms[n] = -1.f;
+    if (last_split_ && !ev_match_only_ && i < 4) {
+      float t2 = 0.f;
+      if (hipEventElapsedTime(&t2, ev2_[i], ev2_[i + 1]) == hipSuccess) ms[n] += t2;
+    }
   }
   return n;
 }

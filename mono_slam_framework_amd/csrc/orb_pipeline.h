@@ -104,6 +104,21 @@ class OrbPipeline {
   FrameSrc last_src_{};
   hipStream_t tau_stream_ = nullptr;            // k_fast_tau of a batch runs here, underneath the pyramid kernels
   hipEvent_t tau_ev_[kOrbLevels + 1] = {};      // level l exists (fork points), all thresholds written (join)
+  // Opt-in (MSF_ORB_SPLIT2=K, K = 2 .. 8): a batch of >= 256 frames is extracted as K sub-batches, alternately on the
+  // caller's stream and split_stream_, part k's pyramid starting when part k-1's is done: the latency-bound streaming
+  // FAST of one part then runs beside the Harris / descriptor kernels of the other (9.44 -> 9.05 ms per 1024 720p pairs,
+  // K = 2 .. 6 alike).  Not the default: with two parts in flight the stage boundaries that msf_stage_times (and the
+  // bench's roofline entry) rest on are no longer well defined -- each part's stages are timed on its own stream with
+  // the other part's kernels beside them, and the sums exceed the step time (13.1 ms of stages in a 9.1 ms step).
+  hipStream_t split_stream_ = nullptr;
+  hipEvent_t split_ev_[3] = {};
+  hipEvent_t split_pyr_[8] = {};
+  hipEvent_t ev2_[kOrbStages + 2] = {};         // stage boundaries of the parts on split_stream_ (profiling)
+  int split_parts_ = 2;
+  bool last_split_ = false;
+  uint32_t* d_redo2_ = nullptr;
+  hipError_t extract_range(const FrameSrc& src, int n, hipStream_t st, uint32_t* redo, bool allow_side, hipEvent_t* evs,
+                           hipEvent_t pyramid_done);
 };
 
 }  // namespace msf

@@ -213,6 +213,17 @@ class FeatureMatcher(_Matcher):
     def level_sizes(self):
         return self._debug(_lib.DBG_LEVEL_SIZES, 0, 0, np.int32, 8 * 4 * 4).reshape(8, 4)
 
+    @staticmethod
+    def extract_parts(n_frames):
+        """Sub-batches one extraction of n_frames frames runs as: 1, or 2 with the opt-in MSF_ORB_SPLIT2=K >= 2 for batches
+        of >= 256 frames (OrbPipeline::extract pipelines the parts on two streams; msf_stage_times then reports each
+        stage summed over the first two parts)."""
+        import os
+        parts = int(os.environ.get("MSF_ORB_SPLIT2", "0"))
+        if n_frames < 256 or parts < 2 or os.environ.get("MSF_ORB_NO_SIDE_STREAM"):
+            return 1
+        return 2
+
     # Introspection of the feature slots.  `slot` counts from the scratch slots of the last MatchFrames / match_batch
     # call (frame A of pair i = i, frame B = n_pairs + i); cache=True addresses the per-frame cache slots of
     # extract_device / store_frame instead (the two ranges are disjoint: [2P, 4P) and [0, 2P), P = max_batch_pairs).

@@ -406,3 +406,27 @@ def test_full_size_batch_properties():
     orc = oracle_orb.FeatureMatcherOracle(0.6)
     for i in (0, n - 1):
         np.testing.assert_array_equal(o1[i, :c1[i]], orc.MatchFrames(A[i], B[i]))
+
+
+@pytest.mark.gpu
+def test_split_extraction_equals_single_pass(monkeypatch):
+    """Opt-in MSF_ORB_SPLIT2=2: batches of >= 256 frames are extracted as two pipelined sub-batches on two streams
+    (OrbPipeline::extract).  Same frames, same slots: identical match lists to the one-pass default, and the stage
+    times of the split run (sums over the parts) are all reported."""
+    from mono_slam_framework_amd import _lib
+    from mono_slam_framework_amd.matcher import FeatureMatcher
+    n = 160                                          # 320 frames
+    A, B = synth.synth_batch(9100, n, 320, 240, mode=0)
+    fl = _lib.MSF_FLAG_NO_FRAME_CACHE | _lib.MSF_FLAG_PROFILE
+    assert FeatureMatcher.extract_parts(2 * n) == 1
+    whole = FeatureMatcher(0.7, 320, 240, max_batch_pairs=n, flags=fl)
+    ref = whole.match_batch(list(A), list(B), cap=1024)
+    assert sum(len(m) for m in ref) > 10 * n
+    monkeypatch.setenv("MSF_ORB_SPLIT2", "2")
+    assert FeatureMatcher.extract_parts(2 * n) == 2
+    split = FeatureMatcher(0.7, 320, 240, max_batch_pairs=n, flags=fl)
+    got = split.match_batch(list(A), list(B), cap=1024)
+    st = split.stage_times()
+    assert set(st) == {"pyramid", "fast_nms", "select_harris", "orient_describe", "match"} and all(v > 0 for v in st.values())
+    for r, g in zip(ref, got):
+        np.testing.assert_array_equal(r, g)
