@@ -1976,7 +1976,7 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
     }
   }
   if (evs) hipEventRecord(evs[1], st);
-  if (pyramid_done) hipEventRecord(pyramid_done, st);
+  if (pyramid_done) hipEventRecord(pyramid_done, st);   // the next part may start (after FAST / selection instead: 9.26 / 9.29 vs 9.07 ms)
   if (g.total_tiles > 0) {
     if (side) {
       hipEventRecord(tau_ev_[kOrbLevels], tau_stream_);
