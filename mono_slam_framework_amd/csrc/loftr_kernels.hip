@@ -3306,6 +3306,114 @@ __global__ __launch_bounds__(256) void k_sim_stats(const float* __restrict__ fa,
   }
 }
 
+// The split path's form of k_sim_stats: a wave carries THREE row tiles (75 = 25 x 3) through the column loop, so every
+// column-tile fragment is fetched once per three tiles of S -- the one-tile-per-wave form re-reads f1's planes 75 times
+// per pair through L2 (4.3 GB per pass, ~14 TB/s aggregate: the pass was bound there, not by its soft-max VALU work).
+constexpr int kSimRT = 3;
+constexpr int kSimWaves = 5;                              // 5 waves x 5 workgroups = the 25 row-tile triples of a pair
+template <bool EMIT>
+__global__ __launch_bounds__(64 * kSimWaves) void k_sim_stats3(const __bf16* __restrict__ pa, const __bf16* __restrict__ pb,
+                                                               long long pair_stride, float* __restrict__ stats,
+                                                               long long stats_stride, const float* __restrict__ lim,
+                                                               SimCand* __restrict__ cand, uint32_t* __restrict__ cand_cnt) {
+  const int pair = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tl = lane & 15, g = lane >> 4;
+  const int it0 = (blockIdx.x * kSimWaves + wave) * kSimRT;
+  if (it0 >= NTOK / 16) return;
+  static_assert((NTOK / 16) % kSimRT == 0, "row tiles per wave");
+  const bf16x8* PA = reinterpret_cast<const bf16x8*>(pa + (long long)pair * 3 * pair_stride);
+  const bf16x8* PB = reinterpret_cast<const bf16x8*>(pb + (long long)pair * 3 * pair_stride);
+  constexpr int kPlane = NTOK * DM / 8;
+  bf16x8 a3[kSimRT][3];
+#pragma unroll
+  for (int t = 0; t < kSimRT; t++)
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) a3[t][pl] = PA[pl * kPlane + ((it0 + t) * 16 + tl) * (DM / 8) + g];
+  float mx[kSimRT][4], sm[kSimRT][4];
+#pragma unroll
+  for (int t = 0; t < kSimRT; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { mx[t][r] = -INFINITY; sm[t][r] = 0.f; }
+  constexpr int TJ = 3;
+  for (int jt0 = 0; jt0 < NTOK / 16; jt0 += TJ) {
+    float sv[kSimRT][TJ][4];
+#pragma unroll
+    for (int u = 0; u < TJ; u++) {
+      bf16x8 b3[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; pl++) b3[pl] = PB[pl * kPlane + ((jt0 + u) * 16 + tl) * (DM / 8) + g];
+#pragma unroll
+      for (int t = 0; t < kSimRT; t++) {
+        f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[t][2], b3[0], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[t][0], b3[2], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[t][1], b3[1], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[t][1], b3[0], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[t][0], b3[1], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[t][0], b3[0], d, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) sv[t][u][r] = div_temperature(d[r]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < kSimRT; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float mn = mx[t][r];
+#pragma unroll
+        for (int u = 0; u < TJ; u++) mn = fmaxf(mn, sv[t][u][r]);
+        float add = 0.f;
+#pragma unroll
+        for (int u = 0; u < TJ; u++) add += __expf(sv[t][u][r] - mn);
+        sm[t][r] = sm[t][r] * __expf(mx[t][r] - mn) + add;
+        mx[t][r] = mn;
+      }
+    if (EMIT) {
+#pragma unroll
+      for (int u = 0; u < TJ; u++) {
+        // the tile is S^T: this lane holds s_ij for i = jt*16 + tl (the row of S) and j = it*16 + 4g + r
+        const int i = (jt0 + u) * 16 + tl;
+        const float li = lim[(long long)pair * NTOK + i];
+#pragma unroll
+        for (int t = 0; t < kSimRT; t++) {
+          const bool h0 = sv[t][u][0] >= li, h1 = sv[t][u][1] >= li, h2 = sv[t][u][2] >= li, h3 = sv[t][u][3] >= li;
+          if (__any(h0 | h1 | h2 | h3)) {
+            const uint32_t nh = (uint32_t)h0 + h1 + h2 + h3;
+            if (nh) {
+              uint32_t k = atomicAdd(&cand_cnt[pair], nh);
+              SimCand* c = cand + (long long)pair * kCandCap;
+              const bool hs[4] = {h0, h1, h2, h3};
+#pragma unroll
+              for (int r = 0; r < 4; r++)
+                if (hs[r]) {
+                  if (k < (uint32_t)kCandCap) c[k] = SimCand{(uint32_t)i | ((uint32_t)((it0 + t) * 16 + 4 * g + r) << 16), sv[t][u][r]};
+                  k++;
+                }
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < kSimRT; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      float m = mx[t][r], sx = sm[t][r];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        const float m2 = __shfl_xor(m, o), s2 = __shfl_xor(sx, o);
+        const float mm = fmaxf(m, m2);
+        sx = sx * __expf(m - mm) + s2 * __expf(m2 - mm);
+        m = mm;
+      }
+      if (tl == 0) {
+        float* st = stats + (long long)pair * stats_stride;
+        st[(it0 + t) * 16 + 4 * g + r] = m;
+        st[NTOK + (it0 + t) * 16 + 4 * g + r] = sx;
+      }
+    }
+}
+
 // working copies of cached per-frame tokens for the pairs (slot_a[i], slot_b[i]): z = 0 -> f0, z = 1 -> f1
 __global__ __launch_bounds__(256) void k_gather_tokens(const float* __restrict__ cache, const int32_t* __restrict__ slot_a,
                                                        const int32_t* __restrict__ slot_b, int n_slots,
@@ -4269,8 +4377,8 @@ hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf
   hipLaunchKernelGGL(k_scale_feats, dim3((unsigned)((n * ts + 255) / 256)), dim3(256), 0, st, f0, f0s, n * ts, p0, ts);
   hipLaunchKernelGGL(k_scale_feats, dim3((unsigned)((n * ts + 255) / 256)), dim3(256), 0, st, f1, f1s, n * ts, p1, ts);
   const int head_blocks = (NTOK / 16 + 3) / 4;
-  if (p0) hipLaunchKernelGGL((k_sim_stats<false, true>), dim3(head_blocks, n), dim3(256), 0, st, f0s, f1s, ts, P.rstats, 2LL * NTOK,
-                             nullptr, nullptr, nullptr, p0, p1);
+  const dim3 grid3((NTOK / 16 / kSimRT + kSimWaves - 1) / kSimWaves, n), block3(64 * kSimWaves);
+  if (p0) hipLaunchKernelGGL(k_sim_stats3<false>, grid3, block3, 0, st, p0, p1, ts, P.rstats, 2LL * NTOK, nullptr, nullptr, nullptr);
   else hipLaunchKernelGGL((k_sim_stats<false, false>), dim3(head_blocks, n), dim3(256), 0, st, f0s, f1s, ts, P.rstats, 2LL * NTOK,
                           nullptr, nullptr, nullptr, nullptr, nullptr);
   if (threshold >= kCandMinThreshold && !P.dense_head) {
@@ -4278,6 +4386,7 @@ hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf
     hipMemsetAsync(P.cand_cnt, 0, (size_t)n * sizeof(uint32_t), st);
     hipMemsetAsync(P.mask, 0, (size_t)n * NTOK * MASK_WORDS * sizeof(uint32_t), st);
     hipLaunchKernelGGL(k_row_limits, dim3((n * NTOK + 255) / 256), dim3(256), 0, st, P.rstats, 2LL * NTOK, threshold, P.lim, n);
+    // (the emitting pass stays one row tile per wave: three per wave serialises the candidate appends, 330 -> 381 us)
     if (p0) hipLaunchKernelGGL((k_sim_stats<true, true>), dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats, 2LL * NTOK,
                                P.lim, P.cand, P.cand_cnt, p1, p0);
     else hipLaunchKernelGGL((k_sim_stats<true, false>), dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats, 2LL * NTOK,
@@ -4289,8 +4398,8 @@ hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf
     hipLaunchKernelGGL(k_conf_cand, dim3(8, n), dim3(256), 0, st, P.cand, P.cand_cnt, P.rstats, P.cstats, 2LL * NTOK, threshold,
                        P.mask);
   } else {
-    if (p0) hipLaunchKernelGGL((k_sim_stats<false, true>), dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats,
-                               2LL * NTOK, nullptr, nullptr, nullptr, p1, p0);
+    if (p0) hipLaunchKernelGGL(k_sim_stats3<false>, grid3, block3, 0, st, p1, p0, ts, P.cstats, 2LL * NTOK, nullptr, nullptr,
+                               nullptr);
     else hipLaunchKernelGGL((k_sim_stats<false, false>), dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats,
                             2LL * NTOK, nullptr, nullptr, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(k_conf_mask, dim3(head_blocks, n), dim3(256), 0, st, f0s, f1s, ts, P.rstats, P.cstats, 2LL * NTOK,
