@@ -21,7 +21,7 @@ STAGE = {"k_resize": "pyramid", "k_fast": "fast_nms", "k_fast_tau": "fast_nms", 
          "k_down32x": "backbone_convs",
          "k_attn_kv": "transformer", "k_attn_update": "transformer", "k_attn_kv_x": "transformer",
          "k_attn_update_x": "transformer", "k_scale_feats": "match_head",
-         "k_sim_stats": "match_head", "k_conf_mask": "match_head", "k_decode": "match_head"}
+         "k_sim_stats": "match_head", "k_sim_stats3": "match_head", "k_conf_mask": "match_head", "k_decode": "match_head"}
 
 
 def load(d, steps):
