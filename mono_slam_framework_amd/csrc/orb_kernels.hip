@@ -52,6 +52,13 @@ __device__ __forceinline__ uint32_t udot2_u16(uint32_t a, uint32_t b, uint32_t c
   return __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, b), c, false);
 }
 
+// v_mad_u32_u24: a * b + c on the low 24 bits of a and b (the compiler prefers two multiplies and an add3)
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // ------------------------------------------------------------------ K2: pyramid level l from l-1
 // cv::resize(..., INTER_LINEAR_EXACT) restated: 8.8 fixed-point taps from host tables, 16-bit horizontal sums,
 // 32-bit vertical, (v + 32768) >> 16.  A workgroup makes a band of `rth` (8) full output rows: the source rows it needs
@@ -64,6 +71,11 @@ __device__ __forceinline__ uint32_t udot2_u16(uint32_t a, uint32_t b, uint32_t c
 // once per task of 4 px x 4 rows instead of once per output dword, the per-row work comes from a small LDS table, and
 // task / row decoding uses host-computed reciprocals instead of integer division (25 -> 12 VALU instructions per px).
 constexpr int kResizeMaxRows = 16;     // output rows per band (rth) upper bound
+// SHARED: the taps of output pixels 4g, 4g+1, 4g+2 all lie inside the aligned dword pair that holds the first one's
+// (true for every level of a 1.2x pyramid; the host checks the table and falls back to per-pixel pairs otherwise), so
+// one ds_read2_b32 serves three pixels.  Either way the two tap bytes are cut out of the pair and widened to u16 by
+// ONE v_perm_b32 whose selector is made once per task.
+template <bool SHARED>
 __global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uint8_t* pyr,
                                                 const uint32_t* __restrict__ tab, int l, int rth, int lds_rows,
                                                 uint32_t magic_n16, uint32_t magic_groups) {
@@ -83,8 +95,8 @@ __global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uin
   const int sy0 = ytab[Y0] & 0xFFFF;
   const int nrow = min((int)(ytab[ylast] & 0xFFFF) + 2 - sy0, lds_rows);
   const int n16 = sw16 >> 4, n4 = sw16 >> 2, rows = ylast - Y0 + 1;
-  if (tid < rows) {
-    const uint32_t yt = ytab[Y0 + tid];
+  if (tid < kResizeMaxRows) {       // rows past the band repeat its last row: the unrolled row loop reads valid entries
+    const uint32_t yt = ytab[Y0 + min(tid, rows - 1)];
     const uint32_t wy1 = yt >> 16;
     ysh[2 * tid] = (uint32_t)(((int)(yt & 0xFFFF) - sy0) * n4 * 4);   // LDS byte offset of the upper source row
     ysh[2 * tid + 1] = wy1;                                            // weight of the lower source row
@@ -97,55 +109,55 @@ __global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uin
     reinterpret_cast<uint4*>(rt)[i] = v;
   }
   __syncthreads();
-  const uint32_t* T = reinterpret_cast<const uint32_t*>(rt);
   const int groups = (L.w + 3) >> 2, rgs = (rows + 3) >> 2;
   for (int i = tid; i < rgs * groups; i += nthr) {
     const int rg = magic_groups ? (int)__umulhi((uint32_t)i, magic_groups) : i, gq = i - rg * groups;   // i / groups
     const int x4 = 4 * gq;
     const uint4 xt = *reinterpret_cast<const uint4*>(xtab + x4);   // table is padded to a multiple of 4 entries
     const uint32_t xe[4] = {xt.x, xt.y, xt.z, xt.w};
-    int w0[4];
-    uint32_t shf[4], wxp[4];
+    uint32_t boff[4], sel[4], wxp[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const uint32_t cx = xe[k] & 0xFFFFu, wx1 = xe[k] >> 16;
-      w0[k] = (int)(cx >> 2);
-      shf[k] = cx & 3u;
+      boff[k] = ((SHARED && k < 3) ? xe[0] : cx) & 0xFFFCu;       // byte offset of the aligned dword pair in the staged row
+      // selector: pair bytes (cx - boff, cx - boff + 1) -> u16 lanes 0 and 1, zero bytes in between
+      sel[k] = 0x0c010c00u + (cx - boff[k]) * 0x00010001u;
       wxp[k] = (256u - wx1) | (wx1 << 16);
     }
-    const int ry0 = 4 * rg, ry1 = min(ry0 + 4, rows);
-    const char* Tb = reinterpret_cast<const char*>(T);
+    const int ry0 = 4 * rg;
+    const char* Tb = reinterpret_cast<const char*>(rt);
     const int rowb = 4 * n4;                               // staged row pitch in bytes
     uint8_t* dp = d + (long long)(Y0 + ry0) * L.pitch + x4;
-    uint32_t hlow[4] = {0u, 0u, 0u, 0u};                   // horizontal sums of the previous row's LOWER source row
-    int prev = -0x40000000;
-    for (int ry = ry0; ry < ry1; ry++) {
-      const int rb = (int)ysh[2 * ry];
-      const uint32_t wy1 = ysh[2 * ry + 1], wy0 = 256u - wy1;
+    // the four rows' (LDS offset, weight) pairs in two 16-byte reads
+    const uint4 ya = *reinterpret_cast<const uint4*>(ysh + 2 * ry0), yb = *reinterpret_cast<const uint4*>(ysh + 2 * ry0 + 4);
+    const uint32_t yrb[4] = {ya.x, ya.z, yb.x, yb.z}, ywy[4] = {ya.y, ya.w, yb.y, yb.w};
+    uint32_t hlow[4];                                      // horizontal sums of the previous row's LOWER source row
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const char* pr = Tb + yrb[j];
       // consecutive output rows usually step one source row: the lower row of the previous output row is this row's
       // upper row, its horizontal sums are reused (exactly the same integers)
-      const bool reuse = rb == prev + rowb;
-      prev = rb;
+      if (j == 0 || yrb[j] != yrb[j - 1] + (uint32_t)rowb) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t* pa = reinterpret_cast<const uint32_t*>(pr + boff[k]);             // row sy: p[cx], p[cx+1]
+          // bytes (p0, p1) -> u16 pair, then w0*p0 + w1*p1 in one v_dot2_u32_u16 (<= 255 * 256: fits 16 bits)
+          hlow[k] = udot2_u16(__builtin_amdgcn_perm(pa[1], pa[0], sel[k]), wxp[k], 0u);
+        }
+      }
+      const uint32_t wy1 = ywy[j], wy0 = 256u - wy1;
       uint32_t v[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const uint32_t* pa = reinterpret_cast<const uint32_t*>(Tb + 4 * w0[k] + rb);
-        uint32_t h0 = hlow[k];
-        if (!reuse) {
-          const uint32_t a = __builtin_amdgcn_alignbyte(pa[1], pa[0], shf[k]);               // row sy:   p[cx], p[cx+1]
-          // bytes (p0, p1) -> u16 pair, then w0*p0 + w1*p1 in one v_dot2_u32_u16 (<= 255 * 256: fits 16 bits)
-          h0 = udot2_u16(__builtin_amdgcn_perm(0u, a, 0x0c010c00u), wxp[k], 0u);
-        }
-        const uint32_t* pc = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(pa) + rowb);
-        const uint32_t c = __builtin_amdgcn_alignbyte(pc[1], pc[0], shf[k]);                 // row sy+1
-        const uint32_t h1 = udot2_u16(__builtin_amdgcn_perm(0u, c, 0x0c010c00u), wxp[k], 0u);
-        hlow[k] = h1;
+        const uint32_t* pc = reinterpret_cast<const uint32_t*>(pr + rowb + boff[k]);        // row sy+1
+        const uint32_t h1 = udot2_u16(__builtin_amdgcn_perm(pc[1], pc[0], sel[k]), wxp[k], 0u);
         // weights sum to 256 * 256, so bits 16..23 hold the result (<= 255) without a clamp
-        v[k] = __umul24(h0, wy0) + __umul24(h1, wy1) + 32768u;
+        v[k] = mad_u24(hlow[k], wy0, mad_u24(h1, wy1, 32768u));
+        hlow[k] = h1;
       }
       // byte 2 of each of the four sums -> one dword
       const uint32_t packed = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u) | __builtin_amdgcn_perm(v[3], v[2], 0x06020c0cu);
-      *reinterpret_cast<uint32_t*>(dp) = packed;           // pitch % 16 == 0, pad bytes are never read as pixels
+      if (ry0 + j < rows) *reinterpret_cast<uint32_t*>(dp) = packed;   // pitch % 16 == 0, pad bytes are never read as pixels
       dp += L.pitch;
     }
   }
@@ -1825,6 +1837,13 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     uint32_t* yt = xt + ((L.w + 3) & ~3);
     make_table(g.lv[l - 1].w, L.w, xt);
     make_table(g.lv[l - 1].h, L.h, yt);
+    for (int x = L.w; x < ((L.w + 3) & ~3); x++) xt[x] = xt[L.w - 1];   // pad entries: the last pixel again
+    // k_resize<true> reads pixels 4g .. 4g+2 from the dword pair of pixel 4g: needs tap offset (rel. to that pair) <= 6
+    bool shared = true;
+    for (int x = 0; x < L.w; x += 4)
+      for (int k = 1; k < 3; k++)
+        if ((xt[x + k] & 0xFFFFu) - (xt[x] & 0xFFFCu) > 6u) shared = false;
+    resize_shared_[l] = shared;
   }
   const size_t S = (size_t)max_slots;
   MSF_HIP_TRY(hipMalloc(&d_pyr_, S * g.pyr_bytes));
@@ -1966,8 +1985,9 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
     const int lds_rows = (rth * 5 + 3) / 4 + 3;
     const uint32_t magic_n16 = (uint32_t)(0x100000000ull / (uint32_t)(sw16 >> 4)) + 1u;
     const uint32_t magic_groups = groups > 1 ? (uint32_t)(0x100000000ull / (uint32_t)groups) + 1u : 0u;
-    hipLaunchKernelGGL(k_resize, dim3((L.h + rth - 1) / rth, n), dim3(threads), (size_t)lds_rows * sw16 + 8 * kResizeMaxRows,
-                       st, g, src, d_pyr_, d_tab_, l, rth, lds_rows, magic_n16, magic_groups);
+    hipLaunchKernelGGL(resize_shared_[l] ? k_resize<true> : k_resize<false>, dim3((L.h + rth - 1) / rth, n), dim3(threads),
+                       (size_t)lds_rows * sw16 + 8 * kResizeMaxRows, st, g, src, d_pyr_, d_tab_, l, rth, lds_rows, magic_n16,
+                       magic_groups);
     if (side) {
       hipEventRecord(tau_ev_[l], st);
       hipStreamWaitEvent(tau_stream_, tau_ev_[l], 0);

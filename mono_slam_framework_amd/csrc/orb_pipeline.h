@@ -86,6 +86,7 @@ class OrbPipeline {
   // device storage
   uint8_t* d_pyr_ = nullptr;
   uint32_t* d_tab_ = nullptr;      // resize tables: per output x / y, source offset | w1 << 16
+  bool resize_shared_[kOrbLevels] = {};   // per level: k_resize may read three pixels' taps from one dword pair
   uint32_t* d_cand_cnt_ = nullptr; // [slots][8]
   uint32_t* d_tau_ = nullptr;      // [2][slots][8] FAST score threshold used per (slot, level) | first estimate
   uint32_t* d_redo_ = nullptr;     // [1 + slots * 8] dense-pass queue: count, entries (frame * 8 + level)
