@@ -71,16 +71,18 @@ __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) 
 // once per task of 4 px x 4 rows instead of once per output dword, the per-row work comes from a small LDS table, and
 // task / row decoding uses host-computed reciprocals instead of integer division (25 -> 12 VALU instructions per px).
 constexpr int kResizeMaxRows = 16;     // output rows per band (rth) upper bound
-// SHARED: the taps of output pixels 4g, 4g+1, 4g+2 all lie inside the aligned dword pair that holds the first one's
-// (true for every level of a 1.2x pyramid; the host checks the table and falls back to per-pixel pairs otherwise), so
-// one ds_read2_b32 serves three pixels.  Either way the two tap bytes are cut out of the pair and widened to u16 by
-// ONE v_perm_b32 whose selector is made once per task.
+// Per group of 4 output pixels the host table holds, ready for use: the byte offsets of the aligned dword pairs the taps
+// are read from, the v_perm selectors that cut the two tap bytes out of a pair and widen them to u16 (ONE v_perm_b32
+// instead of alignbyte + perm), and the weight pairs for v_dot2.
+// SHARED: the taps of output pixels 4g, 4g+1, 4g+2 all lie inside the pair that holds the first one's (true for every
+// level of a 1.2x pyramid; the host checks the table and falls back to per-pixel pairs otherwise), so one
+// ds_read2_b32 serves three pixels.
 template <bool SHARED>
 __global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uint8_t* pyr,
                                                 const uint32_t* __restrict__ tab, int l, int rth, int lds_rows,
                                                 uint32_t magic_n16, uint32_t magic_groups) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint32_t* ysh = reinterpret_cast<uint32_t*>(smem);   // [kResizeMaxRows] per output row: LDS word base | wyp-source
+  uint32_t* ysh = reinterpret_cast<uint32_t*>(smem);   // [kResizeMaxRows] per output row: LDS byte offset, weight | reuse flag
   uint8_t* rt = smem + 4 * kResizeMaxRows * 2;
   const int fi = blockIdx.y;
   const OrbLevelInfo L = g.lv[l];
@@ -88,19 +90,33 @@ __global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uin
   int spitch;
   const uint8_t* s = level_ptr(g, src, pyr, fi, l - 1, &spitch);
   uint8_t* d = pyr + (long long)(src.slot0 + fi) * g.pyr_bytes + L.pix_off;
-  const uint32_t* xtab = tab + L.tab_off;      // per x: xofs | w1 << 16
-  const uint32_t* ytab = xtab + ((L.w + 3) & ~3);
+  const int groups = (L.w + 3) >> 2;
+  const uint4* xsel = reinterpret_cast<const uint4*>(tab + L.tab_off);   // [groups] selectors, weight pairs, pair offsets
+  const uint4* xwxp = xsel + groups;
+  const uint4* xoff = xwxp + groups;
+  const uint32_t* ytab = reinterpret_cast<const uint32_t*>(xoff + groups);   // per y: source row | w1 << 16
   const int Y0 = blockIdx.x * rth, tid = threadIdx.x, nthr = blockDim.x;
   const int ylast = min(Y0 + rth, L.h) - 1;
   const int sy0 = ytab[Y0] & 0xFFFF;
   const int nrow = min((int)(ytab[ylast] & 0xFFFF) + 2 - sy0, lds_rows);
   const int n16 = sw16 >> 4, n4 = sw16 >> 2, rows = ylast - Y0 + 1;
+  const int rowb = 4 * n4;                                 // staged row pitch in bytes
   if (tid < kResizeMaxRows) {       // rows past the band repeat its last row: the unrolled row loop reads valid entries
-    const uint32_t yt = ytab[Y0 + min(tid, rows - 1)];
-    const uint32_t wy1 = yt >> 16;
-    ysh[2 * tid] = (uint32_t)(((int)(yt & 0xFFFF) - sy0) * n4 * 4);   // LDS byte offset of the upper source row
-    ysh[2 * tid + 1] = wy1;                                            // weight of the lower source row
+    const int y = Y0 + min(tid, rows - 1);
+    const uint32_t yt = ytab[y];
+    // bit 31: this row's upper source row is the previous output row's lower one (its horizontal sums are reused).
+    // Only the low 24 bits of the weight reach v_mad_u32_u24, also through 256 - w.
+    const uint32_t step1 = (tid > 0 && tid < rows && (yt & 0xFFFF) == (ytab[y - 1] & 0xFFFF) + 1u) ? 0x80000000u : 0u;
+    ysh[2 * tid] = (uint32_t)(((int)(yt & 0xFFFF) - sy0) * rowb);     // LDS byte offset of the upper source row
+    ysh[2 * tid + 1] = (yt >> 16) | step1;                             // weight of the lower source row
   }
+  // a task = 4 output columns x 4 output rows; its table entries are requested one task ahead (the first one before
+  // the band is staged), clamped instead of guarded so the loads are unconditional
+  const int rgs = (rows + 3) >> 2, ntask = rgs * groups;
+  int i = tid;
+  int rg = magic_groups ? (int)__umulhi((uint32_t)min(i, ntask - 1), magic_groups) : min(i, ntask - 1);   // i / groups
+  int gq = min(i, ntask - 1) - rg * groups;
+  uint4 qs = xsel[gq], qw = xwxp[gq], qo = xoff[gq];
   for (int i = tid; i < nrow * n16; i += nthr) {
     const int r = (int)__umulhi((uint32_t)i, magic_n16), c = i - r * n16;   // i / n16 (exact for i < 2^16)
     const int gx = 16 * c, gy = sy0 + r;
@@ -109,24 +125,19 @@ __global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uin
     reinterpret_cast<uint4*>(rt)[i] = v;
   }
   __syncthreads();
-  const int groups = (L.w + 3) >> 2, rgs = (rows + 3) >> 2;
-  for (int i = tid; i < rgs * groups; i += nthr) {
-    const int rg = magic_groups ? (int)__umulhi((uint32_t)i, magic_groups) : i, gq = i - rg * groups;   // i / groups
-    const int x4 = 4 * gq;
-    const uint4 xt = *reinterpret_cast<const uint4*>(xtab + x4);   // table is padded to a multiple of 4 entries
-    const uint32_t xe[4] = {xt.x, xt.y, xt.z, xt.w};
-    uint32_t boff[4], sel[4], wxp[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const uint32_t cx = xe[k] & 0xFFFFu, wx1 = xe[k] >> 16;
-      boff[k] = ((SHARED && k < 3) ? xe[0] : cx) & 0xFFFCu;       // byte offset of the aligned dword pair in the staged row
-      // selector: pair bytes (cx - boff, cx - boff + 1) -> u16 lanes 0 and 1, zero bytes in between
-      sel[k] = 0x0c010c00u + (cx - boff[k]) * 0x00010001u;
-      wxp[k] = (256u - wx1) | (wx1 << 16);
+  for (; i < ntask; i += nthr) {
+    const int x4 = 4 * gq, ry0 = 4 * rg;
+    const uint32_t sel[4] = {qs.x, qs.y, qs.z, qs.w}, wxp[4] = {qw.x, qw.y, qw.z, qw.w};
+    // pair offsets of the LOWER source row, relative to the upper row's LDS offset
+    const uint32_t boff[4] = {qo.x + (uint32_t)rowb, (SHARED ? qo.x : qo.y) + (uint32_t)rowb,
+                              (SHARED ? qo.x : qo.z) + (uint32_t)rowb, qo.w + (uint32_t)rowb};
+    {
+      const int in = min(i + nthr, ntask - 1);
+      rg = magic_groups ? (int)__umulhi((uint32_t)in, magic_groups) : in;
+      gq = in - rg * groups;
+      qs = xsel[gq], qw = xwxp[gq], qo = xoff[gq];
     }
-    const int ry0 = 4 * rg;
     const char* Tb = reinterpret_cast<const char*>(rt);
-    const int rowb = 4 * n4;                               // staged row pitch in bytes
     uint8_t* dp = d + (long long)(Y0 + ry0) * L.pitch + x4;
     // the four rows' (LDS offset, weight) pairs in two 16-byte reads
     const uint4 ya = *reinterpret_cast<const uint4*>(ysh + 2 * ry0), yb = *reinterpret_cast<const uint4*>(ysh + 2 * ry0 + 4);
@@ -137,10 +148,10 @@ __global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uin
       const char* pr = Tb + yrb[j];
       // consecutive output rows usually step one source row: the lower row of the previous output row is this row's
       // upper row, its horizontal sums are reused (exactly the same integers)
-      if (j == 0 || yrb[j] != yrb[j - 1] + (uint32_t)rowb) {
+      if (j == 0 || (int)ywy[j] >= 0) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const uint32_t* pa = reinterpret_cast<const uint32_t*>(pr + boff[k]);             // row sy: p[cx], p[cx+1]
+          const uint32_t* pa = reinterpret_cast<const uint32_t*>(pr + boff[k] - rowb);      // row sy: p[cx], p[cx+1]
           // bytes (p0, p1) -> u16 pair, then w0*p0 + w1*p1 in one v_dot2_u32_u16 (<= 255 * 256: fits 16 bits)
           hlow[k] = udot2_u16(__builtin_amdgcn_perm(pa[1], pa[0], sel[k]), wxp[k], 0u);
         }
@@ -149,7 +160,7 @@ __global__ __launch_bounds__(256) void k_resize(OrbGeometry g, FrameSrc src, uin
       uint32_t v[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const uint32_t* pc = reinterpret_cast<const uint32_t*>(pr + rowb + boff[k]);        // row sy+1
+        const uint32_t* pc = reinterpret_cast<const uint32_t*>(pr + boff[k]);               // row sy+1
         const uint32_t h1 = udot2_u16(__builtin_amdgcn_perm(pc[1], pc[0], sel[k]), wxp[k], 0u);
         // weights sum to 256 * 256, so bits 16..23 hold the result (<= 255) without a clamp
         v[k] = mad_u24(hlow[k], wy0, mad_u24(h1, wy1, 32768u));
@@ -1732,6 +1743,9 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     const int v = atoi(e) & ~1;
     if (v >= kFastT && v <= 254) force_tau_ = v;
   }
+  // MSF_ORB_RESIZE_GENERIC=1: k_resize reads every pixel's taps from its own dword pair (the fallback for level
+  // geometries whose column table fails the shared-pair check; tests compare the two)
+  if (const char* e = getenv("MSF_ORB_RESIZE_GENERIC")) resize_generic_ = atoi(e) != 0;
   OrbGeometry& g = g_;
   g.nlevels = kOrbLevels;
   g.w0 = width;
@@ -1822,7 +1836,7 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
       if (L.samp_cols == 0) L.samp_rows = 0;
     }
     L.tab_off = tab;
-    if (l > 0) tab += ((L.w + 3) & ~3) + ((L.h + 3) & ~3);
+    if (l > 0) tab += 12 * ((L.w + 3) >> 2) + ((L.h + 3) & ~3);   // 3 x uint4 per group of 4 columns, one dword per row
   }
   g.pyr_bytes = (pix + 255) & ~255ll;
   g.cand_total = cand;
@@ -1833,17 +1847,27 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   std::vector<uint32_t> htab(tab > 0 ? tab : 1, 0u);
   for (int l = 1; l < g.nlevels; l++) {
     const OrbLevelInfo& L = g.lv[l];
-    uint32_t* xt = htab.data() + L.tab_off;
-    uint32_t* yt = xt + ((L.w + 3) & ~3);
-    make_table(g.lv[l - 1].w, L.w, xt);
-    make_table(g.lv[l - 1].h, L.h, yt);
-    for (int x = L.w; x < ((L.w + 3) & ~3); x++) xt[x] = xt[L.w - 1];   // pad entries: the last pixel again
+    const int groups = (L.w + 3) >> 2;
+    std::vector<uint32_t> xt(4 * groups);
+    make_table(g.lv[l - 1].w, L.w, xt.data());
+    for (int x = L.w; x < 4 * groups; x++) xt[x] = xt[L.w - 1];   // pad entries: the last pixel again
     // k_resize<true> reads pixels 4g .. 4g+2 from the dword pair of pixel 4g: needs tap offset (rel. to that pair) <= 6
-    bool shared = true;
-    for (int x = 0; x < L.w; x += 4)
+    bool shared = !resize_generic_;
+    for (int x = 0; x < 4 * groups; x += 4)
       for (int k = 1; k < 3; k++)
         if ((xt[x + k] & 0xFFFFu) - (xt[x] & 0xFFFCu) > 6u) shared = false;
     resize_shared_[l] = shared;
+    uint32_t* xsel = htab.data() + L.tab_off;
+    uint32_t* xwxp = xsel + 4 * groups;
+    uint32_t* xoff = xwxp + 4 * groups;
+    for (int x = 0; x < 4 * groups; x++) {
+      const uint32_t cx = xt[x] & 0xFFFFu, wx1 = xt[x] >> 16;
+      const uint32_t base = ((shared && (x & 3) < 3) ? xt[x & ~3] : cx) & 0xFFFCu;   // byte offset of the aligned dword pair
+      xoff[x] = base;
+      xsel[x] = 0x0c010c00u + (cx - base) * 0x00010001u;   // pair bytes (cx - base, cx - base + 1) -> u16 lanes, zeros between
+      xwxp[x] = (256u - wx1) | (wx1 << 16);
+    }
+    make_table(g.lv[l - 1].h, L.h, xoff + 4 * groups);
   }
   const size_t S = (size_t)max_slots;
   MSF_HIP_TRY(hipMalloc(&d_pyr_, S * g.pyr_bytes));
@@ -1975,6 +1999,7 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
   for (int l = 1; l < g.nlevels; l++) {
     const OrbLevelInfo& L = g.lv[l];
     // band height: 8 output rows x 256 threads measured best (rth 4: 3.26 ms, 8: 2.71, 12: 2.77, 16: 2.74 per 2048
+    // [r02, table-driven kernel: 12 or 16 rows on the small levels only: 2.65 vs 2.65-2.73, within run-to-run noise]
     // 720p frames; workgroup sizes chosen to fill whole passes of 4 px x 4 row tasks -- 320..512 threads -- were
     // slower, 2.99: more, smaller workgroups hide the stage-then-compute latency better than full lanes do)
     const int sw16 = (g.lv[l - 1].w + 16 + 15) & ~15;

@@ -85,8 +85,9 @@ class OrbPipeline {
   int force_tau_ = 0;              // > 0: every (frame, level) starts at this FAST score threshold (20 = dense)
   // device storage
   uint8_t* d_pyr_ = nullptr;
-  uint32_t* d_tab_ = nullptr;      // resize tables: per output x / y, source offset | w1 << 16
+  uint32_t* d_tab_ = nullptr;      // resize tables per level: per group of 4 columns selectors / weights / pair offsets, per row source row | w1 << 16
   bool resize_shared_[kOrbLevels] = {};   // per level: k_resize may read three pixels' taps from one dword pair
+  bool resize_generic_ = false;           // MSF_ORB_RESIZE_GENERIC: never
   uint32_t* d_cand_cnt_ = nullptr; // [slots][8]
   uint32_t* d_tau_ = nullptr;      // [2][slots][8] FAST score threshold used per (slot, level) | first estimate
   uint32_t* d_redo_ = nullptr;     // [1 + slots * 8] dense-pass queue: count, entries (frame * 8 + level)

@@ -409,6 +409,25 @@ def test_full_size_batch_properties():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("w,h", [(640, 480), (333, 251), (1280, 720)])
+def test_resize_fallback_equals_shared_pair_kernel(monkeypatch, w, h):
+    """k_resize<true> reads the taps of three output pixels from one dword pair (valid when the host's check of the
+    column table passes, as for every 1.2x level); MSF_ORB_RESIZE_GENERIC=1 forces the per-pixel fallback.  Both must
+    give the oracle's pyramid, on sizes whose level widths are and are not multiples of 4."""
+    a, b = synth.synth_pair(77, w, h, mode=0)
+    orc = oracle_orb.FeatureMatcherOracle(0.8)
+    orc.MatchFrames(a, b)
+    oa, _ = orc._orb(a.shape)
+    for generic in ("0", "1"):
+        monkeypatch.setenv("MSF_ORB_RESIZE_GENERIC", generic)
+        fm = _matcher(w, h)
+        fm.MatchFrames(a, b)
+        for l in range(1, 8):
+            np.testing.assert_array_equal(fm.level_pixels(0, l), oa.level_pixels(l), err_msg="generic=%s L%d" % (generic, l))
+        fm.close()
+
+
+@pytest.mark.gpu
 def test_split_extraction_equals_single_pass(monkeypatch):
     """Opt-in MSF_ORB_SPLIT2=2: batches of >= 256 frames are extracted as two pipelined sub-batches on two streams
     (OrbPipeline::extract).  Same frames, same slots: identical match lists to the one-pass default, and the stage
