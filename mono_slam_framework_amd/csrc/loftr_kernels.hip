@@ -3500,42 +3500,56 @@ __global__ __launch_bounds__(256) void k_conf_cand(const SimCand* __restrict__ c
   }
 }
 
-// findNonZero row-major + decode (dnnfeaturematcher.cpp:80-99): one workgroup per pair scans the bit mask in order.
-__global__ __launch_bounds__(256) void k_decode(const uint32_t* __restrict__ mask, msf_match* __restrict__ out, int cap,
-                                                int32_t* __restrict__ n_out) {
-  __shared__ uint32_t wsum[4];
-  __shared__ uint32_t running;
+// findNonZero row-major + decode (dnnfeaturematcher.cpp:80-99): one workgroup per pair.  Every thread owns a contiguous
+// run of kDecPer mask words and requests all of them at once (one memory round trip for the 182 KB mask instead of a
+// load + barrier per 4 KB chunk: 57 -> 8 us for a single pair, where the kernel is pure latency); one scan of the
+// per-thread bit counts gives each thread its position in the row-major output.
+constexpr int kDecThreads = 1024;
+constexpr int kDecPer = ((NTOK * MASK_WORDS + kDecThreads - 1) / kDecThreads + 3) & ~3;   // words per thread, whole uint4s
+static_assert((NTOK * MASK_WORDS) % 4 == 0, "mask is read four words at a time");
+__global__ __launch_bounds__(kDecThreads) void k_decode(const uint32_t* __restrict__ mask, msf_match* __restrict__ out, int cap,
+                                                        int32_t* __restrict__ n_out) {
+  __shared__ uint32_t wsum[kDecThreads / 64];
   const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t* mk = mask + (long long)pair * NTOK * MASK_WORDS;
   msf_match* o = out + (long long)pair * cap;
-  if (tid == 0) running = 0;
-  __syncthreads();
   constexpr int total = NTOK * MASK_WORDS;
-  static_assert(total % 4 == 0, "mask rows are read four words at a time");
-  for (int w0 = 0; w0 < total; w0 += 4 * 256) {
-    const int w = w0 + 4 * tid;
-    uint4 b4 = make_uint4(0u, 0u, 0u, 0u);
-    if (w < total) b4 = *reinterpret_cast<const uint4*>(mk + w);
-    const uint32_t wb[4] = {b4.x, b4.y, b4.z, b4.w};
-    const uint32_t c = __popc(wb[0]) + __popc(wb[1]) + __popc(wb[2]) + __popc(wb[3]);
-    if (!__syncthreads_or(c != 0u)) continue;      // almost every 1024-word chunk of the mask is empty
-    // inclusive scan inside the wave
-    uint32_t s = c;
+  const int w_begin = tid * kDecPer;
+  uint4 b[kDecPer / 4];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t v = __shfl_up(s, d);
-      if (lane >= d) s += v;
-    }
-    if (lane == 63) wsum[wave] = s;
-    __syncthreads();
-    uint32_t base = running;
-    for (int k = 0; k < wave; k++) base += wsum[k];
-    uint32_t pos = base + s - c;
+  for (int q = 0; q < kDecPer / 4; q++) {
+    const int w = w_begin + 4 * q;
+    b[q] = w < total ? *reinterpret_cast<const uint4*>(mk + w) : make_uint4(0u, 0u, 0u, 0u);
+  }
+  uint32_t c = 0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      uint32_t bb = wb[q];
+  for (int q = 0; q < kDecPer / 4; q++) c += __popc(b[q].x) + __popc(b[q].y) + __popc(b[q].z) + __popc(b[q].w);
+  uint32_t s = c;                                  // inclusive scan inside the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t v = __shfl_up(s, d);
+    if (lane >= d) s += v;
+  }
+  if (lane == 63) wsum[wave] = s;
+  __syncthreads();
+  uint32_t base = 0, all = 0;
+#pragma unroll
+  for (int k = 0; k < kDecThreads / 64; k++) {
+    const uint32_t v = wsum[k];
+    all += v;
+    if (k < wave) base += v;
+  }
+  if (tid == 0) n_out[pair] = (int32_t)all;
+  if (c == 0) return;
+  uint32_t pos = base + s - c;
+#pragma unroll
+  for (int q = 0; q < kDecPer / 4; q++) {
+    const uint32_t wb[4] = {b[q].x, b[q].y, b[q].z, b[q].w};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      uint32_t bb = wb[r];
       if (!bb) continue;
-      const int ww = w + q;
+      const int ww = w_begin + 4 * q + r;
       const int i = ww / MASK_WORDS, jw = (ww % MASK_WORDS) * 32;
       while (bb) {
         const int bit = __ffs(bb) - 1;
@@ -3550,11 +3564,7 @@ __global__ __launch_bounds__(256) void k_decode(const uint32_t* __restrict__ mas
         pos++;
       }
     }
-    __syncthreads();
-    if (tid == 0) running += wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    __syncthreads();
   }
-  if (tid == 0) n_out[pair] = (int32_t)running;
 }
 
 // ================================================================== host side
@@ -4378,7 +4388,11 @@ hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf
   hipLaunchKernelGGL(k_scale_feats, dim3((unsigned)((n * ts + 255) / 256)), dim3(256), 0, st, f1, f1s, n * ts, p1, ts);
   const int head_blocks = (NTOK / 16 + 3) / 4;
   const dim3 grid3((NTOK / 16 / kSimRT + kSimWaves - 1) / kSimWaves, n), block3(64 * kSimWaves);
-  if (p0) hipLaunchKernelGGL(k_sim_stats3<false>, grid3, block3, 0, st, p0, p1, ts, P.rstats, 2LL * NTOK, nullptr, nullptr, nullptr);
+  // a call of a few pairs is latency-bound: one row tile per wave (75 waves per pair) instead of three (25)
+  const bool few = n < 8;
+  if (p0 && !few) hipLaunchKernelGGL(k_sim_stats3<false>, grid3, block3, 0, st, p0, p1, ts, P.rstats, 2LL * NTOK, nullptr, nullptr, nullptr);
+  else if (p0) hipLaunchKernelGGL((k_sim_stats<false, true>), dim3(head_blocks, n), dim3(256), 0, st, f0s, f1s, ts, P.rstats, 2LL * NTOK,
+                                  nullptr, nullptr, nullptr, p0, p1);
   else hipLaunchKernelGGL((k_sim_stats<false, false>), dim3(head_blocks, n), dim3(256), 0, st, f0s, f1s, ts, P.rstats, 2LL * NTOK,
                           nullptr, nullptr, nullptr, nullptr, nullptr);
   if (threshold >= kCandMinThreshold && !P.dense_head) {
@@ -4398,14 +4412,16 @@ hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf
     hipLaunchKernelGGL(k_conf_cand, dim3(8, n), dim3(256), 0, st, P.cand, P.cand_cnt, P.rstats, P.cstats, 2LL * NTOK, threshold,
                        P.mask);
   } else {
-    if (p0) hipLaunchKernelGGL(k_sim_stats3<false>, grid3, block3, 0, st, p1, p0, ts, P.cstats, 2LL * NTOK, nullptr, nullptr,
-                               nullptr);
+    if (p0 && !few) hipLaunchKernelGGL(k_sim_stats3<false>, grid3, block3, 0, st, p1, p0, ts, P.cstats, 2LL * NTOK, nullptr, nullptr,
+                                       nullptr);
+    else if (p0) hipLaunchKernelGGL((k_sim_stats<false, true>), dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats,
+                                    2LL * NTOK, nullptr, nullptr, nullptr, p1, p0);
     else hipLaunchKernelGGL((k_sim_stats<false, false>), dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats,
                             2LL * NTOK, nullptr, nullptr, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(k_conf_mask, dim3(head_blocks, n), dim3(256), 0, st, f0s, f1s, ts, P.rstats, P.cstats, 2LL * NTOK,
                        threshold, P.mask, P.keep_debug ? P.conf_dbg : nullptr, 0);
   }
-  hipLaunchKernelGGL(k_decode, dim3(n), dim3(256), 0, st, P.mask, d_out, cap, d_n_out);
+  hipLaunchKernelGGL(k_decode, dim3(n), dim3(kDecThreads), 0, st, P.mask, d_out, cap, d_n_out);
   if (P.keep_debug) {
     hipMemcpyAsync(P.feat_dbg, f0, ts * sizeof(float), hipMemcpyDeviceToDevice, st);
     hipMemcpyAsync(P.feat_dbg + ts, f1, ts * sizeof(float), hipMemcpyDeviceToDevice, st);
