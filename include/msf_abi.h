@@ -215,6 +215,29 @@ int msf_render_match_image(msf_handle* h, const msf_image* f1, const msf_image* 
 int msf_pack_matches_device(msf_handle* h, int32_t n_pairs, const msf_match* d_in, int32_t cap_per_pair,
                             const int32_t* d_n_out, msf_match* d_packed, int32_t* d_offsets, void* stream);
 
+/* -------- multi-device sharding of the batched call --------
+ * The reference owns one matcher and calls it from one thread (src/main.cpp:65,78-82; System.cc:63-75): it has no
+ * multi-GPU form.  Pairs are independent units, so a batch shards with no exchange step: msf_multi holds one msf_handle
+ * per entry of device_ids (NULL = devices 0 .. n_devices-1; an id may repeat: two shards then share a card) and
+ * msf_multi_match_batch gives shard r the contiguous block of ceil(n_pairs / G) pairs msf_multi_shard_range reports --
+ * the partition of bench.py's ranks -- on one host thread per shard; every shard writes its block of out / n_out, which
+ * therefore come back in pair order, exactly as from msf_match_batch on one handle with the same cfg.
+ * Returns MSF_OK, MSF_ERR_CAPACITY if that is the only failure of any shard, else the first hard error
+ * (msf_multi_last_error names the shard).  msf_multi_handle: the shard's own handle, for callers that keep frames
+ * resident per device and drive the *_device entry points themselves (one host thread per device); owned by the
+ * msf_multi.  A multi-PROCESS job (one rank per GPU, as bench.py --gpus N) needs none of this: each rank creates an
+ * ordinary handle and the match lists are gathered with msf_pack_matches_device + send/recv. */
+typedef struct msf_multi msf_multi;
+int msf_multi_create(const msf_config* cfg, int32_t n_devices, const int32_t* device_ids, msf_multi** out);
+void msf_multi_destroy(msf_multi* m);
+int32_t msf_multi_device_count(const msf_multi* m);
+msf_handle* msf_multi_handle(msf_multi* m, int32_t shard);
+int msf_multi_set_threshold(msf_multi* m, float value);
+const char* msf_multi_last_error(const msf_multi* m); /* m may be NULL: error of the last failed msf_multi_create */
+void msf_multi_shard_range(int32_t n_pairs, int32_t n_shards, int32_t shard, int32_t* first, int32_t* count);
+int msf_multi_match_batch(msf_multi* m, int32_t n_pairs, const msf_image* a, const msf_image* b, msf_match* out,
+                          int32_t cap_per_pair, int32_t* n_out);
+
 /* -------- introspection used by the parity tests and bench.py (not by the drop-in path) -------- */
 typedef enum msf_debug_what {
   MSF_DBG_LEVEL_SIZES = 0,   /* int32 [nlevels][4] = w, h, row pitch, quota */

@@ -35,7 +35,9 @@ ABI_SYMBOLS = ["msf_abi_version", "msf_default_config", "msf_create", "msf_destr
                "msf_stage_times", "msf_set_mappoints", "msf_count_mappoint_matches_device",
                "msf_store_frame", "msf_match_one_to_many", "msf_check_hypotheses",
                "msf_render_match_image", "msf_weights_info", "msf_convert_weights",
-               "msf_frame_cache_stats"]
+               "msf_frame_cache_stats", "msf_multi_create", "msf_multi_destroy", "msf_multi_device_count",
+               "msf_multi_handle", "msf_multi_set_threshold", "msf_multi_last_error", "msf_multi_shard_range",
+               "msf_multi_match_batch"]
 
 
 class Config(C.Structure):
@@ -93,6 +95,19 @@ def load():
     L.msf_convert_weights.argtypes = [C.c_char_p, C.c_char_p]
     L.msf_frame_cache_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(i32)]
     L.msf_stage_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(f32), i32]
+    L.msf_multi_create.argtypes = [C.POINTER(Config), i32, C.POINTER(i32), C.POINTER(vp)]
+    L.msf_multi_destroy.argtypes = [vp]
+    L.msf_multi_destroy.restype = None
+    L.msf_multi_device_count.argtypes = [vp]
+    L.msf_multi_device_count.restype = i32
+    L.msf_multi_handle.argtypes = [vp, i32]
+    L.msf_multi_handle.restype = vp
+    L.msf_multi_set_threshold.argtypes = [vp, f32]
+    L.msf_multi_last_error.argtypes = [vp]
+    L.msf_multi_last_error.restype = C.c_char_p
+    L.msf_multi_shard_range.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.msf_multi_shard_range.restype = None
+    L.msf_multi_match_batch.argtypes = [vp, i32, C.POINTER(Image), C.POINTER(Image), vp, i32, vp]
     _lib = L
     return L
 

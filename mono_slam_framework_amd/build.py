@@ -9,7 +9,7 @@ LIB = os.path.join(_HERE, "libmsf.so")
 SYNTH = os.path.join(_HERE, "libmsf_synth.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-HIP_SOURCES = ["msf_abi.cpp", "weights_io.cpp", "orb_kernels.hip", "loftr_kernels.hip", "pack_kernels.hip",
+HIP_SOURCES = ["msf_abi.cpp", "msf_multi.cpp", "weights_io.cpp", "orb_kernels.hip", "loftr_kernels.hip", "pack_kernels.hip",
                "ransac_kernels.hip"]
 # -ffp-contract=off + correctly rounded f32 divide: the few f32 steps inside ORB
 # (Harris response, fastAtan2, pattern rotation) must round exactly like the CPU.

@@ -1,0 +1,155 @@
+// Multi-device sharding of the batched MatchFrames call (include/msf_abi.h, section "multi-device").
+// Built on the public single-device entry points only: one msf_handle per shard, one host thread per shard for the
+// duration of a call.  Pairs are independent units, so there is no exchange step: every shard
+// writes its block of the caller's output arrays.
+#include "msf_abi.h"
+
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+struct msf_multi {
+  std::vector<msf_handle*> shard;
+  std::vector<int32_t> device;
+  std::mutex mu;
+  std::string err;
+};
+
+namespace {
+thread_local std::string g_multi_create_error;
+
+int mfail(msf_multi* m, int code, const std::string& msg) {
+  if (m) m->err = msg; else g_multi_create_error = msg;
+  return code;
+}
+
+int mexception(msf_multi* m, const char* where) noexcept {
+  try {
+    mfail(m, MSF_ERR_HIP, std::string(where) + ": host exception (out of memory, or no thread could be started)");
+  } catch (...) {
+  }
+  return MSF_ERR_HIP;
+}
+
+void destroy_shards(msf_multi* m) {
+  for (msf_handle* h : m->shard)
+    if (h) msf_destroy(h);
+  m->shard.clear();
+}
+}  // namespace
+
+extern "C" {
+
+int msf_multi_create(const msf_config* cfg, int32_t n_devices, const int32_t* device_ids, msf_multi** out) {
+  if (out) *out = nullptr;
+  try {
+    if (!cfg || !out || n_devices < 1 || n_devices > 64)
+      return mfail(nullptr, MSF_ERR_INVALID_ARG, "msf_multi_create: bad argument (1 <= n_devices <= 64)");
+    msf_multi* m = new msf_multi();
+    for (int i = 0; i < n_devices; i++) {
+      msf_config c = *cfg;
+      c.device = device_ids ? device_ids[i] : i;
+      msf_handle* h = nullptr;
+      const int rc = msf_create(&c, &h);
+      if (rc != MSF_OK) {
+        const char* e = msf_last_error(nullptr);
+        const std::string msg = "msf_multi_create: device " + std::to_string(c.device) + ": " + (e ? e : "msf_create failed");
+        destroy_shards(m);
+        delete m;
+        return mfail(nullptr, rc, msg);
+      }
+      m->shard.push_back(h);
+      m->device.push_back(c.device);
+    }
+    *out = m;
+    return MSF_OK;
+  } catch (...) {
+    return mexception(nullptr, "msf_multi_create");
+  }
+}
+
+void msf_multi_destroy(msf_multi* m) {
+  if (!m) return;
+  destroy_shards(m);
+  delete m;
+}
+
+int32_t msf_multi_device_count(const msf_multi* m) { return m ? (int32_t)m->shard.size() : 0; }
+
+msf_handle* msf_multi_handle(msf_multi* m, int32_t shard) {
+  return (m && shard >= 0 && shard < (int32_t)m->shard.size()) ? m->shard[shard] : nullptr;
+}
+
+const char* msf_multi_last_error(const msf_multi* m) { return m ? m->err.c_str() : g_multi_create_error.c_str(); }
+
+int msf_multi_set_threshold(msf_multi* m, float value) {
+  try {
+    if (!m) return MSF_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(m->mu);
+    for (size_t i = 0; i < m->shard.size(); i++) {
+      const int rc = msf_set_threshold(m->shard[i], value);
+      if (rc != MSF_OK) return mfail(m, rc, std::string("msf_multi_set_threshold: ") + msf_last_error(m->shard[i]));
+    }
+    return MSF_OK;
+  } catch (...) {
+    return mexception(m, "msf_multi_set_threshold");
+  }
+}
+
+void msf_multi_shard_range(int32_t n_pairs, int32_t n_shards, int32_t shard, int32_t* first, int32_t* count) {
+  // contiguous blocks of ceil(n / G) pairs: the partition of gather.shard_pairs and bench.py
+  int32_t f = 0, c = 0;
+  if (n_pairs > 0 && n_shards > 0 && shard >= 0 && shard < n_shards) {
+    const int64_t per = ((int64_t)n_pairs + n_shards - 1) / n_shards;
+    const int64_t lo = per * shard < n_pairs ? per * shard : n_pairs;
+    const int64_t hi = per * (shard + 1) < n_pairs ? per * (shard + 1) : n_pairs;
+    f = (int32_t)lo;
+    c = (int32_t)(hi - lo);
+  }
+  if (first) *first = f;
+  if (count) *count = c;
+}
+
+int msf_multi_match_batch(msf_multi* m, int32_t n_pairs, const msf_image* a, const msf_image* b, msf_match* out,
+                          int32_t cap_per_pair, int32_t* n_out) {
+  try {
+    if (!m) return MSF_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (n_pairs < 0 || !a || !b || !out || !n_out || cap_per_pair < 1)
+      return mfail(m, MSF_ERR_INVALID_ARG, "msf_multi_match_batch: bad argument");
+    const int G = (int)m->shard.size();
+    std::vector<int> rc(G, MSF_OK);
+    auto run = [&](int r) {
+      int32_t first = 0, count = 0;
+      msf_multi_shard_range(n_pairs, G, r, &first, &count);
+      if (count > 0)
+        rc[r] = msf_match_batch(m->shard[r], count, a + first, b + first, out + (size_t)first * cap_per_pair, cap_per_pair,
+                                n_out + first);
+    };
+    {
+      // shard 0 runs on the calling thread; a thread that cannot be started must not leave earlier ones unjoined
+      struct Joiner {
+        std::vector<std::thread> t;
+        ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); }
+      } workers;
+      for (int r = 1; r < G; r++) workers.t.emplace_back(run, r);
+      run(0);
+    }
+    int result = MSF_OK;
+    for (int r = 0; r < G; r++) {
+      if (rc[r] == MSF_OK) continue;
+      // a hard error wins over MSF_ERR_CAPACITY (every list is still complete up to its capacity then)
+      if (result == MSF_OK || (result == MSF_ERR_CAPACITY && rc[r] != MSF_ERR_CAPACITY)) {
+        result = rc[r];
+        const char* e = msf_last_error(m->shard[r]);
+        m->err = "shard " + std::to_string(r) + " (device " + std::to_string(m->device[r]) + "): " + (e ? e : "error");
+      }
+    }
+    return result;
+  } catch (...) {
+    return mexception(m, "msf_multi_match_batch");
+  }
+}
+
+}  // extern "C"

@@ -274,3 +274,64 @@ class DNNFeatureMatcher(_Matcher):
         """NCHW activation of the first frame of the last call after ResNet stage `stage` + 1 (MSF_FLAG_KEEP_DEBUG)"""
         shape = [(8, 240, 320), (16, 120, 160), (32, 60, 80), (32, 30, 40)][stage]
         return self._debug(_lib.DBG_LOFTR_ACT, 0, stage, np.float32, int(np.prod(shape)) * 4).reshape(shape)
+
+
+class MultiDeviceMatcher:
+    """One matcher over several GPUs of one process (msf_multi_*, include/msf_abi.h): a batch is cut into contiguous
+    blocks of ceil(n / G) pairs, one per device, each run by that device's own handle on its own host thread; the lists
+    come back in pair order, identical to one handle's.  `devices` may name a device twice (two shards share the card).
+    kind: "orb" (::FeatureMatcher) or "loftr" (::DNNFeatureMatcher).  The reference has no multi-GPU form; a
+    multi-process job (bench.py --gpus N) uses ordinary matchers, one per rank."""
+
+    def __init__(self, kind, threshold, image_width, image_height, devices=(0,), max_batch_pairs=1, flags=0,
+                 weights_path=None):
+        self._L = _lib.load()
+        self._m = C.c_void_p()
+        cfg = _lib.Config()
+        self._L.msf_default_config(C.byref(cfg), {"orb": _lib.MSF_KIND_ORB, "loftr": _lib.MSF_KIND_LOFTR}[kind])
+        cfg.threshold = threshold
+        cfg.image_width = image_width
+        cfg.image_height = image_height
+        cfg.max_batch_pairs = max_batch_pairs
+        cfg.flags = flags
+        self._wpath = weights_path.encode() if weights_path else None
+        cfg.weights_path = self._wpath
+        ids = (C.c_int32 * len(devices))(*devices)
+        rc = self._L.msf_multi_create(C.byref(cfg), len(devices), ids, C.byref(self._m))
+        if rc != _lib.MSF_OK:
+            msg = self._L.msf_multi_last_error(None).decode()
+            self._m = C.c_void_p()
+            raise MsfError(rc, msg)
+        self.devices = tuple(devices)
+
+    def close(self):
+        if getattr(self, "_m", None) and self._m.value:
+            self._L.msf_multi_destroy(self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != _lib.MSF_OK:
+            raise MsfError(rc, self._L.msf_multi_last_error(self._m).decode())
+
+    def SetThreshold(self, value):
+        self._check(self._L.msf_multi_set_threshold(self._m, float(value)))
+
+    def shard_range(self, n_pairs, shard):
+        first, count = C.c_int32(0), C.c_int32(0)
+        self._L.msf_multi_shard_range(n_pairs, len(self.devices), shard, C.byref(first), C.byref(count))
+        return first.value, count.value
+
+    def match_batch(self, frames1, frames2, cap=4096):
+        n = len(frames1)
+        A = (_lib.Image * max(n, 1))(*[_Matcher._image(f) for f in frames1])
+        B = (_lib.Image * max(n, 1))(*[_Matcher._image(f) for f in frames2])
+        out = np.zeros((max(n, 1), cap), _lib.MATCH_DTYPE)
+        cnt = np.zeros((max(n, 1),), np.int32)
+        self._check(self._L.msf_multi_match_batch(self._m, n, A, B, out.ctypes.data, cap, cnt.ctypes.data))
+        return [out[i, :min(cnt[i], cap)].view(np.int32).reshape(-1, 4).copy() for i in range(n)]

@@ -1,0 +1,99 @@
+"""Multi-device sharder of the C ABI (msf_multi_*, include/msf_abi.h): the partition on CPU, and on
+the GPU box two / three shards sharing cuda:0 against one ordinary handle on the same inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from mono_slam_framework_amd import _lib, synth
+
+
+def test_shard_range_is_the_bench_partition():
+    from mono_slam_framework_amd.gather import shard_pairs
+    L = _lib.load()
+    first, count = C.c_int32(-1), C.c_int32(-1)
+    for n in (0, 1, 2, 7, 37, 256, 1024, 1025):
+        for g in (1, 2, 3, 4, 8):
+            covered = []
+            for r in range(g):
+                L.msf_multi_shard_range(n, g, r, C.byref(first), C.byref(count))
+                own = shard_pairs(n, r, g)
+                assert count.value == len(own) and (not own or first.value == own[0]), (n, g, r)
+                covered += list(range(first.value, first.value + count.value))
+            assert covered == list(range(n))
+    L.msf_multi_shard_range(10, 2, 5, C.byref(first), C.byref(count))     # shard out of range: empty
+    assert (first.value, count.value) == (0, 0)
+
+
+def test_create_rejects_bad_arguments_and_null_handles_are_inert():
+    L = _lib.load()
+    m = C.c_void_p()
+    cfg = _lib.Config()
+    L.msf_default_config(C.byref(cfg), _lib.MSF_KIND_ORB)
+    assert L.msf_multi_create(None, 1, None, C.byref(m)) == _lib.MSF_ERR_INVALID_ARG
+    assert L.msf_multi_create(C.byref(cfg), 0, None, C.byref(m)) == _lib.MSF_ERR_INVALID_ARG
+    assert b"n_devices" in L.msf_multi_last_error(None)
+    assert not m.value
+    assert L.msf_multi_device_count(None) == 0 and not L.msf_multi_handle(None, 0)
+    assert L.msf_multi_match_batch(None, 0, None, None, None, 1, None) == _lib.MSF_ERR_INVALID_ARG
+    L.msf_multi_destroy(None)
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from mono_slam_framework_amd.matcher import MsfError, MultiDeviceMatcher
+    with pytest.raises(MsfError) as e:
+        MultiDeviceMatcher("orb", 0.8, 640, 480, devices=(0, 1))
+    assert e.value.code == -2 and "device 0" in str(e.value)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 2, 37])
+def test_orb_two_shards_equal_one_handle(n):
+    from mono_slam_framework_amd.matcher import FeatureMatcher, MultiDeviceMatcher
+    w, h = 320, 240
+    A, B = synth.synth_batch(4200, max(n, 1), w, h, mode=0)
+    A, B = list(A)[:n], list(B)[:n]
+    one = FeatureMatcher(0.7, w, h, max_batch_pairs=8, flags=_lib.MSF_FLAG_NO_FRAME_CACHE)   # 37 pairs: five chunks of <= 8
+    ref = one.match_batch(A, B, cap=1024) if n else []
+    multi = MultiDeviceMatcher("orb", 0.7, w, h, devices=(0, 0), max_batch_pairs=8, flags=_lib.MSF_FLAG_NO_FRAME_CACHE)
+    assert [multi.shard_range(n, r)[1] for r in range(2)] == [(n + 1) // 2, n // 2]
+    got = multi.match_batch(A, B, cap=1024)
+    assert len(got) == n
+    for r, g in zip(ref, got):
+        np.testing.assert_array_equal(r, g)
+    if n:
+        assert sum(len(g) for g in got) > 10 * n
+    multi.SetThreshold(0.5)
+    one.SetThreshold(0.5)
+    for r, g in zip(one.match_batch(A, B, cap=1024) if n else [], multi.match_batch(A, B, cap=1024)):
+        np.testing.assert_array_equal(r, g)
+
+
+@pytest.mark.gpu
+def test_loftr_three_shards_equal_one_handle():
+    from mono_slam_framework_amd.matcher import DNNFeatureMatcher, MultiDeviceMatcher
+    A, B = synth.synth_batch(4300, 5, 640, 480, mode=1)
+    one = DNNFeatureMatcher(None, 0.15, 640, 480, max_batch_pairs=2, flags=_lib.MSF_FLAG_NO_FRAME_CACHE)
+    ref = one.match_batch(list(A), list(B), cap=4096)
+    multi = MultiDeviceMatcher("loftr", 0.15, 640, 480, devices=(0, 0, 0), max_batch_pairs=2, flags=_lib.MSF_FLAG_NO_FRAME_CACHE)
+    got = multi.match_batch(list(A), list(B), cap=4096)
+    assert sum(len(g) for g in got) > 0
+    for r, g in zip(ref, got):
+        np.testing.assert_array_equal(r, g)
+
+
+@pytest.mark.gpu
+def test_shard_errors_name_the_shard():
+    from mono_slam_framework_amd.matcher import MsfError, MultiDeviceMatcher
+    multi = MultiDeviceMatcher("orb", 0.7, 320, 240, devices=(0, 0), max_batch_pairs=4)
+    good = np.zeros((240, 320), np.uint8)
+    bad = np.zeros((200, 320), np.uint8)
+    with pytest.raises(MsfError) as e:
+        multi.match_batch([good, good, good, bad], [good] * 4)       # pair 3 belongs to shard 1
+    assert e.value.code == _lib.MSF_ERR_INVALID_ARG and "shard 1 (device 0)" in str(e.value)
+    with pytest.raises(MsfError) as e:
+        MultiDeviceMatcher("orb", 0.7, 320, 240, devices=(0, 99))
+    assert "device 99" in str(e.value)
