@@ -237,6 +237,13 @@ const char* msf_multi_last_error(const msf_multi* m); /* m may be NULL: error of
 void msf_multi_shard_range(int32_t n_pairs, int32_t n_shards, int32_t shard, int32_t* first, int32_t* count);
 int msf_multi_match_batch(msf_multi* m, int32_t n_pairs, const msf_image* a, const msf_image* b, msf_match* out,
                           int32_t cap_per_pair, int32_t* n_out);
+/* HBM-resident form (the throughput path): shard r's n_pairs[r] pairs live on ITS device at d_a[r] / d_b[r] (layout
+ * and alignment as msf_match_batch_device) and its results go to its device buffers d_out[r] [n_pairs[r]][cap_per_pair]
+ * and d_n_out[r]; all arrays have msf_multi_device_count(m) entries.  Every shard runs on its handle's own stream and
+ * the call returns when all have finished. */
+int msf_multi_match_batch_device(msf_multi* m, const int32_t* n_pairs, const uint8_t* const* d_a,
+                                 const uint8_t* const* d_b, int64_t frame_stride, int64_t row_stride,
+                                 msf_match* const* d_out, int32_t cap_per_pair, int32_t* const* d_n_out);
 
 /* -------- introspection used by the parity tests and bench.py (not by the drop-in path) -------- */
 typedef enum msf_debug_what {

@@ -37,7 +37,7 @@ ABI_SYMBOLS = ["msf_abi_version", "msf_default_config", "msf_create", "msf_destr
                "msf_render_match_image", "msf_weights_info", "msf_convert_weights",
                "msf_frame_cache_stats", "msf_multi_create", "msf_multi_destroy", "msf_multi_device_count",
                "msf_multi_handle", "msf_multi_set_threshold", "msf_multi_last_error", "msf_multi_shard_range",
-               "msf_multi_match_batch"]
+               "msf_multi_match_batch", "msf_multi_match_batch_device"]
 
 
 class Config(C.Structure):
@@ -108,6 +108,8 @@ def load():
     L.msf_multi_shard_range.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
     L.msf_multi_shard_range.restype = None
     L.msf_multi_match_batch.argtypes = [vp, i32, C.POINTER(Image), C.POINTER(Image), vp, i32, vp]
+    L.msf_multi_match_batch_device.argtypes = [vp, C.POINTER(i32), C.POINTER(vp), C.POINTER(vp), i64, i64, C.POINTER(vp), i32,
+                                               C.POINTER(vp)]
     _lib = L
     return L
 

@@ -152,4 +152,40 @@ int msf_multi_match_batch(msf_multi* m, int32_t n_pairs, const msf_image* a, con
   }
 }
 
+int msf_multi_match_batch_device(msf_multi* m, const int32_t* n_pairs, const uint8_t* const* d_a, const uint8_t* const* d_b,
+                                 int64_t frame_stride, int64_t row_stride, msf_match* const* d_out, int32_t cap_per_pair,
+                                 int32_t* const* d_n_out) {
+  try {
+    if (!m) return MSF_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (!n_pairs || !d_a || !d_b || !d_out || !d_n_out || cap_per_pair < 1)
+      return mfail(m, MSF_ERR_INVALID_ARG, "msf_multi_match_batch_device: bad argument");
+    const int G = (int)m->shard.size();
+    std::vector<int> rc(G, MSF_OK);
+    auto run = [&](int r) {
+      // stream NULL: the shard's own stream, synchronised before the call returns
+      if (n_pairs[r] > 0)
+        rc[r] = msf_match_batch_device(m->shard[r], n_pairs[r], d_a[r], d_b[r], frame_stride, row_stride, d_out[r], cap_per_pair,
+                                       d_n_out[r], nullptr);
+    };
+    {
+      struct Joiner {
+        std::vector<std::thread> t;
+        ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); }
+      } workers;
+      for (int r = 1; r < G; r++) workers.t.emplace_back(run, r);
+      run(0);
+    }
+    for (int r = 0; r < G; r++)
+      if (rc[r] != MSF_OK) {
+        const char* e = msf_last_error(m->shard[r]);
+        m->err = "shard " + std::to_string(r) + " (device " + std::to_string(m->device[r]) + "): " + (e ? e : "error");
+        return rc[r];
+      }
+    return MSF_OK;
+  } catch (...) {
+    return mexception(m, "msf_multi_match_batch_device");
+  }
+}
+
 }  // extern "C"

@@ -335,3 +335,21 @@ class MultiDeviceMatcher:
         cnt = np.zeros((max(n, 1),), np.int32)
         self._check(self._L.msf_multi_match_batch(self._m, n, A, B, out.ctypes.data, cap, cnt.ctypes.data))
         return [out[i, :min(cnt[i], cap)].view(np.int32).reshape(-1, 4).copy() for i in range(n)]
+
+    def match_batch_device(self, d_a, d_b, d_out, d_n_out):
+        """Per shard r: d_a[r] / d_b[r] uint8 CUDA tensors [n_r, H, pitch] on that shard's device, d_out[r] int32
+        [n_r, cap, 4], d_n_out[r] int32 [n_r] (lists of len(devices) tensors; n_r may be 0).  Returns when every shard
+        has finished."""
+        G = len(self.devices)
+        assert len(d_a) == len(d_b) == len(d_out) == len(d_n_out) == G
+        vp = C.c_void_p
+        ref = next(t for t in d_a if t.shape[0] > 0)
+        for r in range(G):
+            assert d_a[r].is_cuda and d_a[r].stride()[1:] == ref.stride()[1:] and d_b[r].stride() == d_a[r].stride()
+        n = (C.c_int32 * G)(*[int(t.shape[0]) for t in d_a])
+        pa = (vp * G)(*[t.data_ptr() for t in d_a])
+        pb = (vp * G)(*[t.data_ptr() for t in d_b])
+        po = (vp * G)(*[t.data_ptr() for t in d_out])
+        pn = (vp * G)(*[t.data_ptr() for t in d_n_out])
+        self._check(self._L.msf_multi_match_batch_device(self._m, n, pa, pb, ref.stride(0), ref.stride(1), po,
+                                                         d_out[0].shape[1], pn))

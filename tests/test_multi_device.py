@@ -97,3 +97,32 @@ def test_shard_errors_name_the_shard():
     with pytest.raises(MsfError) as e:
         MultiDeviceMatcher("orb", 0.7, 320, 240, devices=(0, 99))
     assert "device 99" in str(e.value)
+
+
+@pytest.mark.gpu
+def test_resident_shards_equal_one_handle():
+    """msf_multi_match_batch_device: each shard's frames and result buffers are resident on its own device (here both
+    shards on cuda:0); same lists as one handle over the concatenated batch."""
+    import torch
+    from mono_slam_framework_amd.matcher import FeatureMatcher, MultiDeviceMatcher
+    w, h, n, cap = 320, 240, 11, 512
+    A, B = synth.synth_batch(4400, n, w, h, mode=0)
+    dA, dB = torch.from_numpy(np.stack(A)).cuda(), torch.from_numpy(np.stack(B)).cuda()
+    fl = _lib.MSF_FLAG_NO_FRAME_CACHE
+    one = FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=fl)
+    out = torch.zeros((n, cap, 4), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros((n,), dtype=torch.int32, device="cuda")
+    one.match_batch_device(dA, dB, out, cnt)
+    torch.cuda.synchronize()
+    multi = MultiDeviceMatcher("orb", 0.7, w, h, devices=(0, 0), max_batch_pairs=n, flags=fl)
+    cut = multi.shard_range(n, 1)[0]
+    parts = [(0, cut), (cut, n)]
+    outs = [torch.zeros((e - s, cap, 4), dtype=torch.int32, device="cuda") for s, e in parts]
+    cnts = [torch.zeros((e - s,), dtype=torch.int32, device="cuda") for s, e in parts]
+    multi.match_batch_device([dA[s:e] for s, e in parts], [dB[s:e] for s, e in parts], outs, cnts)
+    got_cnt = torch.cat(cnts).cpu().numpy()
+    np.testing.assert_array_equal(got_cnt, cnt.cpu().numpy())
+    got, ref = torch.cat(outs).cpu().numpy(), out.cpu().numpy()
+    assert got_cnt.sum() > 10 * n
+    for i in range(n):
+        np.testing.assert_array_equal(got[i, :got_cnt[i]], ref[i, :got_cnt[i]])
