@@ -2960,6 +2960,17 @@ __global__ __launch_bounds__(64 * kKvWaves) void k_attn_kv_x(const float* __rest
   __shared__ float red[kKvWaves][DM * DM + DM];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tl = lane & 15, g = lane >> 4;
   const float* s = src + (long long)blockIdx.x * seq_stride;
+  constexpr int NT16 = NTOK / 16;                                // 75 token tiles: 37 pairs + one single
+  // (the first pair goes out together with the weight loads below)
+  // the token rows of the next pair of tiles are requested before the current pair is processed (a sequence is walked
+  // by 8 waves in 4-5 dependent steps: the kernel is latency-bound for small batches); clamped, so unconditional
+  f32x4 nx[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const float* xr = s + (long long)(min(2 * wave + h, NT16 - 1) * 16 + tl) * DM + 8 * g;
+    nx[h][0] = *reinterpret_cast<const f32x4*>(xr);
+    nx[h][1] = *reinterpret_cast<const f32x4*>(xr + 4);
+  }
   if (tid < 256) {                                               // f32 packing [(n * 8 + slot) * 64 + lane] -> fragments
     const bool isv = tid >= 128;
     const int n = (tid >> 6) & 1, ln = tid & 63;
@@ -2976,15 +2987,22 @@ __global__ __launch_bounds__(64 * kKvWaves) void k_attn_kv_x(const float* __rest
   const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 acc[2][2] = {{zero, zero}, {zero, zero}};
   float ksum[2] = {0.f, 0.f};
-  constexpr int NT16 = NTOK / 16;                                // 75 token tiles: 37 pairs + one single
   for (int t0 = 2 * wave; t0 < NT16; t0 += 2 * kKvWaves) {
     float Kv[2][8], Vv[2][8];                                    // [feature tile][tile of the pair * 4 + r]
+    f32x4 cx[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      cx[h][0] = nx[h][0];
+      cx[h][1] = nx[h][1];
+      const float* xr = s + (long long)(min(t0 + 2 * kKvWaves + h, NT16 - 1) * 16 + tl) * DM + 8 * g;
+      nx[h][0] = *reinterpret_cast<const f32x4*>(xr);
+      nx[h][1] = *reinterpret_cast<const f32x4*>(xr + 4);
+    }
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       const int tile = t0 + h;
       if (tile < NT16) {
-        const float* xr = s + (long long)(tile * 16 + tl) * DM + 8 * g;
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(xr), x1 = *reinterpret_cast<const f32x4*>(xr + 4);
+        const f32x4 x0 = cx[h][0], x1 = cx[h][1];
         const float xa[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
         bf16x8 xh, xl;
         split8(xa, xh, xl);
