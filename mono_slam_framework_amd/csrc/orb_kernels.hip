@@ -526,9 +526,11 @@ __device__ __forceinline__ int stream_score(const uint8_t* ring, uint32_t r0, ui
   return A > tau ? A - 1 : 0;
 }
 
+// phase: -1 = every strip; 0 = the sampled quarter (flat strip index % 4 == 0, n_part of them per frame) at the sampler's
+// tau; 1 = the other strips at the threshold k_fast_tau2 derives from the quarter's corners (see there).
 __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
                                                     const uint32_t* __restrict__ tau, uint32_t* cand_cnt,
-                                                    uint32_t* cand_key, uint8_t* cand_sc) {
+                                                    uint32_t* cand_key, uint8_t* cand_sc, int phase, int n_part) {
   __shared__ StreamSmem sm;
   int G;
   {
@@ -536,7 +538,8 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
     const uint32_t xcd = lin & 7u, q = total >> 3, r = total & 7u;
     G = (int)(xcd * q + (xcd < r ? xcd : r) + (lin >> 3));
   }
-  const int fi = G / g.total_strips, bt = G - fi * g.total_strips;
+  const int fi = G / n_part, ip = G - fi * n_part;
+  const int bt = phase < 0 ? ip : phase == 0 ? 4 * ip : 4 * (ip / 3) + ip % 3 + 1;
   int l = 0;
 #pragma unroll
   for (int i = 1; i < kOrbLevels; i++)
@@ -995,15 +998,65 @@ __global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, c
   }
 }
 
+// Second estimate of tau, from exact data.  The sampler's estimate rests on a few dozen hits and stays 3-9 x above the
+// 2N maxima a large level needs.  So the streaming pass runs in two parts: first every fourth strip (flat strip index
+// % 4 == 0: a quarter of the level, spread over it) at the sampler's tau, then this kernel reads the corners those
+// strips emitted -- exact maxima with exact scores -- and raises tau to the largest multiple of 4 at which the quarter
+// still holds kTau2Margin x its share of 2N; the other strips run at that value.  Everything at or above the final tau
+// is still found exactly (the first quarter found more), k_fast_check counts what reaches it, and a level that falls
+// short is redone densely as before: the result is the dense one bit for bit whatever happens here.
+// Levels with fewer than kTau2MinStrips sampled strips keep the sampler's value.
+constexpr int kTau2Margin = 2, kTau2MinStrips = 4;
+__global__ __launch_bounds__(64) void k_fast_tau2(OrbGeometry g, int slot0, int n_frames, uint32_t* tau, uint32_t* tau_first,
+                                                  const uint32_t* cand_cnt, const uint8_t* cand_sc, uint32_t* cnt_a) {
+  __shared__ uint32_t hist[kTauBins];
+  const int fi = blockIdx.x / kOrbLevels, l = blockIdx.x - fi * kOrbLevels, lane = threadIdx.x;
+  if (fi >= n_frames || l >= g.nlevels) return;
+  const int idx = (slot0 + fi) * kOrbLevels + l;
+  const OrbLevelInfo L = g.lv[l];
+  const uint32_t n_raw = cand_cnt[idx], ts = tau[idx];
+  uint32_t t2 = ts, c_ge = n_raw;
+  const int n_strips = L.strips_x * L.strips_y;
+  if (ts > (uint32_t)kFastT && L.strips_a >= kTau2MinStrips && n_raw <= (uint32_t)L.cand_cap) {
+    hist[lane] = 0;
+    __syncthreads();
+    const uint8_t* scs = cand_sc + (long long)(slot0 + fi) * g.cand_total + L.cand_off;
+    for (uint32_t i = lane; i < n_raw; i += 64) atomicAdd(&hist[scs[i] >> 2], 1u);
+    __syncthreads();
+    uint32_t c = hist[lane];                       // suffix sums: c = corners of the quarter with score >= 4 * lane
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_down(c, o);
+      if (lane + o < 64) c += up;
+    }
+    const uint32_t need = ((uint32_t)(kTau2Margin * 2) * (uint32_t)L.quota * (uint32_t)L.strips_a + n_strips - 1) / n_strips;
+    const unsigned long long ok = __ballot(c >= need && 4u * lane >= ts);
+    if (ok) {
+      const int top = 63 - __builtin_clzll(ok);
+      t2 = 4u * top;
+      c_ge = __shfl(c, top);
+    }
+  }
+  if (lane == 0) {
+    tau[idx] = t2;
+    tau_first[idx] = t2;
+    cnt_a[2 * idx] = c_ge;         // corners of the sampled quarter that reach the final tau
+    cnt_a[2 * idx + 1] = n_raw;    // everything the quarter emitted
+  }
+}
+
 // After k_fast: a (frame, level) that ran with tau above fastThreshold and found fewer than 2N maxima is queued for the
-// dense pass (its candidate list restarts from empty).
+// dense pass (its candidate list restarts from empty).  cnt_a (two-part streaming pass): only corners at or above the
+// final tau count -- those of the sampled quarter that reach it plus everything the second part emitted.
 __global__ __launch_bounds__(256) void k_fast_check(OrbGeometry g, int slot0, int n_frames, uint32_t* tau,
-                                                    uint32_t* cand_cnt, uint32_t* redo_cnt, uint32_t* redo_list) {
+                                                    uint32_t* cand_cnt, uint32_t* redo_cnt, uint32_t* redo_list,
+                                                    const uint32_t* cnt_a) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_frames * kOrbLevels) return;
   const int fi = i / kOrbLevels, l = i - fi * kOrbLevels, idx = (slot0 + fi) * kOrbLevels + l;
   if (l >= g.nlevels || tau[idx] <= (uint32_t)kFastT) return;
-  if (cand_cnt[idx] < 2u * (uint32_t)g.lv[l].quota) {
+  const uint32_t found = cnt_a ? cnt_a[2 * idx] + (cand_cnt[idx] - cnt_a[2 * idx + 1]) : cand_cnt[idx];
+  if (found < 2u * (uint32_t)g.lv[l].quota) {
     tau[idx] = kFastT;
     cand_cnt[idx] = 0;
     redo_list[atomicAdd(redo_cnt, 1u)] = (uint32_t)(fi * kOrbLevels + l);
@@ -1695,7 +1748,7 @@ static void make_table(int src, int dst, uint32_t* tab) {
 OrbPipeline::~OrbPipeline() { destroy(); }
 
 void OrbPipeline::destroy() {
-  hipFree(d_tau_); hipFree(d_redo_); d_tau_ = nullptr; d_redo_ = nullptr;
+  hipFree(d_tau_); hipFree(d_redo_); hipFree(d_cnt_a_); d_tau_ = nullptr; d_redo_ = nullptr; d_cnt_a_ = nullptr;
   hipFree(d_pyr_); hipFree(d_tab_); hipFree(d_cand_cnt_); hipFree(d_cand_); hipFree(d_cand_sc_); hipFree(d_qres_); hipFree(d_done_); hipFree(d_s1_cnt_); hipFree(d_s1_);
   hipFree(d_kp_); hipFree(d_desc_); hipFree(d_kp_cnt_); hipFree(d_status_);
   d_pyr_ = nullptr; d_tab_ = nullptr; d_cand_cnt_ = nullptr; d_cand_ = nullptr; d_cand_sc_ = nullptr; d_qres_ = nullptr; d_done_ = nullptr; d_s1_cnt_ = nullptr;
@@ -1746,6 +1799,8 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   // MSF_ORB_RESIZE_GENERIC=1: k_resize reads every pixel's taps from its own dword pair (the fallback for level
   // geometries whose column table fails the shared-pair check; tests compare the two)
   if (const char* e = getenv("MSF_ORB_RESIZE_GENERIC")) resize_generic_ = atoi(e) != 0;
+  // MSF_ORB_FAST_ONE_PART=1: the streaming FAST pass over all strips at the sampler's threshold (no second estimate)
+  if (const char* e = getenv("MSF_ORB_FAST_ONE_PART")) fast_two_part_ = atoi(e) == 0;
   OrbGeometry& g = g_;
   g.nlevels = kOrbLevels;
   g.w0 = width;
@@ -1815,6 +1870,7 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     L.strips_y = L.tiles_x > 0 ? (L.h - 2 * kEdge + SR - 1) / SR : 0;
     L.strip_base = strips;
     strips += L.strips_x * L.strips_y;
+    L.strips_a = (strips + 3) / 4 - (L.strip_base + 3) / 4;   // multiples of 4 in [strip_base, strips)
     if (L.tiles_x * L.tiles_y > g.max_level_tiles) g.max_level_tiles = L.tiles_x * L.tiles_y;
     // sample lattice of k_fast_tau: about 4096 pixels of the kept region in runs of 4 (one dword), rows sparser than
     // columns (a sampled pixel touches 7 rows); samp_sx counts dwords and is odd, so that block textures with
@@ -1877,6 +1933,7 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   MSF_HIP_TRY(hipMalloc(&d_tau_, 2 * S * kOrbLevels * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMemset(d_tau_, 0, 2 * S * kOrbLevels * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMalloc(&d_redo_, (1 + S * kOrbLevels) * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMalloc(&d_cnt_a_, 2 * S * kOrbLevels * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMalloc(&d_cand_, S * g.cand_total * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMalloc(&d_cand_sc_, S * g.cand_total));
   MSF_HIP_TRY(hipMalloc(&d_s1_cnt_, S * kOrbLevels * sizeof(uint32_t)));
@@ -2034,10 +2091,22 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
       hipLaunchKernelGGL(k_fast, dim3((unsigned)g.total_tiles * (unsigned)n), dim3(kFastThreads), 0, st, g, src, d_pyr_,
                          d_cand_cnt_, d_cand_, d_cand_sc_);
     } else {
-      hipLaunchKernelGGL(k_fast_stream, dim3((unsigned)g.total_strips * (unsigned)n), dim3(64), 0, st, g, src, d_pyr_, tau,
-                         d_cand_cnt_, d_cand_, d_cand_sc_);
-      hipLaunchKernelGGL(k_fast_check, dim3((n * kOrbLevels + 255) / 256), dim3(256), 0, st, g, src.slot0, n, tau, d_cand_cnt_,
-                         d_redo_, d_redo_ + 1);
+      const int n_a = (g.total_strips + 3) / 4, n_b = g.total_strips - n_a;
+      if (fast_two_part_ && force_tau == 0 && n_b > 0) {
+        hipLaunchKernelGGL(k_fast_stream, dim3((unsigned)n_a * (unsigned)n), dim3(64), 0, st, g, src, d_pyr_, tau,
+                           d_cand_cnt_, d_cand_, d_cand_sc_, 0, n_a);
+        hipLaunchKernelGGL(k_fast_tau2, dim3((unsigned)n * kOrbLevels), dim3(64), 0, st, g, src.slot0, n, tau, tau_first,
+                           d_cand_cnt_, d_cand_sc_, d_cnt_a_);
+        hipLaunchKernelGGL(k_fast_stream, dim3((unsigned)n_b * (unsigned)n), dim3(64), 0, st, g, src, d_pyr_, tau,
+                           d_cand_cnt_, d_cand_, d_cand_sc_, 1, n_b);
+        hipLaunchKernelGGL(k_fast_check, dim3((n * kOrbLevels + 255) / 256), dim3(256), 0, st, g, src.slot0, n, tau,
+                           d_cand_cnt_, d_redo_, d_redo_ + 1, d_cnt_a_);
+      } else {
+        hipLaunchKernelGGL(k_fast_stream, dim3((unsigned)g.total_strips * (unsigned)n), dim3(64), 0, st, g, src, d_pyr_, tau,
+                           d_cand_cnt_, d_cand_, d_cand_sc_, -1, g.total_strips);
+        hipLaunchKernelGGL(k_fast_check, dim3((n * kOrbLevels + 255) / 256), dim3(256), 0, st, g, src.slot0, n, tau,
+                           d_cand_cnt_, d_redo_, d_redo_ + 1, (const uint32_t*)nullptr);
+      }
       // fixed grid (a multiple of 8: see the XCD-contiguous unit order), sized to what the batch could need
       long long units = (long long)n * kOrbLevels * g.max_level_tiles;
       unsigned grid = (unsigned)(units < 2048 ? units : 2048);
@@ -2147,8 +2216,15 @@ int OrbPipeline::debug_get(int what, int slot, int level, void* host_out, size_t
         hipMemcpy(tk.data(), d_cand_ + (size_t)slot * g.cand_total + g.lv[level].cand_off, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
         hipMemcpy(ts.data(), d_cand_sc_ + (size_t)slot * g.cand_total + g.lv[level].cand_off, n, hipMemcpyDeviceToHost);
       }
-      std::vector<int32_t> o(n * 3);
-      for (uint32_t i = 0; i < n; i++) { o[i * 3] = tk[i] & 0xFFFF; o[i * 3 + 1] = tk[i] >> 16; o[i * 3 + 2] = ts[i]; }
+      // the sampled quarter of a two-part streaming pass also lists corners below the level's final threshold
+      uint32_t tfin = 0;
+      hipMemcpy(&tfin, d_tau_ + (size_t)slot * kOrbLevels + level, 4, hipMemcpyDeviceToHost);
+      std::vector<int32_t> o;
+      o.reserve(n * 3);
+      for (uint32_t i = 0; i < n; i++)
+        if (tfin <= (uint32_t)kFastT || ts[i] >= tfin) {
+          o.push_back(tk[i] & 0xFFFF); o.push_back(tk[i] >> 16); o.push_back(ts[i]);
+        }
       *n_bytes = o.size() * 4;
       memcpy(host_out, o.data(), *n_bytes < cap ? *n_bytes : cap);
       return 0;

@@ -29,6 +29,7 @@ struct OrbLevelInfo {
   int s1_off;          // offset (entries) of this level inside a slot's stage-1 array
   int tiles_x, tiles_y, tile_base;  // FAST tiling (128 x 32 tiles, dense kernel)
   int strips_x, strips_y, strip_base;   // 248 x 64 column strips of the streaming first pass (one wave each)
+  int strips_a;                         // strips of this level in the sampled quarter (flat strip index % 4 == 0)
   int tab_off;         // offset (entries) of this level's resize tables
   int samp_sx, samp_sy, samp_rows, samp_cols;   // k_fast_tau's sample lattice over [31, w-31) x [31, h-31); rows 0 = none
   long long pix_off;   // byte offset of this level inside a slot's pyramid blob (levels >= 1)
@@ -87,6 +88,8 @@ class OrbPipeline {
   uint8_t* d_pyr_ = nullptr;
   uint32_t* d_tab_ = nullptr;      // resize tables per level: per group of 4 columns selectors / weights / pair offsets, per row source row | w1 << 16
   bool resize_shared_[kOrbLevels] = {};   // per level: k_resize may read three pixels' taps from one dword pair
+  uint32_t* d_cnt_a_ = nullptr;           // [slots][levels][2]: two-part streaming FAST, see k_fast_tau2
+  bool fast_two_part_ = true;             // MSF_ORB_FAST_ONE_PART=1 clears it
   bool resize_generic_ = false;           // MSF_ORB_RESIZE_GENERIC: never
   uint32_t* d_cand_cnt_ = nullptr; // [slots][8]
   uint32_t* d_tau_ = nullptr;      // [2][slots][8] FAST score threshold used per (slot, level) | first estimate
