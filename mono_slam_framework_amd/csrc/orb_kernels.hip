@@ -1006,7 +1006,9 @@ __global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, c
 // is still found exactly (the first quarter found more), k_fast_check counts what reaches it, and a level that falls
 // short is redone densely as before: the result is the dense one bit for bit whatever happens here.
 // Levels with fewer than kTau2MinStrips sampled strips keep the sampler's value.
-constexpr int kTau2Margin = 2, kTau2MinStrips = 4;
+// (measured at 720p, fast_nms ms / levels redone of 10 240 over three textures and two sizes: margin 2.0 with at least 4 / 2 / 1
+// sampled strips 3.92 / 3.74 / 3.80 and none redone; margin 1.5: 3.82 / 3.68 with 4 redone; margin 2.5: 3.93)
+constexpr int kTau2Margin = 2, kTau2MinStrips = 2;
 __global__ __launch_bounds__(64) void k_fast_tau2(OrbGeometry g, int slot0, int n_frames, uint32_t* tau, uint32_t* tau_first,
                                                   const uint32_t* cand_cnt, const uint8_t* cand_sc, uint32_t* cnt_a) {
   __shared__ uint32_t hist[kTauBins];
