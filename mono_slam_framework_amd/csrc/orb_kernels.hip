@@ -1008,6 +1008,9 @@ __global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, c
 // Levels with fewer than kTau2MinStrips sampled strips keep the sampler's value.
 // (measured at 720p, fast_nms ms / levels redone of 10 240 over three textures and two sizes: margin 2.0 with at least 4 / 2 / 1
 // sampled strips 3.92 / 3.74 / 3.80 and none redone; margin 1.5: 3.82 / 3.68 with 4 redone; margin 2.5: 3.93)
+// Every 3rd / 6th / 8th strip instead of every 4th: 3.84 / 3.71 (17 levels redone of 4096) / 3.74 against 3.70-3.75;
+// a cheaper sampler (512 / 256 sites per level instead of 1024) gives the pyramid kernels 0.12 / 0.25 ms back and
+// costs the first part 0.24 / 0.87 ms.
 constexpr int kTau2Margin = 2, kTau2MinStrips = 2;
 __global__ __launch_bounds__(64) void k_fast_tau2(OrbGeometry g, int slot0, int n_frames, uint32_t* tau, uint32_t* tau_first,
                                                   const uint32_t* cand_cnt, const uint8_t* cand_sc, uint32_t* cnt_a) {
