@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, c
 // 2N maxima a large level needs.  So the streaming pass runs in two parts: first every fourth strip (flat strip index
 // % 4 == 0: a quarter of the level, spread over it) at the sampler's tau, then this kernel reads the corners those
 // strips emitted -- exact maxima with exact scores -- and raises tau to the largest multiple of 4 at which the quarter
-// still holds kTau2Margin x its share of 2N; the other strips run at that value.  Everything at or above the final tau
+// still holds kTau2MarginPct % of its share of 2N; the other strips run at that value.  Everything at or above the final tau
 // is still found exactly (the first quarter found more), k_fast_check counts what reaches it, and a level that falls
 // short is redone densely as before: the result is the dense one bit for bit whatever happens here.
 // Levels with fewer than kTau2MinStrips sampled strips keep the sampler's value.
@@ -1011,9 +1011,10 @@ __global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, c
 // Every 3rd / 6th / 8th strip instead of every 4th: 3.84 / 3.71 (17 levels redone of 4096) / 3.74 against 3.70-3.75;
 // a cheaper sampler (512 / 256 sites per level instead of 1024) gives the pyramid kernels 0.12 / 0.25 ms back and
 // costs the first part 0.24 / 0.87 ms.
-constexpr int kTau2Margin = 2, kTau2MinStrips = 2;
+constexpr int kTau2MarginPct = 200, kTau2MinStrips = 2;
 __global__ __launch_bounds__(64) void k_fast_tau2(OrbGeometry g, int slot0, int n_frames, uint32_t* tau, uint32_t* tau_first,
-                                                  const uint32_t* cand_cnt, const uint8_t* cand_sc, uint32_t* cnt_a) {
+                                                  const uint32_t* cand_cnt, const uint8_t* cand_sc, uint32_t* cnt_a,
+                                                  int margin_pct) {
   __shared__ uint32_t hist[kTauBins];
   const int fi = blockIdx.x / kOrbLevels, l = blockIdx.x - fi * kOrbLevels, lane = threadIdx.x;
   if (fi >= n_frames || l >= g.nlevels) return;
@@ -1034,7 +1035,8 @@ __global__ __launch_bounds__(64) void k_fast_tau2(OrbGeometry g, int slot0, int 
       const uint32_t up = __shfl_down(c, o);
       if (lane + o < 64) c += up;
     }
-    const uint32_t need = ((uint32_t)(kTau2Margin * 2) * (uint32_t)L.quota * (uint32_t)L.strips_a + n_strips - 1) / n_strips;
+    const uint32_t den = 100u * (uint32_t)n_strips;
+    const uint32_t need = ((uint32_t)margin_pct * 2u * (uint32_t)L.quota * (uint32_t)L.strips_a + den - 1u) / den;
     const unsigned long long ok = __ballot(c >= need && 4u * lane >= ts);
     if (ok) {
       const int top = 63 - __builtin_clzll(ok);
@@ -1806,6 +1808,13 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   if (const char* e = getenv("MSF_ORB_RESIZE_GENERIC")) resize_generic_ = atoi(e) != 0;
   // MSF_ORB_FAST_ONE_PART=1: the streaming FAST pass over all strips at the sampler's threshold (no second estimate)
   if (const char* e = getenv("MSF_ORB_FAST_ONE_PART")) fast_two_part_ = atoi(e) == 0;
+  // MSF_ORB_TAU2_MARGIN_PCT: the second estimate's safety margin in percent of 2N (tests: a few percent makes it overshoot,
+  // so that levels fail the check and take the dense second pass)
+  tau2_margin_pct_ = kTau2MarginPct;
+  if (const char* e = getenv("MSF_ORB_TAU2_MARGIN_PCT")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= 10000) tau2_margin_pct_ = v;
+  }
   OrbGeometry& g = g_;
   g.nlevels = kOrbLevels;
   g.w0 = width;
@@ -2101,7 +2110,7 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
         hipLaunchKernelGGL(k_fast_stream, dim3((unsigned)n_a * (unsigned)n), dim3(64), 0, st, g, src, d_pyr_, tau,
                            d_cand_cnt_, d_cand_, d_cand_sc_, 0, n_a);
         hipLaunchKernelGGL(k_fast_tau2, dim3((unsigned)n * kOrbLevels), dim3(64), 0, st, g, src.slot0, n, tau, tau_first,
-                           d_cand_cnt_, d_cand_sc_, d_cnt_a_);
+                           d_cand_cnt_, d_cand_sc_, d_cnt_a_, tau2_margin_pct_);
         hipLaunchKernelGGL(k_fast_stream, dim3((unsigned)n_b * (unsigned)n), dim3(64), 0, st, g, src, d_pyr_, tau,
                            d_cand_cnt_, d_cand_, d_cand_sc_, 1, n_b);
         hipLaunchKernelGGL(k_fast_check, dim3((n * kOrbLevels + 255) / 256), dim3(256), 0, st, g, src.slot0, n, tau,

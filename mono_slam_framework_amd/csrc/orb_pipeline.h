@@ -90,6 +90,7 @@ class OrbPipeline {
   bool resize_shared_[kOrbLevels] = {};   // per level: k_resize may read three pixels' taps from one dword pair
   uint32_t* d_cnt_a_ = nullptr;           // [slots][levels][2]: two-part streaming FAST, see k_fast_tau2
   bool fast_two_part_ = true;             // MSF_ORB_FAST_ONE_PART=1 clears it
+  int tau2_margin_pct_ = 200;             // MSF_ORB_TAU2_MARGIN_PCT
   bool resize_generic_ = false;           // MSF_ORB_RESIZE_GENERIC: never
   uint32_t* d_cand_cnt_ = nullptr; // [slots][8]
   uint32_t* d_tau_ = nullptr;      // [2][slots][8] FAST score threshold used per (slot, level) | first estimate

@@ -428,6 +428,41 @@ def test_resize_fallback_equals_shared_pair_kernel(monkeypatch, w, h):
 
 
 @pytest.mark.gpu
+def test_two_part_fast_pass_equals_one_part_and_survives_an_overshooting_estimate(monkeypatch):
+    """The streaming FAST pass runs a sampled quarter of the strips at the sampler's threshold and the rest at a second
+    estimate made from the quarter's exact corners (k_fast_tau2).  Same match lists as the one-part pass
+    (MSF_ORB_FAST_ONE_PART=1); the second estimate really is higher on the large levels; and with the margin cut to
+    3 % of 2N it overshoots, levels fail k_fast_check, take the dense second pass -- and the lists are still the same."""
+    from mono_slam_framework_amd import _lib
+    from mono_slam_framework_amd.matcher import FeatureMatcher
+    n, w, h = 12, 1280, 720
+    A, B = synth.synth_batch(9300, n, w, h, mode=0)
+    fl = _lib.MSF_FLAG_NO_FRAME_CACHE
+    monkeypatch.setenv("MSF_ORB_FAST_ONE_PART", "1")
+    one = FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=fl)
+    ref = one.match_batch(list(A), list(B), cap=1024)
+    tau_one = np.stack([one.fast_tau(s) for s in range(2 * n)])
+    assert sum(len(m) for m in ref) > 50 * n
+    monkeypatch.delenv("MSF_ORB_FAST_ONE_PART")
+    two = FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=fl)
+    got = two.match_batch(list(A), list(B), cap=1024)
+    tau_two = np.stack([two.fast_tau(s) for s in range(2 * n)])
+    for r, g in zip(ref, got):
+        np.testing.assert_array_equal(r, g)
+    assert (tau_two[:, :, 0] >= tau_one[:, :, 0]).all() and (tau_two[:, :3, 0] > tau_one[:, :3, 0]).mean() > 0.5
+    assert (tau_two[:, :, 0] == tau_two[:, :, 1]).all()                    # nothing redone at the default margin
+    orc = oracle_orb.FeatureMatcherOracle(0.7)
+    np.testing.assert_array_equal(got[0], orc.MatchFrames(A[0], B[0]))
+    monkeypatch.setenv("MSF_ORB_TAU2_MARGIN_PCT", "3")
+    wild = FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=fl)
+    got2 = wild.match_batch(list(A), list(B), cap=1024)
+    tau_w = np.stack([wild.fast_tau(s) for s in range(2 * n)])
+    assert (tau_w[:, :, 0] == 20).sum() > 2 * n                            # many levels fell back to the dense pass
+    for r, g in zip(ref, got2):
+        np.testing.assert_array_equal(r, g)
+
+
+@pytest.mark.gpu
 def test_split_extraction_equals_single_pass(monkeypatch):
     """Opt-in MSF_ORB_SPLIT2=2: batches of >= 256 frames are extracted as two pipelined sub-batches on two streams
     (OrbPipeline::extract).  Same frames, same slots: identical match lists to the one-pass default, and the stage
