@@ -207,7 +207,8 @@ def run_workload(args, matcher, W, H, P, ratio_or_thr, rank, world, local_rank, 
         elif dom:
             # a batch of >= 256 frames is extracted as two pipelined sub-batches: every batch kernel is launched once per
             # part, stage times are sums over the parts, and "per launch" below is per part
-            launches = fm.extract_parts(2 * P)
+            # ... and the streaming FAST kernel runs twice per extraction (a quarter of the strips, then the rest)
+            launches = fm.extract_parts(2 * P) * (fm.fast_stream_parts() if dom == "fast_nms" else 1)
             achieved = P * bpp / (stages[dom] * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom,
                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -224,6 +224,14 @@ class FeatureMatcher(_Matcher):
             return 1
         return 2
 
+    @staticmethod
+    def fast_stream_parts():
+        """Launches of the streaming FAST kernel per extraction: 2 (a sampled quarter of the strips at the sampler's
+        threshold, then the rest at the second estimate, k_fast_tau2), or 1 with MSF_ORB_FAST_ONE_PART=1 / a forced
+        threshold (MSF_ORB_FAST_TAU)."""
+        import os
+        return 1 if os.environ.get("MSF_ORB_FAST_ONE_PART", "0") not in ("", "0") or os.environ.get("MSF_ORB_FAST_TAU") else 2
+
     # Introspection of the feature slots.  `slot` counts from the scratch slots of the last MatchFrames / match_batch
     # call (frame A of pair i = i, frame B = n_pairs + i); cache=True addresses the per-frame cache slots of
     # extract_device / store_frame instead (the two ranges are disjoint: [2P, 4P) and [0, 2P), P = max_batch_pairs).
