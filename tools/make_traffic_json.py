@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STAGE = {"k_resize": "pyramid", "k_fast": "fast_nms", "k_fast_tau": "fast_nms", "k_fast_stream": "fast_nms",
-         "k_fast_check": "fast_nms", "k_fast_redo": "fast_nms", "k_thr_harris": "select_harris", "k_select": "select_harris",
+         "k_fast_check": "fast_nms", "k_fast_tau2": "fast_nms", "k_fast_redo": "fast_nms", "k_thr_harris": "select_harris", "k_select": "select_harris",
          "k_describe": "orient_describe", "k_match": "match", "k_conv": "backbone_convs", "k_tokens": "backbone_convs",
          "k_block8": "backbone_convs", "k_block16": "backbone_convs", "k_block8x": "backbone_convs",
          "k_block16x": "backbone_convs", "k_convx": "backbone_convs", "k_down16x": "backbone_convs",
