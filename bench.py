@@ -216,7 +216,10 @@ def run_workload(args, matcher, W, H, P, ratio_or_thr, rank, world, local_rank, 
                         "avg_launch_ms": round(stages[dom] / launches, 4), "launches_per_step": launches,
                         "algorithmic_bytes_per_launch": P * bpp // launches,
                         "stage_ms": {k: round(v, 4) for k, v in stages.items()},
-                        "pipeline_frac": round(value / world * bpp / 1e9 / HBM_PEAK_GBS, 5)}
+                        "pipeline_frac": round(value / world * bpp / 1e9 / HBM_PEAK_GBS, 5),
+                        # the stage's measured HBM bytes (committed PMC passes) over its time: how busy the bus really is
+                        "hbm_frac": (round(traffic["bytes"] / (stages[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                                     if traffic else None)}
         if world > 1:
             assert gathered[0] > 0, "rank 0 gathered no match records"
         res = {
