@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, c
 // 2N maxima a large level needs.  So the streaming pass runs in two parts: first every fourth strip (flat strip index
 // % 4 == 0: a quarter of the level, spread over it) at the sampler's tau, then this kernel reads the corners those
 // strips emitted -- exact maxima with exact scores -- and raises tau to the largest multiple of 4 at which the quarter
-// still holds kTau2MarginPct % of its share of 2N; the other strips run at that value.  Everything at or above the final tau
+// still holds kTau2MarginPct % (kTau2MarginPctMany % when at least kTau2ManyStrips strips were sampled) of its share of 2N; the other strips run at that value.  Everything at or above the final tau
 // is still found exactly (the first quarter found more), k_fast_check counts what reaches it, and a level that falls
 // short is redone densely as before: the result is the dense one bit for bit whatever happens here.
 // Levels with fewer than kTau2MinStrips sampled strips keep the sampler's value.
@@ -1012,6 +1012,7 @@ __global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, c
 // a cheaper sampler (512 / 256 sites per level instead of 1024) gives the pyramid kernels 0.12 / 0.25 ms back and
 // costs the first part 0.24 / 0.87 ms.
 constexpr int kTau2MarginPct = 200, kTau2MinStrips = 2;
+constexpr int kTau2MarginPctMany = 150, kTau2ManyStrips = 8;
 __global__ __launch_bounds__(64) void k_fast_tau2(OrbGeometry g, int slot0, int n_frames, uint32_t* tau, uint32_t* tau_first,
                                                   const uint32_t* cand_cnt, const uint8_t* cand_sc, uint32_t* cnt_a,
                                                   int margin_pct) {
@@ -1036,7 +1037,10 @@ __global__ __launch_bounds__(64) void k_fast_tau2(OrbGeometry g, int slot0, int 
       if (lane + o < 64) c += up;
     }
     const uint32_t den = 100u * (uint32_t)n_strips;
-    const uint32_t need = ((uint32_t)margin_pct * 2u * (uint32_t)L.quota * (uint32_t)L.strips_a + den - 1u) / den;
+    // a level with many sampled strips gives a steadier estimate and takes the smaller margin (720p: levels 0-2;
+    // fast_nms 3.73 -> 3.65 ms, none redone at 720p / 1080p); an explicit MSF_ORB_TAU2_MARGIN_PCT applies to every level
+    const uint32_t mp = (L.strips_a >= kTau2ManyStrips && margin_pct == kTau2MarginPct) ? (uint32_t)kTau2MarginPctMany : (uint32_t)margin_pct;
+    const uint32_t need = (mp * 2u * (uint32_t)L.quota * (uint32_t)L.strips_a + den - 1u) / den;
     const unsigned long long ok = __ballot(c >= need && 4u * lane >= ts);
     if (ok) {
       const int top = 63 - __builtin_clzll(ok);
