@@ -1038,7 +1038,8 @@ __global__ __launch_bounds__(64) void k_fast_tau2(OrbGeometry g, int slot0, int 
     }
     const uint32_t den = 100u * (uint32_t)n_strips;
     // a level with many sampled strips gives a steadier estimate and takes the smaller margin (720p: levels 0-2;
-    // fast_nms 3.73 -> 3.65 ms, none redone at 720p / 1080p); an explicit MSF_ORB_TAU2_MARGIN_PCT applies to every level
+    // fast_nms 3.73 -> 3.65 ms, none redone at 720p / 1080p; 125 % there: 3.85 ms with 26 of 4096 levels redone, 150 % from
+    // 4 strips: 3.67 with 4 redone); an explicit MSF_ORB_TAU2_MARGIN_PCT applies to every level
     const uint32_t mp = (L.strips_a >= kTau2ManyStrips && margin_pct == kTau2MarginPct) ? (uint32_t)kTau2MarginPctMany : (uint32_t)margin_pct;
     const uint32_t need = (mp * 2u * (uint32_t)L.quota * (uint32_t)L.strips_a + den - 1u) / den;
     const unsigned long long ok = __ballot(c >= need && 4u * lane >= ts);
