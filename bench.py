@@ -19,7 +19,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, exact f32 (the LoFTR path's dtype)
+MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, exact f32 (MSF_FLAG_LOFTR_F32)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (the default LoFTR path issues v_mfma_f32_16x16x32_bf16)
 LOFTR_FLOPS_PER_PAIR = 2.601e9  # conv 2.273 G + matmul 0.328 G (2 x MAC)
 LOFTR_CONV_FLOPS_PER_PAIR = 2.273e9
 
@@ -29,14 +30,36 @@ def algorithmic_bytes_per_pair(w, h):
     return 2 * w * h + 2 * 500 * 40 + 500 * 16
 
 
+def host_cpu():
+    """nproc + CPU model of the box the CPU leg runs on (SURVEY.md 8d asks for both next to every CPU figure)."""
+    model = None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return {"nproc": os.cpu_count() or 1, "usable": usable, "model": model}
+
+
 def cpu_baseline(args, A, B, gpu_lists):
-    """Times the CPU oracle (kind "port") on a bounded sample of the same pairs, one pair per thread."""
+    """Times the CPU oracle (kind "port") on a bounded sample of the same pairs, one pair per thread.  The sample is
+    sized for about --cpu-seconds of wall time from a short calibration run (never more than the resident batch)."""
     from concurrent.futures import ThreadPoolExecutor
     import numpy as np
     from oracle import orb as oracle_orb
-    cores = min(os.cpu_count() or 1, args.cpu_threads)
-    n = min(len(A), cores * args.cpu_pairs_per_thread)
+    host = host_cpu()
+    cores = max(1, min(host["usable"], args.cpu_threads))
     oracle_orb.lib()
+    t0 = time.perf_counter()
+    oracle_orb.FeatureMatcherOracle(args.ratio).MatchFrames(A[0], B[0])
+    one = max(time.perf_counter() - t0, 1e-4)
+    n = int(min(len(A), max(cores * args.cpu_pairs_per_thread, cores * (args.cpu_seconds / one))))
 
     def work(t):
         orc = oracle_orb.FeatureMatcherOracle(args.ratio)
@@ -54,26 +77,30 @@ def cpu_baseline(args, A, B, gpu_lists):
         if gpu_lists is not None and not (len(m) == len(gpu_lists[i]) and np.array_equal(m, gpu_lists[i])):
             mismatches += 1
     return {"value": round(n / dt, 3), "unit": "frame-pairs/sec", "cores": cores, "kind": "port",
-            "sample": "%d of the same %dx%d pairs, oracle/orb_oracle.c (scalar C restatement), one pair per thread, %.1f s"
-                      % (n, args.width, args.height, dt),
-            "parity_mismatches_vs_gpu": mismatches}
+            "sample": "%d of the same %dx%d pairs, oracle/orb_oracle.c (scalar C restatement), one pair per thread, "
+                      "%d unpinned threads, %.1f s" % (n, args.width, args.height, cores, dt),
+            "host": host, "parity_mismatches_vs_gpu": mismatches}
 
 
 def cpu_baseline_loftr(args, A, B, gpu_lists):
     """LoFTR CPU baseline: the C restatement (OpenMP over its convolutions), pairs one after another."""
     import numpy as np
     from oracle import loftr as oracle_loftr
-    cores = oracle_loftr.set_threads(min(os.cpu_count() or 1, args.cpu_threads))
+    host = host_cpu()
+    cores = oracle_loftr.set_threads(max(1, min(host["usable"], args.cpu_threads)))
     orc = oracle_loftr.DNNFeatureMatcherOracle(args.threshold)
-    n = min(len(A), args.cpu_loftr_pairs)
+    t0 = time.perf_counter()
+    orc.MatchFrames(A[0], B[0])
+    one = max(time.perf_counter() - t0, 1e-4)
+    n = int(min(len(A), max(args.cpu_loftr_pairs, args.cpu_seconds / one)))
     t0 = time.perf_counter()
     res = [orc.MatchFrames(A[i], B[i]) for i in range(n)]
     dt = time.perf_counter() - t0
     mism = sum(0 if (len(m) == len(gpu_lists[i]) and np.array_equal(m, gpu_lists[i])) else 1 for i, m in enumerate(res))
     return {"value": round(n / dt, 3), "unit": "frame-pairs/sec", "cores": cores, "kind": "port",
-            "sample": "%d of the same 640x480 pairs, oracle/loftr_oracle.c (f32 C restatement, OpenMP with %d threads), %.1f s"
-                      % (n, cores, dt),
-            "match_list_mismatches_vs_gpu": mism}
+            "sample": "%d of the same 640x480 pairs, oracle/loftr_oracle.c (f32 C restatement, OpenMP with %d unpinned "
+                      "threads), %.1f s" % (n, cores, dt),
+            "host": host, "match_list_mismatches_vs_gpu": mism}
 
 
 def opencv_probe(args, A, B, gpu_lists):
@@ -112,7 +139,7 @@ def opencv_probe(args, A, B, gpu_lists):
             "mean_match_set_jaccard": round(float(np.mean(jacc)), 4)}
 
 
-def run_workload(args, matcher, W, H, P, ratio_or_thr, rank, world, local_rank, dev, cdev, with_cpu):
+def run_workload(args, matcher, W, H, P, ratio_or_thr, loftr_f32, rank, world, local_rank, dev, cdev, with_cpu):
     """One metric configuration: P synthetic pairs per GPU resident in HBM, `warmup` untimed + `steps` timed steps on a
     stream of its own.  Returns the result fields of one JSON line (rank 0) or None."""
     import numpy as np
@@ -130,7 +157,7 @@ def run_workload(args, matcher, W, H, P, ratio_or_thr, rank, world, local_rank, 
         fm = FeatureMatcher(ratio_or_thr, W, H, device=local_rank, max_batch_pairs=P, flags=_lib.MSF_FLAG_PROFILE)
     else:
         fm = DNNFeatureMatcher(threshold=ratio_or_thr, device=local_rank, max_batch_pairs=P,
-                               flags=_lib.MSF_FLAG_PROFILE | (_lib.MSF_FLAG_LOFTR_F32 if args.loftr_f32 else 0))
+                               flags=_lib.MSF_FLAG_PROFILE | (_lib.MSF_FLAG_LOFTR_F32 if loftr_f32 else 0))
     out = torch.zeros((P, args.cap, 4), dtype=torch.int32, device=dev)
     cnt = torch.zeros((P,), dtype=torch.int32, device=dev)
     packed = torch.zeros((P * args.cap, 4), dtype=torch.int32, device=dev)
@@ -140,7 +167,7 @@ def run_workload(args, matcher, W, H, P, ratio_or_thr, rank, world, local_rank, 
     # they are given; one stream in flight per handle: include/msf_abi.h)
     side = torch.cuda.Stream(device=dev)
     stream = side.cuda_stream
-    gather = MatchListGather(P, cdev) if world > 1 else None
+    gather = MatchListGather(P, cdev, capacity_records=P * args.cap) if world > 1 else None
     stage_acc = {}
     gathered = [0]
 
@@ -186,24 +213,29 @@ def run_workload(args, matcher, W, H, P, ratio_or_thr, rank, world, local_rank, 
         stages = {k: v / args.steps for k, v in stage_acc.items()}
         dom = max(stages, key=stages.get) if stages else None
         roofline = None
-        traffic = traffic_record(matcher, dom, P, W, H)
+        traffic = traffic_record("loftr_f32" if loftr_f32 else matcher, dom, P, W, H)
         if dom and matcher == "loftr":
-            # dominant "kernel" = the 22-launch convolution stack (k_conv<...>) of one call
+            # dominant "kernel" = the convolution stack of one call (peak = 157.3 TF where the f32 MFMA is
+            # used, 2.5 PF where the operands are bf16 -- "state which")
             flops = P * (LOFTR_CONV_FLOPS_PER_PAIR if dom == "backbone_convs" else LOFTR_FLOPS_PER_PAIR)
             achieved = flops / (stages[dom] * 1e-3) / 1e12
-            # `frac` keeps its definition (algorithmic f32 FLOPs against the f32 MFMA peak).  In the default build the
-            # ResNet blocks compute each f32 product as three bf16 MFMAs of hi/lo-split operands (f32 accumulation), so
-            # the stack is no longer bound by the f32 matrix pipe but by its HBM traffic: `hbm_frac` prices that.
-            roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 5), "traffic": traffic,
+            peak = MFMA_F32_PEAK_TFLOPS if loftr_f32 else MFMA_BF16_PEAK_TFLOPS
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": peak,
+                        "unit": "TFLOP/s", "frac": round(achieved / peak, 5), "traffic": traffic,
                         "avg_launch_ms": round(stages[dom], 4), "algorithmic_flops_per_launch": flops,
                         "stage_ms": {k: round(v, 4) for k, v in stages.items()},
-                        "pipeline_frac": round(value / world * LOFTR_FLOPS_PER_PAIR / 1e12 / MFMA_F32_PEAK_TFLOPS, 5),
-                        "mfma_form": ("f32 (v_mfma_f32_16x16x4_f32)" if args.loftr_f32 else
-                                      "split-bf16: 3 x v_mfma_f32_16x16x32_bf16 per f32 product in the ResNet blocks and "
-                                      "32-channel layers, f32 MFMA elsewhere"),
+                        "pipeline_frac": round(value / world * LOFTR_FLOPS_PER_PAIR / 1e12 / peak, 5),
+                        "mfma_form": ("f32: v_mfma_f32_16x16x4_f32 everywhere, peak = the f32 matrix rate" if loftr_f32 else
+                                      "split-bf16: each f32 product of the ResNet = 3 x v_mfma_f32_16x16x32_bf16 on hi/lo "
+                                      "operands (f32 accumulation), peak = the dense bf16 matrix rate"),
                         "hbm_frac": (round(traffic["bytes"] / (stages[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-                                     if traffic and not args.loftr_f32 else None)}
+                                     if traffic else None)}
+            if not loftr_f32:
+                # algorithmic FLOPs x 3 = the matrix work actually issued on the split layers; the same time against the
+                # f32 matrix peak is what r01/r02 printed as `frac` (no utilisation figure: the f32 pipe is not used)
+                roofline["issued_frac"] = round(3 * achieved / peak, 5)
+                roofline["f32_equiv_frac"] = round(achieved / MFMA_F32_PEAK_TFLOPS, 5)
+            roofline["mfma_busy"] = mfma_busy_record(dom, P, loftr_f32)
         elif dom:
             # a batch of >= 256 frames is extracted as two pipelined sub-batches: every batch kernel is launched once per
             # part, stage times are sums over the parts, and "per launch" below is per part
@@ -224,7 +256,7 @@ def run_workload(args, matcher, W, H, P, ratio_or_thr, rank, world, local_rank, 
             assert gathered[0] > 0, "rank 0 gathered no match records"
         res = {
             "value": round(value, 2), "ms_per_step": round(ms_per_step, 4),
-            "dtype": "u8" if matcher == "orb" else ("f32" if args.loftr_f32 else "f32 (split-bf16 MFMA products, f32 accumulation)"),
+            "dtype": "u8" if matcher == "orb" else ("f32" if loftr_f32 else "f32 (split-bf16 MFMA products, f32 accumulation)"),
             "config": {"workload": "%s extract+match, %dx%d pairs, %d pairs/GPU/step resident in HBM, %s"
                                    % (matcher.upper(), W, H, P,
                                       "ratio %.2f" % ratio_or_thr if matcher == "orb" else "conf threshold %.2f" % ratio_or_thr),
@@ -268,6 +300,38 @@ def traffic_record(matcher, dom, P, W, H):
             "measured_at": tj.get("_commit")}
 
 
+def mfma_busy_record(dom, P, loftr_f32):
+    """Matrix-pipe utilisation of the dominant stage from the committed counter pass (profiles/traffic_loftr*.json,
+    tools/make_traffic_json.py): sum over the stage's dispatches of SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs
+    x 1024 SIMDs), i.e. the fraction of SIMD-cycles in which a matrix instruction executes.  Not measured inside this
+    run (PMC needs rocprofv3); None when no pass is committed for this variant / batch."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_loftr%s.json" % ("_f32" if loftr_f32 else ""))))
+    except Exception:
+        return None
+    mb = tj.get("_mfma_busy")
+    if not mb or tj.get("_pairs_per_gpu") != P or dom not in mb:
+        return None
+    return {"value": mb[dom], "per_kernel": mb.get("_per_kernel"), "derivation": mb.get("_derivation"),
+            "source": "profiles/traffic_loftr%s.json" % ("_f32" if loftr_f32 else ""), "measured_at": tj.get("_commit")}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) started as a plain process: start the N ranks as a CHILD torch.distributed.run
+    and relay its output -- before anything here has touched the GPU (torch is not even imported in this process)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -286,6 +350,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--cpu-pairs-per-thread", type=int, default=2)
     ap.add_argument("--cpu-loftr-pairs", type=int, default=8)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0,
+                    help="wall time each CPU-baseline leg aims for (its sample is sized from a one-pair calibration)")
     ap.add_argument("--threshold", type=float, default=0.15, help="LoFTR confidence threshold (dnnfeaturematcher.h:11)")
     ap.add_argument("--loftr-f32", action="store_true",
                     help="LoFTR: MSF_FLAG_LOFTR_F32 (every convolution on the f32 MFMA instead of split-bf16 products)")
@@ -295,6 +361,10 @@ def main():
                     help="nccl = RCCL over xGMI (the measured configuration); gloo = rehearsal of the N > 1 code path "
                          "on a box with fewer GPUs than ranks (all ranks share cuda:0, results staged through host)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -302,8 +372,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): one rank per GPU" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     if args.backend == "gloo":
@@ -320,17 +390,26 @@ def main():
 
     with_cpu = not args.no_cpu_baseline and world == 1     # the CPU leg is timed on rank 0 of the 1-GPU run only
     if args.matcher == "loftr":
-        head = ("loftr", 640, 480, args.pairs or 256, args.threshold)
+        head = ("loftr", 640, 480, args.pairs or 256, args.threshold, args.loftr_f32)
     else:
         vga = (args.width, args.height) == (640, 480)
-        head = ("orb", args.width, args.height, args.pairs or (4096 if vga else 1024), args.ratio)
+        head = ("orb", args.width, args.height, args.pairs or (4096 if vga else 1024), args.ratio, False)
     extra = []
     if args.matcher is None and world == 1 and not args.no_secondary and (args.width, args.height) == (1280, 720) \
             and args.pairs is None:
-        extra = [("orb", 640, 480, 4096, args.ratio), ("loftr", 640, 480, 256, args.threshold)]
+        extra = [("orb", 640, 480, 4096, args.ratio, False), ("loftr", 640, 480, 256, args.threshold, False),
+                 ("loftr", 640, 480, 256, args.threshold, True)]     # the exact-f32 LoFTR path, driver-timed too
+    devices = [(local_rank, torch.cuda.get_device_name(local_rank))]
+    if world > 1:
+        gathered_dev = [None] * world
+        dist.all_gather_object(gathered_dev, devices[0])
+        devices = gathered_dev
     r = run_workload(args, *head, rank, world, local_rank, dev, cdev, with_cpu)
-    secondary = [run_workload(args, *w, rank, world, local_rank, dev, cdev, with_cpu) for w in extra]
+    secondary = [run_workload(args, *w, rank, world, local_rank, dev, cdev, with_cpu and not w[5]) for w in extra]
     if rank == 0:
+        r["config"].update({"ranks": world, "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0,
+                            "collective_backend": (args.backend if world > 1 else None),
+                            "rank_devices": ["rank %d: cuda:%d %s" % (i, d[0], d[1]) for i, d in enumerate(devices)]})
         line = {"metric": "frame-pairs/sec (extract+match)", "value": r["value"], "unit": "frame-pairs/sec",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": r["dtype"],

@@ -14,7 +14,9 @@ def shard_pairs(n_pairs_total, rank, world):
 
 
 class MatchListGather:
-    def __init__(self, pairs_per_rank, device, group=None):
+    def __init__(self, pairs_per_rank, device, group=None, capacity_records=0):
+        """capacity_records > 0: rank 0's receive buffers are allocated here, once, for that many match records per
+        rank (a step that stays within it allocates nothing); 0: they grow on demand."""
         self.P = pairs_per_rank
         self.dev = device
         self.group = group
@@ -22,6 +24,9 @@ class MatchListGather:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.all_offs = torch.zeros((self.world * (self.P + 1),), dtype=torch.int32, device=device)
         self.recv = [None] * self.world
+        if capacity_records > 0 and self.rank == 0:
+            for r in range(1, self.world):
+                self.recv[r] = torch.empty((capacity_records, 4), dtype=torch.int32, device=device)
 
     def __call__(self, packed, offsets):
         """packed int32 [>= total, 4], offsets int32 [P + 1] (offsets[P] = total), both on self.dev.
@@ -30,7 +35,9 @@ class MatchListGather:
             return [(packed[:int(offsets[self.P])], offsets)]
         dist.all_gather_into_tensor(self.all_offs, offsets.contiguous(), group=self.group)
         offs = self.all_offs.view(self.world, self.P + 1)
-        totals = offs[:, self.P].tolist()           # one small D2H read per step
+        # one small D2H read per step: exact-size send / recv need the totals on the host (the alternative, a padded
+        # all-gather of capacity-sized lists, moves cap / mean-length = ~10x the bytes over xGMI)
+        totals = offs[:, self.P].tolist()
         ops = []
         if self.rank == 0:
             for r in range(1, self.world):

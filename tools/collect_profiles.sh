@@ -5,7 +5,7 @@
 # Outputs land under gpurun_out/prof_<tag>/ ; tools/pmc_summary.py + tools/make_traffic_json.py digest them.
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT
 mkdir -p $OUT
@@ -17,5 +17,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/loftr_stats -- pyth
 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/orb_fetch -- python3 $R/bench.py $ORB > $OUT/orb_fetch.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/orb_write -- python3 $R/bench.py $ORB > $OUT/orb_write.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/loftr_fetch -- python3 $R/bench.py $LOF > $OUT/loftr_fetch.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/loftr_write -- python3 $R/bench.py $LOF > $OUT/loftr_write.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT/loftr_write -- python3 $R/bench.py $LOF > $OUT/loftr_write.log 2>&1 || exit 1
+if [ "$2" = "f32" ]; then
+rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/loftr_f32_fetch -- python3 $R/bench.py $LOF --loftr-f32 > $OUT/loftr_f32_fetch.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT/loftr_f32_write -- python3 $R/bench.py $LOF --loftr-f32 > $OUT/loftr_f32_write.log 2>&1 || exit 1
+fi
 echo collected

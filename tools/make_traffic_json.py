@@ -34,9 +34,37 @@ def load(d, steps):
     return acc
 
 
+MFMA_DERIVATION = ("sum over the stage's dispatches of SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024): "
+                   "SQ_VALU_MFMA_BUSY_CYCLES counts, summed over the 1024 SIMDs, the cycles in which a matrix instruction "
+                   "executes; GRBM_GUI_ACTIVE is the sum of the 8 XCDs' active cycles; both from ONE rocprofv3 --pmc pass "
+                   "(<which>_write), so the fraction is matrix-pipe busy SIMD-cycles over available SIMD-cycles")
+
+
+def mfma_busy(write):
+    """per stage and per kernel: MFMA-busy SIMD-cycles over available SIMD-cycles (None without the counters)"""
+    num, den, per_kernel = collections.defaultdict(float), collections.defaultdict(float), {}
+    for k, c in write.items():
+        if "SQ_VALU_MFMA_BUSY_CYCLES" not in c or "GRBM_GUI_ACTIVE" not in c or c["GRBM_GUI_ACTIVE"] <= 0:
+            continue
+        avail = c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+        per_kernel[k] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / avail, 4)
+        st = STAGE.get(k)
+        if st:
+            num[st] += c["SQ_VALU_MFMA_BUSY_CYCLES"]
+            den[st] += avail
+    if not den:
+        return None
+    out = {s: round(num[s] / den[s], 4) for s in den}
+    out["_per_kernel"] = {k: v for k, v in per_kernel.items() if v > 0}
+    out["_derivation"] = MFMA_DERIVATION
+    return out
+
+
 def main(tag="r02", steps=6):
     base = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
-    for which in ("orb", "loftr"):
+    for which in ("orb", "loftr", "loftr_f32"):
+        if not os.path.isdir(os.path.join(base, which + "_fetch")):
+            continue
         fetch, write = load(os.path.join(base, which + "_fetch"), steps), load(os.path.join(base, which + "_write"), steps)
         stages = collections.defaultdict(lambda: {"fetch_kb_raw": 0.0, "write_kb": 0.0})
         for k in sorted(set(fetch) | set(write)):
@@ -49,6 +77,9 @@ def main(tag="r02", steps=6):
                 stages[st]["write_kb"] += wk
         out = {s: int((2 * v["fetch_kb_raw"] + v["write_kb"]) * 1024) for s, v in stages.items()}
         out["_raw"] = {s: {"FETCH_SIZE_KB": v["fetch_kb_raw"], "WRITE_SIZE_KB": v["write_kb"]} for s, v in stages.items()}
+        mb = mfma_busy(write)
+        if mb:
+            out["_mfma_busy"] = mb
         out["_pairs_per_gpu"] = 1024 if which == "orb" else 256   # the bench defaults the passes were run with
         out["_width"] = 1280 if which == "orb" else 640
         try:
