@@ -239,8 +239,8 @@ def run_workload(args, matcher, W, H, P, ratio_or_thr, loftr_f32, rank, world, l
         elif dom:
             # a batch of >= 256 frames is extracted as two pipelined sub-batches: every batch kernel is launched once per
             # part, stage times are sums over the parts, and "per launch" below is per part
-            # ... and the streaming FAST kernel runs twice per extraction (a quarter of the strips, then the rest)
-            launches = fm.extract_parts(2 * P) * (fm.fast_stream_parts() if dom == "fast_nms" else 1)
+            # ... and the fused pyramid + FAST walker runs once per source level (7 launches per extraction)
+            launches = fm.extract_parts(2 * P) * fm.walker_launches(dom)
             achieved = P * bpp / (stages[dom] * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom,
                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

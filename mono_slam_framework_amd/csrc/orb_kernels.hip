@@ -463,10 +463,10 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
   fast_tile(g, src, pyr, fi, l, bt - g.lv[l].tile_base, kFastT, cand_cnt, cand_key, cand_sc, sm);
 }
 
-// ------------------------------------------------------------------ K3+K4, streaming form for tau well above fastThreshold
+// ------------------------------------------------------------------ K2+K3+K4, streaming form: one wave walks a column strip
 // The tile kernels above are bound by workgroup dispatch and by their barriers once the scoring work is gone (measured:
 // 1.9 ms to dispatch the 10^6 tiles of a 1024-pair batch, 6 ms of phase latency).  Here ONE WAVE walks a column strip
-// of the level, 248 px wide (lanes 1..62 hold 4 px each, lanes 0 and 63 the halo), top to bottom, with no barrier:
+// of a level, a 256-px window (lane i holds 4 px), top to bottom, with no barrier:
 //  * every pixel is fetched once, as one dword per lane and row, four rows ahead of its use (register queue q0..q3);
 //  * the rows live in a wave-private LDS ring of 16 rows;
 //  * the cardinal prefilter of row y reads rows y-3, y, y+3 from the ring, the left / right dwords come by DPP;
@@ -476,11 +476,29 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
 //    runByImageBorder run over the hits whose three score rows are final; kept corners are buffered and appended to
 //    the level's candidate list with one global atomic per buffer flush.
 // Emits exactly the maxima with score >= tau of the strip's pixels, like fast_tile(tau).
+//
+// RESIZE (r03): the strips cover the whole level and the walker of level l - 1 also MAKES level l (K2,
+// cv::resize INTER_LINEAR_EXACT as in k_resize, the same host tables): the source rows it needs are the rows in its
+// ring.  A lane owns one group of 4 output columns whose taps lie inside the strip's window; when source row y arrives
+// the lane forms its four horizontal 8.8 sums from the ring (two 8-byte LDS reads, v_perm, v_dot2), and if an output
+// row Y has rows (y - 1, y) as its taps it blends them with the previous row's sums and stores one dword.  Every pixel
+// of level l - 1 is then read from HBM once per step (plus the strips' halos) instead of once by k_resize and once by
+// the FAST pass: 17.2 -> 10.5 GB per 1024-pair 720p step for pyramid + FAST.
+//
+// Threshold refinement inside the launch (was: two launches with k_fast_tau2 between them).  The strips whose flat index
+// is a multiple of 4 -- a quarter of the level, spread over it -- come first in the launch order and run at the
+// sampler's tau; each adds the scores of the corners it emitted to a per-(frame, level) histogram and counts itself
+// done.  A strip of the other three quarters that finds the quarter complete when it starts raises tau to the largest
+// multiple of 4 at which the quarter still holds margin % of its share of 2N (k_fast_tau2's rule) and publishes it with
+// an atomic max; one that does not (dispatch order is no contract) runs at the value it read.  Whatever a strip read,
+// it finds every maximum >= its own tau, so every maximum >= the final tau[idx] (the maximum over the strips) is in the
+// list; k_fast_check counts those and a level that falls short is redone densely: the result is the dense one bit for
+// bit in every interleaving.
 constexpr int kTauBins = 64;             // score histogram bins of width 4 (k_fast_tau's sample, the emitted corners)
-constexpr int SR = 64;                   // output rows per strip
+constexpr int kQStat = kTauBins + 2;     // per (slot, level): the quarter's histogram, its strips done, spare
 constexpr int RK = 16;                   // ring rows (power of two)
-constexpr int SPX = 248;                 // output px per strip
-constexpr int kSX0 = 24;                 // x of lane 0's first px in strip 0: lane 1 then holds px 28..31
+constexpr int kWkMaxPx = 244;            // strip pitch <= 244: a group of 4 output px reads two aligned 8-byte pairs <= 8 B apart
+constexpr int kWkRowsTarget = 80, kWkMaxRows = 112;   // owned rows per strip (the emit table of a strip lives in two registers per lane)
 constexpr int kSGCap = 288, kSPCap = 256, kSHCap = 64, kSOCap = 48;   // 10 224 B of LDS per wave: 16 waves per CU
 constexpr uint32_t kSGFlush = 32;        // records that trigger a flush at the end of a four-step group (<= 4 x 64 more arrive)
 static_assert(kSGCap >= (int)kSGFlush + 256, "record list capacity");
@@ -491,6 +509,8 @@ constexpr uint32_t kFlagGather = (1u << 24) | (1u << 18) | (1u << 12) | (1u << 6
 // score rows >= last_flush - 1: the flush interval (a multiple of the four-step group) must stay below 11 rows.
 constexpr int kFlushRows = 8;
 static_assert(kFlushRows < RK - 5 && kFlushRows % 4 == 0, "ring too short for the flush interval");
+constexpr int kTau2MarginPct = 200, kTau2MinStrips = 2;
+constexpr int kTau2MarginPctMany = 150, kTau2ManyStrips = 8;
 
 struct StreamSmem {
   __attribute__((aligned(16))) uint8_t px[RK * 256];
@@ -526,69 +546,169 @@ __device__ __forceinline__ int stream_score(const uint8_t* ring, uint32_t r0, ui
   return A > tau ? A - 1 : 0;
 }
 
-// phase: -1 = every strip; 0 = the sampled quarter (flat strip index % 4 == 0, n_part of them per frame) at the sampler's
-// tau; 1 = the other strips at the threshold k_fast_tau2 derives from the quarter's corners (see there).
-__global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
-                                                    const uint32_t* __restrict__ tau, uint32_t* cand_cnt,
-                                                    uint32_t* cand_key, uint8_t* cand_sc, int phase, int n_part) {
+// Launch over the strips of levels [l_lo, l_hi] of n_frames frames.  Workgroups b, b + 8, ... share an XCD (observed
+// placement, speed only): XCD x takes the frames [x n / 8, (x + 1) n / 8) and runs first the sampled quarter of all their
+// strips, then the rest, so the lines neighbouring strips share stay in one L2 and a frame's quarter is long done when
+// its other strips start.  dyn = 0: no refinement (forced threshold, MSF_ORB_FAST_ONE_PART).  part = -1: all strips;
+// 0 / 1: only the sampled quarter / only the rest (small launches, whose strips would all start together, run as two).
+template <bool RESIZE>
+__global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_t* pyr, const uint32_t* __restrict__ tab,
+                                             uint32_t* tau, uint32_t* qstat, uint32_t* cand_cnt, uint32_t* cand_key,
+                                             uint8_t* cand_sc, int l_lo, int l_hi, int n_frames, int margin_pct, int dyn,
+                                             int part) {
   __shared__ StreamSmem sm;
-  int G;
+  const int lane = threadIdx.x;
+  int fi, t;
+  bool quarter;
   {
-    const uint32_t total = gridDim.x, lin = blockIdx.x;
-    const uint32_t xcd = lin & 7u, q = total >> 3, r = total & 7u;
-    G = (int)(xcd * q + (xcd < r ? xcd : r) + (lin >> 3));
+    const int xcd = (int)(blockIdx.x & 7u), u = (int)(blockIdx.x >> 3);
+    const int nf8 = n_frames >> 3, nrem = n_frames & 7;
+    const int nfx = nf8 + (xcd < nrem ? 1 : 0), f0 = xcd * nf8 + (xcd < nrem ? xcd : nrem);
+    const int S = g.lv[l_hi].wk_base + g.lv[l_hi].wk_nx * g.lv[l_hi].wk_ny - g.lv[l_lo].wk_base;
+    const int Sq = (S + 3) >> 2, Sr = S - Sq;
+    const int nq = part == 1 ? 0 : nfx * Sq;     // quarter units of this XCD in this launch
+    if (u < nq) {
+      fi = f0 + u / Sq;
+      t = 4 * (u % Sq);
+      quarter = true;
+    } else {
+      const int u2 = u - nq;
+      if (part == 0 || u2 >= nfx * Sr) return;
+      fi = f0 + u2 / Sr;
+      const int ip = u2 % Sr;
+      t = 4 * (ip / 3) + ip % 3 + 1;
+      quarter = false;
+    }
   }
-  const int fi = G / n_part, ip = G - fi * n_part;
-  const int bt = phase < 0 ? ip : phase == 0 ? 4 * ip : 4 * (ip / 3) + ip % 3 + 1;
-  int l = 0;
+  const int tb = t + g.lv[l_lo].wk_base;        // flat strip index over all levels
+  int l = l_lo;
 #pragma unroll
   for (int i = 1; i < kOrbLevels; i++)
-    if (i < g.nlevels && bt >= g.lv[i].strip_base) l = i;
-  const int slot = src.slot0 + fi;
-  const int tv = (int)tau[slot * kOrbLevels + l];
-  if (tv <= kFastT) return;
+    if (i > l_lo && i <= l_hi && tb >= g.lv[i].wk_base) l = i;
   const OrbLevelInfo L = g.lv[l];
-  const int t = bt - L.strip_base;
-  const int sy = t / L.strips_x, sx = t - sy * L.strips_x;
-  const int lane = threadIdx.x;
+  const int slot = src.slot0 + fi, idx = slot * kOrbLevels + l;
+  const int ts = tb - L.wk_base;
+  const int sy = ts / L.wk_nx, sx = ts - sy * L.wk_nx;
+  uint32_t* const qs = qstat + (size_t)idx * kQStat;
+  // strips of this level in the sampled quarter of this launch
+  const int rel0 = L.wk_base - g.lv[l_lo].wk_base, n_strips = L.wk_nx * L.wk_ny;
+  const int qa = (rel0 + n_strips + 3) / 4 - (rel0 + 3) / 4;
+  const bool count_me = dyn && quarter;          // single exit below: a quarter strip always reports itself done
+
+  // ---- geometry of the strip
+  const int xs = sx * L.wk_px;                    // x of lane 0's first px (multiple of 4)
+  const int xb = xs + 4 * lane;
+  const int R0 = sy * L.wk_rows, R1 = min(R0 + L.wk_rows, L.h);      // owned rows
+  // FAST outputs: owned rows inside the 31-px border; a FAST-only walk covers just those
+  const int ya = RESIZE ? R0 : max(R0, kEdge), yb = RESIZE ? R1 : min(R1, L.h - kEdge);
+  const int ox0 = sx == 0 ? 0 : xs + 4, ox1 = sx == L.wk_nx - 1 ? L.w : xs + 4 + L.wk_px;   // owned columns
+  const int y0 = ya - 1;                          // rel row r = y - y0; rel row 0 is the NMS neighbour of row ya
   int pitch;
   const uint8_t* img = level_ptr(g, src, pyr, fi, l, &pitch);
+  // lanes right of the row's end re-read its last dword (weight-0 taps, never scored); rows outside the image re-read
+  // its first / last row (warm-up above row 0, the idle tail steps, the weight-0 lower tap of the last output row)
+  const uint8_t* gp = img + (xb + 4 <= pitch ? xb : pitch - 4);
+  const int ylim = L.h - 1;
+#define LOAD_ROW(y_) (*reinterpret_cast<const uint32_t*>(gp + (long long)max(min((y_), ylim), 0) * pitch))
+  // the first ten pixel rows are requested before anything else: the state of the (frame, level) below is one more
+  // memory latency, and the two overlap (they were serial: +10 us on a 40-us strip)
+  uint32_t w0_ = LOAD_ROW(y0 - 3), w1_ = LOAD_ROW(y0 - 2), w2_ = LOAD_ROW(y0 - 1), w3_ = LOAD_ROW(y0), w4_ = LOAD_ROW(y0 + 1),
+           w5_ = LOAD_ROW(y0 + 2);
+  uint32_t q0 = LOAD_ROW(y0 + 3), q1 = LOAD_ROW(y0 + 4), q2 = LOAD_ROW(y0 + 5), q3 = LOAD_ROW(y0 + 6);
+
+  // ---- threshold: the sampler's, raised from the quarter's exact corners when they are all in.  The whole state of the
+  // (frame, level) -- 64 bins, strips done, threshold in force -- comes in with two independent loads (one latency).
+  const uint32_t qv = __hip_atomic_load(&qs[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t qx = __hip_atomic_load(&qs[kTauBins + (lane & 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int tv = (int)__builtin_amdgcn_readlane((int)qx, 1);
+  if (dyn && !quarter && tv > kFastT && qa >= kTau2MinStrips) {
+    const uint32_t done = (uint32_t)__builtin_amdgcn_readlane((int)qx, 0);
+    if (done >= (uint32_t)qa) {     // uniform
+      uint32_t c = qv;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {   // suffix sums: c = corners of the quarter with score >= 4 * lane
+        const uint32_t up = __shfl_down(c, o);
+        if (lane + o < 64) c += up;
+      }
+      // a level with many sampled strips gives a steadier estimate and takes the smaller margin; an explicit
+      // MSF_ORB_TAU2_MARGIN_PCT applies to every level
+      const uint32_t mp = (qa >= kTau2ManyStrips && margin_pct == kTau2MarginPct) ? (uint32_t)kTau2MarginPctMany : (uint32_t)margin_pct;
+      const uint32_t den = 100u * (uint32_t)n_strips;
+      const uint32_t need = (mp * 2u * (uint32_t)L.quota * (uint32_t)qa + den - 1u) / den;
+      const unsigned long long ok = __ballot(c >= need && 4 * lane >= tv);
+      if (ok) {
+        const int t2 = 4 * (63 - __builtin_clzll(ok));
+        if (t2 > tv) {
+          tv = t2;
+          if (lane == 0) atomicMax(&qs[kTauBins + 1], (uint32_t)t2);
+        }
+      }
+    }
+  }
+  const bool do_fast = tv > kFastT && L.tiles_x > 0;   // tau = fastThreshold: the level goes to the dense tile kernel
+  const bool empty = !RESIZE && (!do_fast || ya >= yb || max(ox0, kEdge) >= min(ox1, L.w - kEdge));
+  if (!empty) {
+  const int r_last = yb - y0;                     // last rel row that can be scored (NMS neighbour of row yb - 1)
+  // rows that are scored lie in [30, h - 30), rows that are output in [31, h - 31)
+  const int s_lo = max(0, kEdge - 1 - y0), s_hi = min(r_last, L.h - kEdge - y0);
+  const int o_lo = max(1, kEdge - y0), o_hi = min(r_last, L.h - kEdge - y0);      // output rel rows [o_lo, o_hi)
+  uint32_t vm = 0, om = 0;
+  if (do_fast) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int x = xb + j;
+      // scored: owned columns and their NMS neighbours, with the 3-px ring inside the window
+      if (x >= max(ox0 - 1, kEdge - 1) && x < min(ox1 + 1, L.w - (kEdge - 1)) && x >= xs + 3 && x < xs + 253) vm |= 0x80u << (8 * j);
+      if (x >= max(ox0, kEdge) && x < min(ox1, L.w - kEdge)) om |= 0x80u << (8 * j);
+    }
+  }
+  const int ox_lo = max(ox0, kEdge), ox_hi = min(ox1, L.w - kEdge);
   const uint32_t lerp_bright = 0x01010101u * (uint32_t)(128 - tv / 2);
   const uint32_t lerp_not_dark = 0x01010101u * (uint32_t)(255 - (254 - tv) / 2);
-  uint32_t* const out_cnt = cand_cnt + slot * kOrbLevels + l;
+  uint32_t* const out_cnt = cand_cnt + idx;
   uint32_t* const outk = cand_key + (long long)slot * g.cand_total + L.cand_off;
   uint8_t* const outs = cand_sc + (long long)slot * g.cand_total + L.cand_off;
   const uint32_t out_cap = (uint32_t)L.cand_cap;
-  const int lw = L.w;
-
-  const int xs = kSX0 + SPX * sx;                 // x of lane 0's first px
-  const int xb = xs + 4 * lane;
-  const int ya = kEdge + SR * sy, yb = min(ya + SR, L.h - kEdge);   // output rows [ya, yb)
-  const int y0 = ya - 1;                          // first scored row (NMS neighbour of row ya); rel row r = y - y0
-  const int r_last = yb - y0;                     // last scored row (NMS neighbour of row yb - 1)
-  // scored domain of this lane's 4 px: [30, w-30), halo lanes score only the px next to the strip
-  uint32_t vm = 0, om = 0;
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int x = xb + j;
-    const bool in_lane = (lane >= 1 && lane <= 62) || (lane == 0 && j == 3) || (lane == 63 && j == 0);
-    if (in_lane && x >= kEdge - 1 && x < L.w - (kEdge - 1)) vm |= 0x80u << (8 * j);
-    if (lane >= 1 && lane <= 62 && x >= kEdge && x < L.w - kEdge) om |= 0x80u << (8 * j);
-  }
-  // lanes right of the row's end re-read its last dword (never used: vm = 0 there); rows past the image re-read the
-  // last row (only in the idle tail steps after r_last)
-  const uint8_t* gp = img + (xb + 4 <= pitch ? xb : pitch - 4);
-  const int ylim = L.h - 1;
   uint32_t* pxw = reinterpret_cast<uint32_t*>(sm.px);
   uint32_t* scw = reinterpret_cast<uint32_t*>(sm.sc);
   uint8_t* pxb = sm.px;
   uint8_t* scb = sm.sc;
 
+  // ---- resize state: this lane's group of 4 output columns of level l + 1
+  uint32_t rsel[4] = {0, 0, 0, 0}, rwxp[4] = {0, 0, 0, 0}, roff0 = 0, roff3 = 0, em_lo = 0, em_hi = 0;
+  uint8_t* dcol = nullptr;
+  bool rz_lane = false;
+  int dpitch = 0;
+  if (RESIZE) {
+    const OrbLevelInfo Ld = g.lv[l + 1];
+    const int groups = (Ld.w + 3) >> 2;
+    const uint4* xsel = reinterpret_cast<const uint4*>(tab + Ld.tab_off);
+    const uint4* xwxp = xsel + groups;
+    const uint4* xoff = xwxp + groups;
+    const uint32_t* xstrip = tab + Ld.tab_xstrip;
+    const uint32_t* yemit = tab + Ld.tab_yemit;
+    const int g_first = (int)xstrip[sx], g_end = (int)xstrip[sx + 1];
+    const int gq = min(g_first + lane, groups - 1);
+    rz_lane = g_first + lane < g_end;
+    const uint4 qsv = xsel[gq], qwv = xwxp[gq], qov = xoff[gq];
+    rsel[0] = qsv.x; rsel[1] = qsv.y; rsel[2] = qsv.z; rsel[3] = qsv.w;
+    rwxp[0] = qwv.x; rwxp[1] = qwv.y; rwxp[2] = qwv.z; rwxp[3] = qwv.w;
+    // pair offsets relative to the window (host-checked: 0 <= off <= 248 for the groups of this strip)
+    roff0 = rz_lane ? qov.x - (uint32_t)xs : 0u;
+    roff3 = rz_lane ? qov.w - (uint32_t)xs : 0u;
+    dpitch = Ld.pitch;
+    dcol = pyr + (long long)slot * g.pyr_bytes + Ld.pix_off + 4 * gq;
+    // emit entries of the source rows R0 - 4 + j, j = lane (em_lo) and 64 + lane (em_hi): output row | w1 << 16 | 1 << 31
+    // if an output row has source rows (y, y + 1) as its taps and y is owned by this strip
+    const int ra = R0 - 4 + lane, rb = ra + 64;
+    if (ra >= R0 && ra < R1) em_lo = yemit[ra];
+    if (rb >= R0 && rb < R1) em_hi = yemit[rb];
+  }
+
   // wave-uniform state
   uint32_t nG = 0, nH = 0, nO = 0;
   int nms_lo = 1, last_flush = -1;               // first rel row whose NMS is pending; rel row of the last flush
 
-#define LOAD_ROW(y_) (*reinterpret_cast<const uint32_t*>(gp + (long long)min((y_), ylim) * pitch))
   // pixel row with ring index k (= rel row + 3) -> ring row k & 15; its score row is zeroed
 #define PUT_ROW(k_, v_)                                                                      \
   do {                                                                                       \
@@ -596,17 +716,47 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
     pxw[sl_ * 64 + lane] = (v_);                                                             \
     scw[sl_ * 64 + lane] = 0u;                                                               \
   } while (0)
+  // the lane's four horizontal 8.8 sums of the pixel row with ring index k: w0 * p[cx] + w1 * p[cx + 1] per output column
+#define RZ_HSUM(k_, h_)                                                                                                \
+  do {                                                                                                                 \
+    const uint8_t* rr_ = pxb + (((k_) & (RK - 1)) << 8);                                                               \
+    const uint32_t* pa_ = reinterpret_cast<const uint32_t*>(rr_ + roff0);                                              \
+    const uint32_t* pb_ = reinterpret_cast<const uint32_t*>(rr_ + roff3);                                              \
+    const uint32_t a0_ = pa_[0], a1_ = pa_[1], b0_ = pb_[0], b1_ = pb_[1];                                             \
+    h_[0] = udot2_u16(__builtin_amdgcn_perm(a1_, a0_, rsel[0]), rwxp[0], 0u);                                          \
+    h_[1] = udot2_u16(__builtin_amdgcn_perm(a1_, a0_, rsel[1]), rwxp[1], 0u);                                          \
+    h_[2] = udot2_u16(__builtin_amdgcn_perm(a1_, a0_, rsel[2]), rwxp[2], 0u);                                          \
+    h_[3] = udot2_u16(__builtin_amdgcn_perm(b1_, b0_, rsel[3]), rwxp[3], 0u);                                          \
+  } while (0)
+  // j_ = index of the UPPER source row in the strip's emit table (row R0 - 4 + j_); hu_ / hl_ = sums of the upper / lower row
+#define RZ_EMIT(j_, hu_, hl_)                                                                                          \
+  do {                                                                                                                 \
+    const int jj_ = (j_);                                                                                              \
+    const uint32_t em_ = jj_ < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)em_lo, jj_ & 63)                          \
+                                  : (uint32_t)__builtin_amdgcn_readlane((int)em_hi, jj_ & 63);                         \
+    if ((int)em_ < 0) {                                                                                                \
+      const uint32_t wy1_ = (em_ >> 16) & 0x1FFu, wy0_ = 256u - wy1_;                                                  \
+      const uint32_t v0_ = mad_u24(hu_[0], wy0_, mad_u24(hl_[0], wy1_, 32768u));                                       \
+      const uint32_t v1_ = mad_u24(hu_[1], wy0_, mad_u24(hl_[1], wy1_, 32768u));                                       \
+      const uint32_t v2_ = mad_u24(hu_[2], wy0_, mad_u24(hl_[2], wy1_, 32768u));                                       \
+      const uint32_t v3_ = mad_u24(hu_[3], wy0_, mad_u24(hl_[3], wy1_, 32768u));                                       \
+      const uint32_t pk_ = __builtin_amdgcn_perm(v1_, v0_, 0x0c0c0602u) | __builtin_amdgcn_perm(v3_, v2_, 0x06020c0cu); \
+      if (rz_lane) *reinterpret_cast<uint32_t*>(dcol + (long long)(em_ & 0xFFFFu) * dpitch) = pk_;                     \
+    }                                                                                                                  \
+  } while (0)
 
   auto flush_out = [&]() {
     if (nO == 0) return;
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(out_cnt, nO);
     base = __builtin_amdgcn_readfirstlane(base);
-    for (uint32_t i = lane; i < nO; i += 64)
+    for (uint32_t i = lane; i < nO; i += 64) {
       if (base + i < out_cap) {
         outk[base + i] = sm.okey[i];
         outs[base + i] = sm.osc[i];
       }
+      if (count_me) atomicAdd(&qs[sm.osc[i] >> 2], 1u);     // the quarter's exact scores: what the other strips refine tau from
+    }
     MSF_WAVE_SYNC();
     nO = 0;
   };
@@ -701,8 +851,7 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
           const uint8_t* qd = scb + (((row + 1) & (RK - 1)) << 8) + xl;
           c = qc[0];
           const int x = xs + (int)xl, y = y0 + rr;
-          keep = rr >= nms_lo && rr <= hi && rr >= 1 && rr < r_last && xl >= 4u && xl < 252u && x >= kEdge &&
-                 x < lw - kEdge;
+          keep = rr >= nms_lo && rr <= hi && rr >= o_lo && rr < o_hi && x >= ox_lo && x < ox_hi;
           keep = keep && c > qc[-1] && c > qc[1] && c > qu[-1] && c > qu[0] && c > qu[1] && c > qd[-1] && c > qd[0] &&
                  c > qd[1];
           key = ((uint32_t)y << 16) | (uint32_t)x;
@@ -711,12 +860,12 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
       }
     } else {
       for (int rr = nms_lo; rr <= hi; rr++) {
-        if (rr < 1 || rr >= r_last) continue;
+        if (rr < o_lo || rr >= o_hi) continue;
         const int row = (rr + 3) & (RK - 1);
         const int w = (row << 6) + lane, wu = (((row + RK - 1) & (RK - 1)) << 6) + lane, wd = (((row + 1) & (RK - 1)) << 6) + lane;
         const uint32_t C = scw[w];
         if (__ballot(C != 0u) == 0ull) continue;
-        // left / right dwords by DPP: the halo lanes' own neighbours are never output (om = 0 there)
+        // left / right dwords by DPP: the window's edge lanes' outer neighbours are never output (om = 0 there)
         const uint32_t U = scw[wu], D = scw[wd];
 #define SHR1(v_) __builtin_amdgcn_update_dpp(0u, (v_), 0x138, 0xf, 0xf, true)
 #define SHL1(v_) __builtin_amdgcn_update_dpp(0u, (v_), 0x130, 0xf, 0xf, true)
@@ -759,14 +908,15 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
   };
 
   // warm-up: pixel rows y0 - 3 .. y0 + 2 (ring indices 0 .. 5), then the queue holds rows y0 + 3 .. y0 + 6
-  {
-    uint32_t v[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) v[k] = LOAD_ROW(y0 - 3 + k);
-#pragma unroll
-    for (int k = 0; k < 6; k++) PUT_ROW(k, v[k]);
+  PUT_ROW(0, w0_); PUT_ROW(1, w1_); PUT_ROW(2, w2_); PUT_ROW(3, w3_); PUT_ROW(4, w4_); PUT_ROW(5, w5_);
+  // resize: rows R0 = y0 + 1 (ring index 4) and R0 + 1 (index 5) are in; the output row (if any) between them goes out
+  uint32_t hp[4] = {0, 0, 0, 0};                  // sums of the newest row handled
+  if (RESIZE) {
+    uint32_t hu[4];
+    RZ_HSUM(4, hu);
+    RZ_HSUM(5, hp);
+    RZ_EMIT(4, hu, hp);                           // upper row R0 = table entry 4
   }
-  uint32_t q0 = LOAD_ROW(y0 + 3), q1 = LOAD_ROW(y0 + 4), q2 = LOAD_ROW(y0 + 5), q3 = LOAD_ROW(y0 + 6);
   // One group = four rel rows s .. s+3, in three straight-line parts so that the four rows' dependent chains overlap
   // (a wave has 4 x the instruction-level parallelism of one row at a time; the kernel is latency-bound):
   //  1. the four queued rows (row + 3 of each step) go to the ring and their queue slots are refilled four rows ahead
@@ -787,7 +937,7 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
     const uint32_t b8_ = __builtin_amdgcn_lerp(l8_, lerp_bright, 0), b12_ = __builtin_amdgcn_lerp(l12_, lerp_bright, 0);   \
     const uint32_t n0_ = __builtin_amdgcn_lerp(l0_, lerp_not_dark, 0), n4_ = __builtin_amdgcn_lerp(l4_, lerp_not_dark, 0); \
     const uint32_t n8_ = __builtin_amdgcn_lerp(l8_, lerp_not_dark, 0), n12_ = __builtin_amdgcn_lerp(l12_, lerp_not_dark, 0); \
-    const uint32_t vmr_ = (s_) <= r_last ? vm : 0u;                    /* rows past the strip's last scored row */      \
+    const uint32_t vmr_ = ((s_) >= s_lo && (s_) <= s_hi) ? vm : 0u;      /* rows outside the strip's scored rows */       \
     cb_ = ((b0_ | b8_) & (b4_ | b12_)) & vmr_;                                                                         \
     cd_ = ~((n0_ & n8_) | (n4_ & n12_)) & vmr_;                                                                        \
   } while (0)
@@ -811,6 +961,21 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
     const uint32_t u0 = pxw[((s) & (RK - 1)) * 64 + lane], u1 = pxw[((s + 1) & (RK - 1)) * 64 + lane];
     const uint32_t u2 = pxw[((s + 2) & (RK - 1)) * 64 + lane], u3 = pxw[((s + 3) & (RK - 1)) * 64 + lane];   // = c0
     const uint32_t c1 = pxw[((s + 4) & (RK - 1)) * 64 + lane], c2 = pxw[((s + 5) & (RK - 1)) * 64 + lane];
+    if (RESIZE) {
+      // the four rows just stored are source rows y0 + s + 3 .. y0 + s + 6 = R0 + s + 2 .. (table entries s + 6 ..);
+      // an output row between rows (y - 1, y) has the UPPER row's entry: s + 5 .. s + 8
+      uint32_t ha[4], hb[4], hc[4], hd[4];
+      RZ_HSUM(s + 6, ha);
+      RZ_HSUM(s + 7, hb);
+      RZ_HSUM(s + 8, hc);
+      RZ_HSUM(s + 9, hd);
+      RZ_EMIT(s + 5, hp, ha);
+      RZ_EMIT(s + 6, ha, hb);
+      RZ_EMIT(s + 7, hb, hc);
+      RZ_EMIT(s + 8, hc, hd);
+#pragma unroll
+      for (int k = 0; k < 4; k++) hp[k] = hd[k];
+    }
     uint32_t cb0, cd0, cb1, cd1, cb2, cd2, cb3, cd3;
     STREAM_PRE(u0, u3, d0, s, cb0, cd0);
     STREAM_PRE(u1, c1, d1, s + 1, cb1, cd1);
@@ -822,7 +987,7 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
     STREAM_APPEND(s + 3, cb3, cd3);
     const int sl = min(s + 3, r_last);
     // flushes happen between groups of four steps: at most kSGFlush + 4 x 64 records wait (kSGCap), at most 8 rows
-    if (nG > kSGFlush || sl - last_flush >= kFlushRows || sl == r_last) {
+    if (do_fast && (nG > kSGFlush || sl - last_flush >= kFlushRows || sl == r_last)) {
       MSF_WAVE_SYNC();
       flush(sl);
     }
@@ -832,6 +997,14 @@ __global__ __launch_bounds__(64) void k_fast_stream(OrbGeometry g, FrameSrc src,
   flush_out();
 #undef LOAD_ROW
 #undef PUT_ROW
+#undef RZ_HSUM
+#undef RZ_EMIT
+  }
+  if (count_me) {
+    // every histogram add of this strip is complete before the strip counts as done (agent-scope atomics both sides)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) atomicAdd(&qs[kTauBins], 1u);
+  }
 }
 
 // ------------------------------------------------------------------ output-sensitive FAST: threshold estimate, check, redo
@@ -883,12 +1056,15 @@ constexpr int kTauListCap = 2048;     // prefilter survivors kept per (frame, le
                                       // lower, still valid, tau)
 __global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, const uint8_t* pyr, int force_tau,
                                                   uint32_t* tau, uint32_t* tau_first, uint32_t* redo_cnt,
-                                                  uint32_t* redo_list, int level0) {
+                                                  uint32_t* redo_list, int level0, uint32_t* qstat, int fi_base) {
   __shared__ uint32_t hist[kTauBins];
   __shared__ uint32_t list[kTauListCap];
   __shared__ uint32_t nlist;
   const int l = level0 + blockIdx.x, fi = blockIdx.y, slot = src.slot0 + fi, tid = threadIdx.x;
   const OrbLevelInfo L = g.lv[l];
+  // the walker's refinement state of this (frame, level): histogram and done count start at 0, word kTauBins + 1 is the
+  // threshold in force (written below; the walker raises it with atomicMax, k_fast_check copies it to tau[])
+  if (tid <= kTauBins) qstat[(size_t)(slot * kOrbLevels + l) * kQStat + tid] = 0;
   int tv = kFastT, pre_used = kTauPre;
   if (force_tau > 0) {
     tv = force_tau;
@@ -993,85 +1169,47 @@ __global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, c
   if (tid == 0) {
     tau[slot * kOrbLevels + l] = (uint32_t)tv;
     tau_first[slot * kOrbLevels + l] = (uint32_t)tv;
+    qstat[(size_t)(slot * kOrbLevels + l) * kQStat + kTauBins + 1] = (uint32_t)tv;
     // nothing to gain from a threshold: straight to the dense pass
-    if (tv <= kFastT && L.tiles_x > 0) redo_list[atomicAdd(redo_cnt, 1u)] = (uint32_t)(fi * kOrbLevels + l);
+    // (fi_base: this launch covers the frames from fi_base on of the batch the redo queue belongs to)
+    if (tv <= kFastT && L.tiles_x > 0) redo_list[atomicAdd(redo_cnt, 1u)] = (uint32_t)((fi_base + fi) * kOrbLevels + l);
   }
 }
 
-// Second estimate of tau, from exact data.  The sampler's estimate rests on a few dozen hits and stays 3-9 x above the
-// 2N maxima a large level needs.  So the streaming pass runs in two parts: first every fourth strip (flat strip index
-// % 4 == 0: a quarter of the level, spread over it) at the sampler's tau, then this kernel reads the corners those
-// strips emitted -- exact maxima with exact scores -- and raises tau to the largest multiple of 4 at which the quarter
-// still holds kTau2MarginPct % (kTau2MarginPctMany % when at least kTau2ManyStrips strips were sampled) of its share of 2N; the other strips run at that value.  Everything at or above the final tau
-// is still found exactly (the first quarter found more), k_fast_check counts what reaches it, and a level that falls
-// short is redone densely as before: the result is the dense one bit for bit whatever happens here.
-// Levels with fewer than kTau2MinStrips sampled strips keep the sampler's value.
-// (measured at 720p, fast_nms ms / levels redone of 10 240 over three textures and two sizes: margin 2.0 with at least 4 / 2 / 1
-// sampled strips 3.92 / 3.74 / 3.80 and none redone; margin 1.5: 3.82 / 3.68 with 4 redone; margin 2.5: 3.93)
-// Every 3rd / 6th / 8th strip instead of every 4th: 3.84 / 3.71 (17 levels redone of 4096) / 3.74 against 3.70-3.75;
-// a cheaper sampler (512 / 256 sites per level instead of 1024) gives the pyramid kernels 0.12 / 0.25 ms back and
-// costs the first part 0.24 / 0.87 ms.
-constexpr int kTau2MarginPct = 200, kTau2MinStrips = 2;
-constexpr int kTau2MarginPctMany = 150, kTau2ManyStrips = 8;
-__global__ __launch_bounds__(64) void k_fast_tau2(OrbGeometry g, int slot0, int n_frames, uint32_t* tau, uint32_t* tau_first,
-                                                  const uint32_t* cand_cnt, const uint8_t* cand_sc, uint32_t* cnt_a,
-                                                  int margin_pct) {
-  __shared__ uint32_t hist[kTauBins];
+// After the walker: tau[idx] is the largest threshold any strip of the (frame, level) ran at, and every strict maximum
+// with a score at or above it is in the candidate list (strips that ran lower also left smaller ones).  If fewer than 2N
+// reach it, retainBest(2N) would cut below what was searched completely: the level is queued for the dense pass (its
+// candidate list restarts from empty).  One wave per (frame, level).
+__global__ __launch_bounds__(64) void k_fast_check(OrbGeometry g, int slot0, int n_frames, uint32_t* tau, uint32_t* tau_first,
+                                                   uint32_t* cand_cnt, const uint8_t* cand_sc, uint32_t* redo_cnt,
+                                                   uint32_t* redo_list, const uint32_t* qstat) {
   const int fi = blockIdx.x / kOrbLevels, l = blockIdx.x - fi * kOrbLevels, lane = threadIdx.x;
   if (fi >= n_frames || l >= g.nlevels) return;
   const int idx = (slot0 + fi) * kOrbLevels + l;
+  if (tau[idx] <= (uint32_t)kFastT) return;
+  const uint32_t T = max(tau[idx], qstat[(size_t)idx * kQStat + kTauBins + 1]);   // the largest threshold any strip ran at
   const OrbLevelInfo L = g.lv[l];
-  const uint32_t n_raw = cand_cnt[idx], ts = tau[idx];
-  uint32_t t2 = ts, c_ge = n_raw;
-  const int n_strips = L.strips_x * L.strips_y;
-  if (ts > (uint32_t)kFastT && L.strips_a >= kTau2MinStrips && n_raw <= (uint32_t)L.cand_cap) {
-    hist[lane] = 0;
-    __syncthreads();
-    const uint8_t* scs = cand_sc + (long long)(slot0 + fi) * g.cand_total + L.cand_off;
-    for (uint32_t i = lane; i < n_raw; i += 64) atomicAdd(&hist[scs[i] >> 2], 1u);
-    __syncthreads();
-    uint32_t c = hist[lane];                       // suffix sums: c = corners of the quarter with score >= 4 * lane
+  const uint32_t n = min(cand_cnt[idx], (uint32_t)L.cand_cap);   // an overflowed list is flagged by k_thr_harris
+  const uint8_t* scs = cand_sc + (long long)(slot0 + fi) * g.cand_total + L.cand_off;
+  uint32_t found = 0;
+  for (uint32_t i = 16u * lane; i < n; i += 16u * 64u) {
+    const uint4 v = *reinterpret_cast<const uint4*>(scs + i);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t up = __shfl_down(c, o);
-      if (lane + o < 64) c += up;
-    }
-    const uint32_t den = 100u * (uint32_t)n_strips;
-    // a level with many sampled strips gives a steadier estimate and takes the smaller margin (720p: levels 0-2;
-    // fast_nms 3.73 -> 3.65 ms, none redone at 720p / 1080p; 125 % there: 3.85 ms with 26 of 4096 levels redone, 150 % from
-    // 4 strips: 3.67 with 4 redone); an explicit MSF_ORB_TAU2_MARGIN_PCT applies to every level
-    const uint32_t mp = (L.strips_a >= kTau2ManyStrips && margin_pct == kTau2MarginPct) ? (uint32_t)kTau2MarginPctMany : (uint32_t)margin_pct;
-    const uint32_t need = (mp * 2u * (uint32_t)L.quota * (uint32_t)L.strips_a + den - 1u) / den;
-    const unsigned long long ok = __ballot(c >= need && 4u * lane >= ts);
-    if (ok) {
-      const int top = 63 - __builtin_clzll(ok);
-      t2 = 4u * top;
-      c_ge = __shfl(c, top);
-    }
+    for (int b = 0; b < 16; b++)
+      if (i + b < n && ((w[b >> 2] >> (8 * (b & 3))) & 255u) >= T) found++;
   }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) found += __shfl_xor(found, o);
   if (lane == 0) {
-    tau[idx] = t2;
-    tau_first[idx] = t2;
-    cnt_a[2 * idx] = c_ge;         // corners of the sampled quarter that reach the final tau
-    cnt_a[2 * idx + 1] = n_raw;    // everything the quarter emitted
-  }
-}
-
-// After k_fast: a (frame, level) that ran with tau above fastThreshold and found fewer than 2N maxima is queued for the
-// dense pass (its candidate list restarts from empty).  cnt_a (two-part streaming pass): only corners at or above the
-// final tau count -- those of the sampled quarter that reach it plus everything the second part emitted.
-__global__ __launch_bounds__(256) void k_fast_check(OrbGeometry g, int slot0, int n_frames, uint32_t* tau,
-                                                    uint32_t* cand_cnt, uint32_t* redo_cnt, uint32_t* redo_list,
-                                                    const uint32_t* cnt_a) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_frames * kOrbLevels) return;
-  const int fi = i / kOrbLevels, l = i - fi * kOrbLevels, idx = (slot0 + fi) * kOrbLevels + l;
-  if (l >= g.nlevels || tau[idx] <= (uint32_t)kFastT) return;
-  const uint32_t found = cnt_a ? cnt_a[2 * idx] + (cand_cnt[idx] - cnt_a[2 * idx + 1]) : cand_cnt[idx];
-  if (found < 2u * (uint32_t)g.lv[l].quota) {
-    tau[idx] = kFastT;
-    cand_cnt[idx] = 0;
-    redo_list[atomicAdd(redo_cnt, 1u)] = (uint32_t)(fi * kOrbLevels + l);
+    if (found < 2u * (uint32_t)L.quota) {
+      tau[idx] = kFastT;
+      cand_cnt[idx] = 0;
+      redo_list[atomicAdd(redo_cnt, 1u)] = (uint32_t)(fi * kOrbLevels + l);
+    } else {
+      tau[idx] = T;           // the threshold the list is complete from (MSF_DBG_FAST_TAU reports both)
+      tau_first[idx] = T;
+    }
   }
 }
 
@@ -1760,7 +1898,7 @@ static void make_table(int src, int dst, uint32_t* tab) {
 OrbPipeline::~OrbPipeline() { destroy(); }
 
 void OrbPipeline::destroy() {
-  hipFree(d_tau_); hipFree(d_redo_); hipFree(d_cnt_a_); d_tau_ = nullptr; d_redo_ = nullptr; d_cnt_a_ = nullptr;
+  hipFree(d_tau_); hipFree(d_redo_); hipFree(d_qstat_); d_tau_ = nullptr; d_redo_ = nullptr; d_qstat_ = nullptr;
   hipFree(d_pyr_); hipFree(d_tab_); hipFree(d_cand_cnt_); hipFree(d_cand_); hipFree(d_cand_sc_); hipFree(d_qres_); hipFree(d_done_); hipFree(d_s1_cnt_); hipFree(d_s1_);
   hipFree(d_kp_); hipFree(d_desc_); hipFree(d_kp_cnt_); hipFree(d_status_);
   d_pyr_ = nullptr; d_tab_ = nullptr; d_cand_cnt_ = nullptr; d_cand_ = nullptr; d_cand_sc_ = nullptr; d_qres_ = nullptr; d_done_ = nullptr; d_s1_cnt_ = nullptr;
@@ -1813,6 +1951,12 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   if (const char* e = getenv("MSF_ORB_RESIZE_GENERIC")) resize_generic_ = atoi(e) != 0;
   // MSF_ORB_FAST_ONE_PART=1: the streaming FAST pass over all strips at the sampler's threshold (no second estimate)
   if (const char* e = getenv("MSF_ORB_FAST_ONE_PART")) fast_two_part_ = atoi(e) == 0;
+  // MSF_ORB_UNFUSED=1: the pyramid by k_resize and one FAST-only walker launch over all levels (the r02 structure; tests
+  // compare it with the fused default, in which the walker of level l - 1 also makes level l)
+  if (const char* e = getenv("MSF_ORB_UNFUSED")) fused_ = atoi(e) == 0;
+  // MSF_ORB_WALK_ROUND: a walker launch whose sampled quarter has fewer strips than this runs as two launches (tests: 0
+  // = always one launch, refinement depending on dispatch timing; a huge value = always two)
+  if (const char* e = getenv("MSF_ORB_WALK_ROUND")) walk_round_ = atoll(e);
   // MSF_ORB_TAU2_MARGIN_PCT: the second estimate's safety margin in percent of 2N (tests: a few percent makes it overshoot,
   // so that levels fail the check and take the dense second pass)
   tau2_margin_pct_ = kTau2MarginPct;
@@ -1884,12 +2028,16 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     if (L.tiles_x == 0 || L.tiles_y == 0) L.tiles_x = L.tiles_y = 0;
     L.tile_base = tiles;
     tiles += L.tiles_x * L.tiles_y;
-    // strips: lane 1 of strip 0 holds px 28..31; 248 output px per strip over [31, w - 31), 64 output rows
-    L.strips_x = L.tiles_x > 0 ? (L.w - kEdge - (kSX0 + 4) + SPX - 1) / SPX : 0;
-    L.strips_y = L.tiles_x > 0 ? (L.h - 2 * kEdge + SR - 1) / SR : 0;
-    L.strip_base = strips;
-    strips += L.strips_x * L.strips_y;
-    L.strips_a = (strips + 3) / 4 - (L.strip_base + 3) / 4;   // multiples of 4 in [strip_base, strips)
+    // walker strips over the whole level: 256-px windows wk_px apart ((nx - 1) * wk_px + 256 >= w), wk_rows owned rows
+    L.wk_nx = L.w > 256 ? (L.w - 256 + kWkMaxPx - 1) / kWkMaxPx + 1 : 1;
+    L.wk_px = L.wk_nx > 1 ? (((L.w - 256 + L.wk_nx - 2) / (L.wk_nx - 1)) + 3) & ~3 : kWkMaxPx;
+    L.wk_ny = (L.h + kWkRowsTarget - 1) / kWkRowsTarget;
+    L.wk_rows = (((L.h + L.wk_ny - 1) / L.wk_ny) + 3) & ~3;
+    L.wk_ny = (L.h + L.wk_rows - 1) / L.wk_rows;
+    L.wk_base = strips;
+    strips += L.wk_nx * L.wk_ny;
+    L.wk_fused = 0;
+    L.tab_yemit = L.tab_xstrip = 0;
     if (L.tiles_x * L.tiles_y > g.max_level_tiles) g.max_level_tiles = L.tiles_x * L.tiles_y;
     // sample lattice of k_fast_tau: about 4096 pixels of the kept region in runs of 4 (one dword), rows sparser than
     // columns (a sampled pixel touches 7 rows); samp_sx counts dwords and is odd, so that block textures with
@@ -1911,7 +2059,13 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
       if (L.samp_cols == 0) L.samp_rows = 0;
     }
     L.tab_off = tab;
-    if (l > 0) tab += 12 * ((L.w + 3) >> 2) + ((L.h + 3) & ~3);   // 3 x uint4 per group of 4 columns, one dword per row
+    if (l > 0) {
+      tab += 12 * ((L.w + 3) >> 2) + ((L.h + 3) & ~3);   // 3 x uint4 per group of 4 columns, one dword per row
+      L.tab_yemit = tab;                                 // one dword per SOURCE row (level l - 1)
+      tab += (g.lv[l - 1].h + 3) & ~3;
+      L.tab_xstrip = tab;                                // first output group of each walker strip of level l - 1, + end
+      tab += (g.lv[l - 1].wk_nx + 1 + 3) & ~3;
+    }
   }
   g.pyr_bytes = (pix + 255) & ~255ll;
   g.cand_total = cand;
@@ -1942,7 +2096,33 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
       xsel[x] = 0x0c010c00u + (cx - base) * 0x00010001u;   // pair bytes (cx - base, cx - base + 1) -> u16 lanes, zeros between
       xwxp[x] = (256u - wx1) | (wx1 << 16);
     }
-    make_table(g.lv[l - 1].h, L.h, xoff + 4 * groups);
+    uint32_t* ytab = xoff + 4 * groups;
+    make_table(g.lv[l - 1].h, L.h, ytab);
+    // ---- tables of the fused form (the walker of level l - 1 makes this level): valid if every source row is the
+    // upper tap of at most one output row, the shared-pair column form holds, and every strip's groups fit its window
+    const OrbLevelInfo& Ls = g.lv[l - 1];
+    bool fused = shared && Ls.wk_rows <= kWkMaxRows && Ls.h < 65536;
+    uint32_t* yemit = htab.data() + L.tab_yemit;
+    uint32_t* xstrip = htab.data() + L.tab_xstrip;
+    for (int y = 0; y < L.h; y++) {
+      const uint32_t sy = ytab[y] & 0xFFFFu, w1 = ytab[y] >> 16;
+      if (sy >= (uint32_t)Ls.h || yemit[sy] != 0u || w1 > 256u) { fused = false; break; }
+      yemit[sy] = 0x80000000u | (w1 << 16) | (uint32_t)y;
+    }
+    // group gq belongs to the last strip whose window starts at or before its first pair
+    for (int c = 0; c <= Ls.wk_nx; c++) xstrip[c] = (uint32_t)groups;
+    for (int gq = groups - 1; gq >= 0; gq--) {
+      const uint32_t b0 = xoff[4 * gq], b3 = xoff[4 * gq + 3];
+      int c = (int)(b0 / (uint32_t)Ls.wk_px);
+      if (c > Ls.wk_nx - 1) c = Ls.wk_nx - 1;
+      const uint32_t xs = (uint32_t)(c * Ls.wk_px);
+      if (b0 < xs || b3 < b0 || b3 + 8u > xs + 256u) fused = false;   // both 8-byte pairs inside the 256-px window
+      for (int cc = 0; cc <= c; cc++) xstrip[cc] = (uint32_t)gq;       // groups are monotone in b0: the last write is the first group
+    }
+    for (int c = 0; c < Ls.wk_nx; c++)
+      if (xstrip[c + 1] < xstrip[c] || xstrip[c + 1] - xstrip[c] > 64u) fused = false;
+    if (xstrip[0] != 0u) fused = false;
+    g.lv[l].wk_fused = fused ? 1 : 0;
   }
   const size_t S = (size_t)max_slots;
   MSF_HIP_TRY(hipMalloc(&d_pyr_, S * g.pyr_bytes));
@@ -1952,7 +2132,8 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   MSF_HIP_TRY(hipMalloc(&d_tau_, 2 * S * kOrbLevels * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMemset(d_tau_, 0, 2 * S * kOrbLevels * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMalloc(&d_redo_, (1 + S * kOrbLevels) * sizeof(uint32_t)));
-  MSF_HIP_TRY(hipMalloc(&d_cnt_a_, 2 * S * kOrbLevels * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMalloc(&d_qstat_, S * kOrbLevels * kQStat * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMemset(d_qstat_, 0, S * kOrbLevels * kQStat * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMalloc(&d_cand_, S * g.cand_total * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMalloc(&d_cand_sc_, S * g.cand_total));
   MSF_HIP_TRY(hipMalloc(&d_s1_cnt_, S * kOrbLevels * sizeof(uint32_t)));
@@ -2057,22 +2238,17 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
   if ((e = hipMemsetAsync(d_status_ + src.slot0, 0, (size_t)n * 4, st))) return e;
   if ((e = hipMemsetAsync(d_redo_, 0, 4, st))) return e;
   if (evs) hipEventRecord(evs[0], st);
-  // k_fast_tau is a light, latency-bound kernel (one workgroup per (frame, level), scattered loads): for a batch it
-  // runs level by level on a side stream underneath the pyramid kernels, each level as soon as it exists
   uint32_t* tau = d_tau_;
   uint32_t* tau_first = d_tau_ + (size_t)max_slots_ * kOrbLevels;
   // A call of a few frames (the single-pair MatchFrames, a key frame upload) is latency-bound: a wave of the
-  // streaming pass walks its strip in ~70 dependent steps, whereas the dense tile kernel is one short workgroup per
-  // tile.  Such calls take the dense kernel directly; the result is the same either way.
+  // streaming pass walks its strip in ~90 dependent steps, whereas the dense tile kernel is one short workgroup per
+  // tile.  Such calls take k_resize + the dense kernel directly; the result is the same either way.
   const int force_tau = (force_tau_ == 0 && n < stream_min_frames_) ? kFastT : force_tau_;
-  const bool side = allow_side && tau_stream_ != nullptr && n >= 64 && g.total_tiles > 0 && force_tau != kFastT;
-  if (side) {
-    hipEventRecord(tau_ev_[0], st);
-    hipStreamWaitEvent(tau_stream_, tau_ev_[0], 0);
-    hipLaunchKernelGGL(k_fast_tau, dim3(1, n), dim3(256), 0, tau_stream_, g, src, d_pyr_, force_tau, tau, tau_first, d_redo_,
-                       d_redo_ + 1, 0);
-  }
-  for (int l = 1; l < g.nlevels; l++) {
+  const bool dense = force_tau == kFastT;
+  const int dyn = (fast_two_part_ && force_tau == 0) ? 1 : 0;
+  bool fused = fused_ && !dense && g.total_tiles > 0;
+  for (int l = 1; l < g.nlevels; l++) fused = fused && g.lv[l].wk_fused != 0;
+  auto launch_resize = [&](int l) {
     const OrbLevelInfo& L = g.lv[l];
     // band height: 8 output rows x 256 threads measured best (rth 4: 3.26 ms, 8: 2.71, 12: 2.77, 16: 2.74 per 2048
     // [r02, table-driven kernel: 12 or 16 rows on the small levels only: 2.65 vs 2.65-2.73, within run-to-run noise]
@@ -2089,53 +2265,113 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
     hipLaunchKernelGGL(resize_shared_[l] ? k_resize<true> : k_resize<false>, dim3((L.h + rth - 1) / rth, n), dim3(threads),
                        (size_t)lds_rows * sw16 + 8 * kResizeMaxRows, st, g, src, d_pyr_, d_tab_, l, rth, lds_rows, magic_n16,
                        magic_groups);
-    if (side) {
-      hipEventRecord(tau_ev_[l], st);
-      hipStreamWaitEvent(tau_stream_, tau_ev_[l], 0);
-      hipLaunchKernelGGL(k_fast_tau, dim3(1, n), dim3(256), 0, tau_stream_, g, src, d_pyr_, force_tau, tau, tau_first,
-                         d_redo_, d_redo_ + 1, l);
+  };
+  // strips of levels [l_lo, l_hi] of the frames of `fs`: 8 x ceil(nf / 8) frames x strips workgroups of one wave (see
+  // k_walk for the order).  A launch whose sampled quarter is less than one round of the chip (16 waves x 256 CUs)
+  // would start all its strips together and refine nothing: it runs as two launches, the quarter and then the rest.
+  auto launch_walk = [&](bool resize, int l_lo, int l_hi, const FrameSrc& fs, int nf, hipStream_t s_) {
+    const int S = g.lv[l_hi].wk_base + g.lv[l_hi].wk_nx * g.lv[l_hi].wk_ny - g.lv[l_lo].wk_base;
+    const int Sq = (S + 3) / 4, Sr = S - Sq;
+    const unsigned f8 = 8u * (unsigned)((nf + 7) / 8);
+    const bool two = dyn && Sr > 0 && (long long)nf * Sq < walk_round_;
+    for (int part = two ? 0 : -1; part <= (two ? 1 : -1); part++) {
+      const unsigned units = part < 0 ? (unsigned)S : part == 0 ? (unsigned)Sq : (unsigned)Sr;
+      if (resize)
+        hipLaunchKernelGGL(k_walk<true>, dim3(f8 * units), dim3(64), 0, s_, g, fs, d_pyr_, d_tab_, tau, d_qstat_, d_cand_cnt_,
+                           d_cand_, d_cand_sc_, l_lo, l_hi, nf, tau2_margin_pct_, dyn, part);
+      else
+        hipLaunchKernelGGL(k_walk<false>, dim3(f8 * units), dim3(64), 0, s_, g, fs, d_pyr_, d_tab_, tau, d_qstat_, d_cand_cnt_,
+                           d_cand_, d_cand_sc_, l_lo, l_hi, nf, tau2_margin_pct_, dyn, part);
     }
-  }
-  if (evs) hipEventRecord(evs[1], st);
-  if (pyramid_done) hipEventRecord(pyramid_done, st);   // the next part may start (after FAST / selection instead: 9.26 / 9.29 vs 9.07 ms)
-  if (g.total_tiles > 0) {
-    if (side) {
+  };
+  // frames [f0, f0 + cnt) of src as a source of their own
+  auto sub_src = [&](int f0) {
+    FrameSrc sk = src;
+    sk.slot0 = src.slot0 + f0;
+    if (f0 <= src.n_a) { sk.a = src.a + (long long)f0 * src.frame_stride; sk.n_a = src.n_a - f0; }
+    else { sk.n_a = 0; sk.b = src.b + (long long)(f0 - src.n_a) * src.frame_stride; }
+    return sk;
+  };
+  last_fused_ = fused;
+  if (fused) {
+    // The walker of level l - 1 makes level l and finds level l - 1's corners in one pass over its pixels.  Its
+    // threshold comes from the sampler, which needs level l - 1 to exist: sampler and walker alternate.  The sampler is
+    // a short latency-bound kernel that leaves the chip nearly idle (8 x 68 us per step when everything is one chain),
+    // so a large batch runs as two chains of half the frames on two streams: one half's samplers run beside the other
+    // half's walkers.  Both chains lie between the same two stage events.
+    auto chain = [&](const FrameSrc& fs, int nf, int f0, hipStream_t s_) {
+      hipLaunchKernelGGL(k_fast_tau, dim3(1, nf), dim3(256), 0, s_, g, fs, d_pyr_, force_tau, tau, tau_first, d_redo_,
+                         d_redo_ + 1, 0, d_qstat_, f0);
+      for (int l = 1; l < g.nlevels; l++) {
+        launch_walk(true, l - 1, l - 1, fs, nf, s_);
+        hipLaunchKernelGGL(k_fast_tau, dim3(1, nf), dim3(256), 0, s_, g, fs, d_pyr_, force_tau, tau, tau_first, d_redo_,
+                           d_redo_ + 1, l, d_qstat_, f0);
+      }
+      launch_walk(false, g.nlevels - 1, g.nlevels - 1, fs, nf, s_);
+    };
+    const bool halves = allow_side && tau_stream_ != nullptr && n >= 256 && !getenv("MSF_ORB_ONE_CHAIN");
+    if (halves) {
+      const int n0 = n / 2;
+      hipEventRecord(tau_ev_[0], st);
+      hipStreamWaitEvent(tau_stream_, tau_ev_[0], 0);
+      chain(src, n0, 0, st);
+      chain(sub_src(n0), n - n0, n0, tau_stream_);
       hipEventRecord(tau_ev_[kOrbLevels], tau_stream_);
       hipStreamWaitEvent(st, tau_ev_[kOrbLevels], 0);
     } else {
-      hipLaunchKernelGGL(k_fast_tau, dim3(g.nlevels, n), dim3(256), 0, st, g, src, d_pyr_, force_tau, tau, tau_first, d_redo_,
-                         d_redo_ + 1, 0);
+      chain(src, n, 0, st);
     }
-    if (force_tau == kFastT) {   // MSF_FLAG_FAST_DENSE: the plain detector over every tile, nothing to verify
-      hipLaunchKernelGGL(k_fast, dim3((unsigned)g.total_tiles * (unsigned)n), dim3(kFastThreads), 0, st, g, src, d_pyr_,
-                         d_cand_cnt_, d_cand_, d_cand_sc_);
-    } else {
-      const int n_a = (g.total_strips + 3) / 4, n_b = g.total_strips - n_a;
-      if (fast_two_part_ && force_tau == 0 && n_b > 0) {
-        hipLaunchKernelGGL(k_fast_stream, dim3((unsigned)n_a * (unsigned)n), dim3(64), 0, st, g, src, d_pyr_, tau,
-                           d_cand_cnt_, d_cand_, d_cand_sc_, 0, n_a);
-        hipLaunchKernelGGL(k_fast_tau2, dim3((unsigned)n * kOrbLevels), dim3(64), 0, st, g, src.slot0, n, tau, tau_first,
-                           d_cand_cnt_, d_cand_sc_, d_cnt_a_, tau2_margin_pct_);
-        hipLaunchKernelGGL(k_fast_stream, dim3((unsigned)n_b * (unsigned)n), dim3(64), 0, st, g, src, d_pyr_, tau,
-                           d_cand_cnt_, d_cand_, d_cand_sc_, 1, n_b);
-        hipLaunchKernelGGL(k_fast_check, dim3((n * kOrbLevels + 255) / 256), dim3(256), 0, st, g, src.slot0, n, tau,
-                           d_cand_cnt_, d_redo_, d_redo_ + 1, d_cnt_a_);
-      } else {
-        hipLaunchKernelGGL(k_fast_stream, dim3((unsigned)g.total_strips * (unsigned)n), dim3(64), 0, st, g, src, d_pyr_, tau,
-                           d_cand_cnt_, d_cand_, d_cand_sc_, -1, g.total_strips);
-        hipLaunchKernelGGL(k_fast_check, dim3((n * kOrbLevels + 255) / 256), dim3(256), 0, st, g, src.slot0, n, tau,
-                           d_cand_cnt_, d_redo_, d_redo_ + 1, (const uint32_t*)nullptr);
+    if (evs) hipEventRecord(evs[1], st);
+    if (pyramid_done) hipEventRecord(pyramid_done, st);
+  } else {
+    // k_fast_tau is a light, latency-bound kernel (one workgroup per (frame, level), scattered loads): for a batch it
+    // runs level by level on a side stream underneath the pyramid kernels, each level as soon as it exists
+    const bool side = allow_side && tau_stream_ != nullptr && n >= 64 && g.total_tiles > 0 && !dense;
+    if (side) {
+      hipEventRecord(tau_ev_[0], st);
+      hipStreamWaitEvent(tau_stream_, tau_ev_[0], 0);
+      hipLaunchKernelGGL(k_fast_tau, dim3(1, n), dim3(256), 0, tau_stream_, g, src, d_pyr_, force_tau, tau, tau_first, d_redo_,
+                         d_redo_ + 1, 0, d_qstat_, 0);
+    }
+    for (int l = 1; l < g.nlevels; l++) {
+      launch_resize(l);
+      if (side) {
+        hipEventRecord(tau_ev_[l], st);
+        hipStreamWaitEvent(tau_stream_, tau_ev_[l], 0);
+        hipLaunchKernelGGL(k_fast_tau, dim3(1, n), dim3(256), 0, tau_stream_, g, src, d_pyr_, force_tau, tau, tau_first,
+                           d_redo_, d_redo_ + 1, l, d_qstat_, 0);
       }
-      // fixed grid (a multiple of 8: see the XCD-contiguous unit order), sized to what the batch could need
-      long long units = (long long)n * kOrbLevels * g.max_level_tiles;
-      unsigned grid = (unsigned)(units < 2048 ? units : 2048);
-      grid = (grid + 7u) & ~7u;
-      hipLaunchKernelGGL(k_fast_redo, dim3(grid), dim3(kFastThreads), 0, st, g, src, d_pyr_, d_redo_, d_redo_ + 1,
-                         g.max_level_tiles, d_cand_cnt_, d_cand_, d_cand_sc_);
+    }
+    if (evs) hipEventRecord(evs[1], st);
+    if (pyramid_done) hipEventRecord(pyramid_done, st);   // the next part may start (after FAST / selection instead: 9.26 / 9.29 vs 9.07 ms)
+    if (g.total_tiles > 0) {
+      if (side) {
+        hipEventRecord(tau_ev_[kOrbLevels], tau_stream_);
+        hipStreamWaitEvent(st, tau_ev_[kOrbLevels], 0);
+      } else {
+        hipLaunchKernelGGL(k_fast_tau, dim3(g.nlevels, n), dim3(256), 0, st, g, src, d_pyr_, force_tau, tau, tau_first, d_redo_,
+                           d_redo_ + 1, 0, d_qstat_, 0);
+      }
+      if (dense) {   // MSF_FLAG_FAST_DENSE / a call of a few frames: the plain detector over every tile, nothing to verify
+        hipLaunchKernelGGL(k_fast, dim3((unsigned)g.total_tiles * (unsigned)n), dim3(kFastThreads), 0, st, g, src, d_pyr_,
+                           d_cand_cnt_, d_cand_, d_cand_sc_);
+      } else {
+        launch_walk(false, 0, g.nlevels - 1, src, n, st);
+      }
     }
   }
+  if (g.total_tiles > 0 && !dense) {
+    hipLaunchKernelGGL(k_fast_check, dim3((unsigned)n * kOrbLevels), dim3(64), 0, st, g, src.slot0, n, tau, tau_first,
+                       d_cand_cnt_, d_cand_sc_, d_redo_, d_redo_ + 1, d_qstat_);
+    // fixed grid (a multiple of 8: see the XCD-contiguous unit order), sized to what the batch could need
+    long long units = (long long)n * kOrbLevels * g.max_level_tiles;
+    unsigned grid = (unsigned)(units < 2048 ? units : 2048);
+    grid = (grid + 7u) & ~7u;
+    hipLaunchKernelGGL(k_fast_redo, dim3(grid), dim3(kFastThreads), 0, st, g, src, d_pyr_, d_redo_, d_redo_ + 1,
+                       g.max_level_tiles, d_cand_cnt_, d_cand_, d_cand_sc_);
+  }
   if (evs) hipEventRecord(evs[2], st);
-  hipLaunchKernelGGL(k_thr_harris, dim3(g.nlevels, n), dim3(force_tau == kFastT ? 256 : 64), 0, st, g, src, d_pyr_,
+  hipLaunchKernelGGL(k_thr_harris, dim3(g.nlevels, n), dim3(dense ? 256 : 64), 0, st, g, src, d_pyr_,
                      d_cand_cnt_, d_cand_, d_cand_sc_, d_s1_cnt_, d_s1_, d_status_);
   hipLaunchKernelGGL(k_select, dim3(n), dim3(256), 0, st, g, src.slot0, d_s1_cnt_, d_s1_, d_kp_, d_kp_cnt_,
                      d_status_);
@@ -2179,7 +2415,9 @@ hipError_t OrbPipeline::match(int n_pairs, const int32_t* d_slot_a, const int32_
 }
 
 int OrbPipeline::stage_times(const char** names, float* ms, int cap) {
-  static const char* kNames[5] = {"pyramid", "fast_nms", "select_harris", "orient_describe", "match"};
+  // fused extraction: the first stage is pyramid + FAST of levels 0 .. 6 in one pass per level (samplers included), the
+  // second what is left of FAST (the last level, the check, the dense redo)
+  const char* kNames[5] = {last_fused_ ? "pyramid_fast" : "pyramid", "fast_nms", "select_harris", "orient_describe", "match"};
   if (!ev_ok_ || !ev_recorded_) return 0;
   if (hipEventSynchronize(ev_[5]) != hipSuccess) return 0;
   int n = 0;

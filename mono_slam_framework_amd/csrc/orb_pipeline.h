@@ -28,8 +28,12 @@ struct OrbLevelInfo {
   int cand_off;        // offset (entries) of this level inside a slot's candidate array
   int s1_off;          // offset (entries) of this level inside a slot's stage-1 array
   int tiles_x, tiles_y, tile_base;  // FAST tiling (128 x 32 tiles, dense kernel)
-  int strips_x, strips_y, strip_base;   // 248 x 64 column strips of the streaming first pass (one wave each)
-  int strips_a;                         // strips of this level in the sampled quarter (flat strip index % 4 == 0)
+  // column strips of the streaming walker (one wave each) over the WHOLE level: strip (sx, sy) holds the 256-px window
+  // starting at x = sx * wk_px and owns rows [sy * wk_rows, (sy + 1) * wk_rows)
+  int wk_nx, wk_ny, wk_px, wk_rows, wk_base;   // wk_base: flat index of the level's first strip
+  int wk_fused;        // this level (as the DESTINATION of a resize) can be made by the walker of level l - 1
+  int tab_yemit;       // offset (entries) of the per-source-row emit table of the resize INTO this level
+  int tab_xstrip;      // offset (entries) of the first output group of each walker strip of level l - 1
   int tab_off;         // offset (entries) of this level's resize tables
   int samp_sx, samp_sy, samp_rows, samp_cols;   // k_fast_tau's sample lattice over [31, w-31) x [31, h-31); rows 0 = none
   long long pix_off;   // byte offset of this level inside a slot's pyramid blob (levels >= 1)
@@ -39,7 +43,7 @@ struct OrbGeometry {
   int nlevels;
   int w0, h0;
   int total_tiles;
-  int total_strips;
+  int total_strips;        // walker strips of all levels
   int max_level_tiles;     // largest tile count of one level
   int cand_total;          // candidate entries per slot
   int s1_total;            // stage-1 entries per slot
@@ -88,8 +92,11 @@ class OrbPipeline {
   uint8_t* d_pyr_ = nullptr;
   uint32_t* d_tab_ = nullptr;      // resize tables per level: per group of 4 columns selectors / weights / pair offsets, per row source row | w1 << 16
   bool resize_shared_[kOrbLevels] = {};   // per level: k_resize may read three pixels' taps from one dword pair
-  uint32_t* d_cnt_a_ = nullptr;           // [slots][levels][2]: two-part streaming FAST, see k_fast_tau2
-  bool fast_two_part_ = true;             // MSF_ORB_FAST_ONE_PART=1 clears it
+  uint32_t* d_qstat_ = nullptr;           // [slots][levels][kTauBins + 2]: score histogram of the sampled quarter's corners,
+                                          // its strips done (in-launch threshold refinement, see k_walk)
+  bool fast_two_part_ = true;             // MSF_ORB_FAST_ONE_PART=1 clears it: no refinement of the sampler's threshold
+  long long walk_round_ = 4096;           // strips the chip runs at once (16 waves x 256 CUs): see launch_walk
+  bool fused_ = true;                     // MSF_ORB_UNFUSED=1 clears it: k_resize x 7, then one FAST-only walker launch
   int tau2_margin_pct_ = 200;             // MSF_ORB_TAU2_MARGIN_PCT
   bool resize_generic_ = false;           // MSF_ORB_RESIZE_GENERIC: never
   uint32_t* d_cand_cnt_ = nullptr; // [slots][8]
@@ -121,7 +128,7 @@ class OrbPipeline {
   hipEvent_t split_pyr_[8] = {};
   hipEvent_t ev2_[kOrbStages + 2] = {};         // stage boundaries of the parts on split_stream_ (profiling)
   int split_parts_ = 2;
-  bool last_split_ = false;
+  bool last_split_ = false, last_fused_ = false;
   uint32_t* d_redo2_ = nullptr;
   hipError_t extract_range(const FrameSrc& src, int n, hipStream_t st, uint32_t* redo, bool allow_side, hipEvent_t* evs,
                            hipEvent_t pyramid_done);

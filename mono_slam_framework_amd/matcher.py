@@ -225,12 +225,11 @@ class FeatureMatcher(_Matcher):
         return 2
 
     @staticmethod
-    def fast_stream_parts():
-        """Launches of the streaming FAST kernel per extraction: 2 (a sampled quarter of the strips at the sampler's
-        threshold, then the rest at the second estimate, k_fast_tau2), or 1 with MSF_ORB_FAST_ONE_PART=1 / a forced
-        threshold (MSF_ORB_FAST_TAU)."""
-        import os
-        return 1 if os.environ.get("MSF_ORB_FAST_ONE_PART", "0") not in ("", "0") or os.environ.get("MSF_ORB_FAST_TAU") else 2
+    def walker_launches(stage):
+        """Launches of the dominant kernel (the streaming walker k_walk) in one extraction of a large batch: one per
+        source level for the fused stage "pyramid_fast" (levels 0..6, each also making the next level), one otherwise
+        (the unfused "fast_nms" stage walks all levels in one launch; so does the last level of the fused form)."""
+        return 7 if stage == "pyramid_fast" else 1
 
     # Introspection of the feature slots.  `slot` counts from the scratch slots of the last MatchFrames / match_batch
     # call (frame A of pair i = i, frame B = n_pairs + i); cache=True addresses the per-frame cache slots of

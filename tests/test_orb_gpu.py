@@ -428,11 +428,13 @@ def test_resize_fallback_equals_shared_pair_kernel(monkeypatch, w, h):
 
 
 @pytest.mark.gpu
-def test_two_part_fast_pass_equals_one_part_and_survives_an_overshooting_estimate(monkeypatch):
-    """The streaming FAST pass runs a sampled quarter of the strips at the sampler's threshold and the rest at a second
-    estimate made from the quarter's exact corners (k_fast_tau2).  Same match lists as the one-part pass
-    (MSF_ORB_FAST_ONE_PART=1); the second estimate really is higher on the large levels; and with the margin cut to
-    3 % of 2N it overshoots, levels fail k_fast_check, take the dense second pass -- and the lists are still the same."""
+def test_refined_fast_threshold_equals_unrefined_and_survives_an_overshooting_estimate(monkeypatch):
+    """The streaming walker runs a sampled quarter of the strips at the sampler's threshold; the other strips raise it from
+    the quarter's exact corners (k_walk).  Same match lists as without the refinement (MSF_ORB_FAST_ONE_PART=1); the
+    refined threshold really is higher on the large levels; with the margin cut to 3 % of 2N it overshoots, levels fail
+    k_fast_check, take the dense second pass -- and the lists are still the same.  Also the same: everything in ONE launch
+    per level (MSF_ORB_WALK_ROUND=0: whether a strip sees the quarter complete then depends on dispatch timing), and the
+    unfused form (MSF_ORB_UNFUSED=1: k_resize x 7 + one FAST-only walker launch)."""
     from mono_slam_framework_amd import _lib
     from mono_slam_framework_amd.matcher import FeatureMatcher
     n, w, h = 12, 1280, 720
@@ -453,6 +455,8 @@ def test_two_part_fast_pass_equals_one_part_and_survives_an_overshooting_estimat
     assert (tau_two[:, :, 0] == tau_two[:, :, 1]).all()                    # nothing redone at the default margin
     orc = oracle_orb.FeatureMatcherOracle(0.7)
     np.testing.assert_array_equal(got[0], orc.MatchFrames(A[0], B[0]))
+    for l in range(1, 8):                                                  # the walker's pyramid is k_resize's
+        np.testing.assert_array_equal(two.level_pixels(0, l), one.level_pixels(0, l), err_msg="pyramid L%d" % l)
     monkeypatch.setenv("MSF_ORB_TAU2_MARGIN_PCT", "3")
     wild = FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=fl)
     got2 = wild.match_batch(list(A), list(B), cap=1024)
@@ -460,6 +464,50 @@ def test_two_part_fast_pass_equals_one_part_and_survives_an_overshooting_estimat
     assert (tau_w[:, :, 0] == 20).sum() > 2 * n                            # many levels fell back to the dense pass
     for r, g in zip(ref, got2):
         np.testing.assert_array_equal(r, g)
+    monkeypatch.delenv("MSF_ORB_TAU2_MARGIN_PCT")
+    for env in ({"MSF_ORB_WALK_ROUND": "0"}, {"MSF_ORB_UNFUSED": "1"}, {"MSF_ORB_UNFUSED": "1", "MSF_ORB_WALK_ROUND": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        alt = FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=fl)
+        got3 = alt.match_batch(list(A), list(B), cap=1024)
+        for r, g in zip(ref, got3):
+            np.testing.assert_array_equal(r, g, err_msg=str(env))
+        for l in range(1, 8):
+            np.testing.assert_array_equal(alt.level_pixels(1, l), one.level_pixels(1, l), err_msg="%s pyramid L%d" % (env, l))
+        alt.close()
+        for k in env:
+            monkeypatch.delenv(k)
+
+
+@pytest.mark.gpu
+def test_two_half_batch_chains_equal_one_chain_and_the_unfused_form(monkeypatch):
+    """A batch of >= 256 frames runs its fused pyramid + FAST stage as two chains of half the frames on two streams (one
+    half's threshold samplers beside the other half's walkers).  Same lists, key points and pyramids as one chain
+    (MSF_ORB_ONE_CHAIN=1) and as the unfused form; a frame of the second half is checked against the oracle."""
+    from mono_slam_framework_amd import _lib
+    from mono_slam_framework_amd.matcher import FeatureMatcher
+    n, w, h = 144, 333, 251                                  # 288 frames, odd sizes
+    A, B = synth.synth_batch(9500, n, w, h, mode=0)
+    fl = _lib.MSF_FLAG_NO_FRAME_CACHE
+    two = FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=fl)
+    ref = two.match_batch(list(A), list(B), cap=1024)
+    assert sum(len(m) for m in ref) > 5 * n
+    orc = oracle_orb.FeatureMatcherOracle(0.7)
+    for i in (0, n // 2 + 3, n - 1):
+        np.testing.assert_array_equal(ref[i], orc.MatchFrames(A[i], B[i]))
+    kp_ref = [two.keypoints(s) for s in (0, n - 1, n, 2 * n - 1)]
+    for env in ("MSF_ORB_ONE_CHAIN", "MSF_ORB_UNFUSED"):
+        monkeypatch.setenv(env, "1")
+        alt = FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=fl)
+        got = alt.match_batch(list(A), list(B), cap=1024)
+        for r, g_ in zip(ref, got):
+            np.testing.assert_array_equal(r, g_, err_msg=env)
+        for s_, k in zip((0, n - 1, n, 2 * n - 1), kp_ref):
+            np.testing.assert_array_equal(alt.keypoints(s_), k, err_msg=env)
+            for l in (1, 4, 7):
+                np.testing.assert_array_equal(alt.level_pixels(s_, l), two.level_pixels(s_, l), err_msg="%s L%d" % (env, l))
+        alt.close()
+        monkeypatch.delenv(env)
 
 
 @pytest.mark.gpu
