@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MSF_ABI_VERSION 2 /* 2: msf_weights_info, msf_convert_weights, msf_frame_cache_stats, flags FAST_DENSE / NO_FRAME_CACHE / LEVEL_SIZE_MUL_INV */
+#define MSF_ABI_VERSION 3 /* 3: MSF_FLAG_BLUR_SUM256, msf_gather_*; 2: msf_weights_info, msf_convert_weights, msf_frame_cache_stats, flags FAST_DENSE / NO_FRAME_CACHE / LEVEL_SIZE_MUL_INV */
 
 typedef struct msf_handle msf_handle;
 
@@ -72,6 +72,9 @@ typedef enum msf_kind {
                                         k-ordered fmaf chain; default: the ResNet, the attention blocks and the similarity
                                         run as bf16 MFMA products of hi/lo-split f32 operands with f32 accumulation
                                         (|conf error| ~3e-5 against a 1e-3 bar, 1.9x the throughput) */
+#define MSF_FLAG_BLUR_SUM256 256u     /* ORB 7x7 blur with OpenCV's bit-exact fixed-point kernel 18 34 48 56 48 34 18 (sum 256,
+                                        rounding half up) instead of the sepFilter2D integer kernel 18 34 49 55 49 34 18
+                                        (sum 257) that cv::ORB reaches in OpenCV 4.x */
 #define MSF_FLAG_FAST_DENSE 8u       /* ORB: score every pixel at fastThreshold (no output-sensitive first pass); same results */
 
 typedef struct msf_config {

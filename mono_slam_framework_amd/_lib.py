@@ -24,6 +24,7 @@ MSF_FLAG_NO_FRAME_CACHE = 16
 MSF_FLAG_LEVEL_SIZE_MUL_INV = 32
 MSF_FLAG_FAST_STREAM = 64
 MSF_FLAG_LOFTR_F32 = 128
+MSF_FLAG_BLUR_SUM256 = 256
 
 (DBG_LEVEL_SIZES, DBG_LEVEL_PIXELS, DBG_FAST_CANDS, DBG_KEYPOINTS, DBG_DESCRIPTORS, DBG_STAGE1,
  DBG_LOFTR_CONF, DBG_LOFTR_FEAT, DBG_FAST_TAU, DBG_LOFTR_ACT) = range(10)

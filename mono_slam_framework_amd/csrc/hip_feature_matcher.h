@@ -51,14 +51,22 @@ class HipMatcherBase {
   HipMatcherBase& operator=(const HipMatcherBase&) = delete;
   virtual ~HipMatcherBase() { msf_destroy(h_); }
 
-  void SetThreshold(float value) { msf_set_threshold(h_, value); }
+  virtual void SetThreshold(float value) { msf_set_threshold(h_, value); }
 
-  MatchResult MatchFrames(const ImageView& f1, const ImageView& f2) {
+  virtual MatchResult MatchFrames(const ImageView& f1, const ImageView& f2) { return match_on(h_, f1, f2); }
+
+  const char* LastError() const { return msf_last_error(h_); }
+  msf_handle* handle() { return h_; }
+  int max_batch_pairs() const { return max_pairs_; }   // capacity of the one-vs-many callers (hip_keyframe_database.h)
+  int result_cap() const { return cap_; }
+
+ protected:
+  MatchResult match_on(msf_handle* h, const ImageView& f1, const ImageView& f2) {
     MatchResult r;
     msf_image a{f1.data, f1.width, f1.height, f1.stride}, b{f2.data, f2.width, f2.height, f2.stride};
     int32_t n = 0;
     buf_.resize(cap_);
-    if (msf_match_pair(h_, &a, &b, buf_.data(), cap_, &n) != MSF_OK || n <= 0) return r;  // empty on any error
+    if (msf_match_pair(h, &a, &b, buf_.data(), cap_, &n) != MSF_OK || n <= 0) return r;  // empty on any error
     if (n > cap_) n = cap_;
     r.keyPoints1.reserve(n);
     r.keyPoints2.reserve(n);
@@ -69,12 +77,6 @@ class HipMatcherBase {
     return r;
   }
 
-  const char* LastError() const { return msf_last_error(h_); }
-  msf_handle* handle() { return h_; }
-  int max_batch_pairs() const { return max_pairs_; }   // capacity of the one-vs-many callers (hip_keyframe_database.h)
-  int result_cap() const { return cap_; }
-
- protected:
   explicit HipMatcherBase(const msf_config& cfg, int cap) : cap_(cap), max_pairs_(cfg.max_batch_pairs) {
     if (msf_create(&cfg, &h_) != MSF_OK)
       throw std::runtime_error(std::string("msf_create: ") + msf_last_error(nullptr));  // the reference's ctor throws too (Ort::Session)
@@ -86,19 +88,74 @@ class HipMatcherBase {
 };
 
 // ::FeatureMatcher(float threshold = 0.8f)  (featurematcher.h:9)
+// The reference matcher takes whatever size the frames it is handed have (cv::ORB sizes its pyramid per call,
+// featurematcher.cpp:10-17).  A device handle is built for one size (image_width x image_height: the size the
+// one-vs-many callers and the batch entry points use), so MatchFrames on a pair of another size goes to a handle of that
+// size, created on first use and kept in a small least-recently-used set; SetThreshold reaches all of them.  The two
+// frames of one call must have the same size (every frame of one camera does); a mixed pair gives an empty result.
 class HipFeatureMatcher : public HipMatcherBase {
  public:
   explicit HipFeatureMatcher(float threshold = 0.8f, int image_width = 640, int image_height = 480, int device = 0,
                              int max_batch_pairs = 1)
-      : HipMatcherBase(make(threshold, image_width, image_height, device, max_batch_pairs), 2048) {}
+      : HipMatcherBase(make(threshold, image_width, image_height, device, max_batch_pairs), 2048),
+        thr_(threshold), w_(image_width), h0_(image_height), dev_(device) {}
+  ~HipFeatureMatcher() override {
+    for (Extra& e : extra_) msf_destroy(e.h);
+  }
+
+  void SetThreshold(float value) override {
+    thr_ = value;
+    msf_set_threshold(h_, value);
+    for (Extra& e : extra_) msf_set_threshold(e.h, value);
+  }
+
+  MatchResult MatchFrames(const ImageView& f1, const ImageView& f2) override {
+    if (f1.width != f2.width || f1.height != f2.height) return MatchResult();
+    if (f1.width == w_ && f1.height == h0_) return match_on(h_, f1, f2);
+    msf_handle* h = handle_for(f1.width, f1.height);
+    return h ? match_on(h, f1, f2) : MatchResult();
+  }
+
+  size_t extra_sizes() const { return extra_.size(); }   // handles held for other frame sizes (tests)
+  static constexpr size_t kMaxExtraSizes = 4;
 
  private:
+  struct Extra {
+    int w, h_dim;
+    msf_handle* h;
+    uint64_t used;
+  };
+  msf_handle* handle_for(int w, int h) {
+    for (Extra& e : extra_)
+      if (e.w == w && e.h_dim == h) { e.used = ++tick_; return e.h; }
+    msf_config c = make(thr_, w, h, dev_, 1);
+    msf_handle* nh = nullptr;
+    if (msf_create(&c, &nh) != MSF_OK) return nullptr;       // e.g. a size outside [64, 8192]: empty result
+    if (extra_.size() >= kMaxExtraSizes) {                     // replace the least recently used size
+      size_t v = 0;
+      for (size_t i = 1; i < extra_.size(); i++)
+        if (extra_[i].used < extra_[v].used) v = i;
+      msf_destroy(extra_[v].h);
+      extra_.erase(extra_.begin() + v);
+    }
+    try {
+      extra_.push_back(Extra{w, h, nh, ++tick_});
+    } catch (...) {
+      msf_destroy(nh);
+      return nullptr;
+    }
+    return nh;
+  }
   static msf_config make(float thr, int w, int h, int dev, int max_pairs) {
     msf_config c;
     msf_default_config(&c, MSF_KIND_ORB);
     c.threshold = thr; c.image_width = w; c.image_height = h; c.device = dev; c.max_batch_pairs = max_pairs;
     return c;
   }
+  float thr_;
+  int w_, h0_, dev_;
+  uint64_t tick_ = 0;
+  std::vector<Extra> extra_;
 };
 
 // ::DNNFeatureMatcher(model_file_path, threshold = 0.15f, image_width = 640, image_height = 480,

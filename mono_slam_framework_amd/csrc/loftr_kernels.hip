@@ -21,6 +21,7 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -3439,10 +3440,20 @@ __global__ __launch_bounds__(256) void k_gather_tokens(const float* __restrict__
   const int i = blockIdx.x * 256 + threadIdx.x, pair = blockIdx.y;
   if (i >= NTOK * DM / 4) return;
   int slot = blockIdx.z ? slot_b[pair] : slot_a[pair];
-  slot = min(max(slot, 0), n_slots - 1);
+  slot = min(max(slot, 0), n_slots - 1);     // a slot outside the caller's range: some valid tokens, the pair is marked below
   const f32x4* src = reinterpret_cast<const f32x4*>(cache + (long long)slot * NTOK * DM);
   f32x4* dst = reinterpret_cast<f32x4*>((blockIdx.z ? f1 : f0) + (long long)pair * NTOK * DM);
   dst[i] = src[i];
+}
+
+// slot arrays come from the caller's device memory and cannot be checked on the host: a pair with a slot outside
+// [0, slot_limit) reports n_out = -1 (msf_abi.h), whatever the clamped gather above made of it
+__global__ __launch_bounds__(256) void k_mark_bad_slots(int n_pairs, const int32_t* __restrict__ slot_a,
+                                                        const int32_t* __restrict__ slot_b, int slot_limit, int32_t* n_out) {
+  const int pair = blockIdx.x * 256 + threadIdx.x;
+  if (pair >= n_pairs) return;
+  const int a = slot_a[pair], b = slot_b[pair];
+  if (a < 0 || a >= slot_limit || b < 0 || b >= slot_limit) n_out[pair] = -1;
 }
 
 // conf_ij = softmax_i(s)_ij * softmax_j(s)_ij, '> threshold' -> bit mask (16-bit chunk per row and column tile);
@@ -4037,11 +4048,11 @@ void launch_conv(const ConvDesc& c, const void* in, long long in_img_stride, int
   static_assert(C::PLANE >= C::RAW, "plane too small");
   const size_t lds = (size_t)CIN * C::PLANE * sizeof(float);
   auto kern = k_conv<CIN, COUT, KS, S, OTW, RELU, RES, U8IN, RP, SC>;
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static std::once_flag attr_once;     // handles on several host threads (msf_multi) may arrive here together
+  std::call_once(attr_once, [&] {
+    if (lds > 48 * 1024)
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  });
   const int n_bands = (c.hout + C::OTH - 1) / C::OTH;     // a workgroup walks the x tiles of its row band
   hipLaunchKernelGGL(kern, dim3(n_bands * n_img), dim3(64 * kConvWaves), lds, st, in, in_img_stride, in_row_stride,
                      RP == 2 ? c.d_w2 : c.d_w, c.d_b, res, out, c.hin, c.win, c.hout, c.wout, sc ? sc->d_w : nullptr,
@@ -4051,11 +4062,10 @@ void launch_conv(const ConvDesc& c, const void* in, long long in_img_stride, int
 // y = relu(conv_b(relu(conv_a(x))) + x) for an 8-channel, stride-1 BasicBlock at 240 x 320 (k_block8)
 void launch_block8(const ConvDesc& ca, const ConvDesc& cb, const float* in, float* out, int n_img, hipStream_t st) {
   const size_t lds = (size_t)blk8::LDS_FLOATS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;     // handles on several host threads (msf_multi) may arrive here together
+  std::call_once(attr_once, [&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_block8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  });
   const int n_bands = ca.hout / blk8::R;      // 240 / 8
   hipLaunchKernelGGL(k_block8, dim3(n_bands * n_img), dim3(256), lds, st, in, ca.d_w2, ca.d_b, cb.d_w2, cb.d_b, out, ca.hout,
                      ca.wout, n_bands);
@@ -4063,11 +4073,10 @@ void launch_block8(const ConvDesc& ca, const ConvDesc& cb, const float* in, floa
 
 // the same block on split-bf16 MFMAs (k_block8x)
 void launch_block8x(const ConvDesc& ca, const ConvDesc& cb, const float* in, float* out, int n_img, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;     // handles on several host threads (msf_multi) may arrive here together
+  std::call_once(attr_once, [&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_block8x), hipFuncAttributeMaxDynamicSharedMemorySize, blk8x::LDS_BYTES);
-    attr_set = true;
-  }
+  });
   const int n_bands = ca.hout / blk8x::R;
   hipLaunchKernelGGL(k_block8x, dim3(n_bands * n_img), dim3(256), blk8x::LDS_BYTES, st, in, ca.d_wx, ca.d_b, cb.d_wx, cb.d_b,
                      out, ca.hout, ca.wout, n_bands);
@@ -4078,11 +4087,10 @@ template <int NB>
 void launch_strip8x(const ConvDesc* cv, const float* in, float* out, int n_img, hipStream_t st) {
   auto kern = k_strip8x<NB>;
   constexpr int lds = strip8::lds_bytes<NB>();
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;     // handles on several host threads (msf_multi) may arrive here together
+  std::call_once(attr_once, [&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
+  });
   StripW sw{};
   for (int c = 0; c < 2 * NB; c++) { sw.wx[c] = cv[c].d_wx; sw.b[c] = cv[c].d_b; }
   const int n_strips = cv[0].wout / strip8::S;
@@ -4093,11 +4101,10 @@ void launch_strip8x(const ConvDesc* cv, const float* in, float* out, int n_img, 
 // stem + first 8-channel BasicBlock as one streaming pass over u8 frames (k_stem_strip8x): convolutions cv[0 .. 3)
 void launch_stem_strip8x(const ConvDesc* cv, const uint8_t* framesA, int nA, const uint8_t* framesB, int nB,
                          long long frame_stride, int row_stride, float* out, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;     // handles on several host threads (msf_multi) may arrive here together
+  std::call_once(attr_once, [&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_stem_strip8x), hipFuncAttributeMaxDynamicSharedMemorySize, stem8::LDS_BYTES);
-    attr_set = true;
-  }
+  });
   StripW sw{};
   for (int c = 0; c < 2; c++) { sw.wx[c] = cv[1 + c].d_wx; sw.b[c] = cv[1 + c].d_b; }
   const int n_strips = cv[1].wout / strip8::S;
@@ -4108,11 +4115,10 @@ void launch_stem_strip8x(const ConvDesc* cv, const uint8_t* framesA, int nA, con
 // down-sampling block 8 -> 16 as one streaming pass (k_down16x): cs2 = 3x3 stride 2, csc = 1x1 stride 2, c2 = 3x3
 void launch_down16x(const ConvDesc& cs2, const ConvDesc& csc, const ConvDesc& c2, const float* in, float* out, int n_img,
                     hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;     // handles on several host threads (msf_multi) may arrive here together
+  std::call_once(attr_once, [&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_down16x), hipFuncAttributeMaxDynamicSharedMemorySize, down16::LDS_BYTES);
-    attr_set = true;
-  }
+  });
   DownW dw{cs2.d_wx, csc.d_wx, c2.d_wx, cs2.d_b, csc.d_b, c2.d_b};
   const int n_strips = c2.wout / down16::S;
   hipLaunchKernelGGL(k_down16x, dim3(n_strips * n_img), dim3(64 * down16::WAVES), down16::LDS_BYTES, st, in, dw, out, c2.hout,
@@ -4121,11 +4127,10 @@ void launch_down16x(const ConvDesc& cs2, const ConvDesc& csc, const ConvDesc& c2
 
 // the 16-channel BasicBlock on split-bf16 MFMAs (k_block16x)
 void launch_block16x(const ConvDesc& ca, const ConvDesc& cb, const float* in, float* out, int n_img, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;     // handles on several host threads (msf_multi) may arrive here together
+  std::call_once(attr_once, [&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_block16x), hipFuncAttributeMaxDynamicSharedMemorySize, blk16x::LDS_BYTES);
-    attr_set = true;
-  }
+  });
   const int n_bands = ca.hout / blk16x::R;
   hipLaunchKernelGGL(k_block16x, dim3(n_bands * n_img), dim3(256), blk16x::LDS_BYTES, st, in, ca.d_wx, ca.d_b, cb.d_wx, cb.d_b,
                      out, ca.hout, ca.wout, n_bands);
@@ -4133,11 +4138,10 @@ void launch_block16x(const ConvDesc& ca, const ConvDesc& cb, const float* in, fl
 
 // the 16-channel BasicBlock as one streaming pass (k_strip16x)
 void launch_strip16x(const ConvDesc& ca, const ConvDesc& cb, const float* in, float* out, int n_img, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;     // handles on several host threads (msf_multi) may arrive here together
+  std::call_once(attr_once, [&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_strip16x), hipFuncAttributeMaxDynamicSharedMemorySize, strip16::LDS_BYTES);
-    attr_set = true;
-  }
+  });
   const int n_strips = ca.wout / strip16::S;
   hipLaunchKernelGGL(k_strip16x, dim3(n_strips * n_img), dim3(64 * strip16::WAVES), strip16::LDS_BYTES, st, in, ca.d_wx, ca.d_b,
                      cb.d_wx, cb.d_b, out, ca.hout, ca.wout, n_strips);
@@ -4146,11 +4150,10 @@ void launch_strip16x(const ConvDesc& ca, const ConvDesc& cb, const float* in, fl
 // down-sampling block 16 -> 32 as one streaming pass (k_down32x): cs2 = 3x3 stride 2, csc = 1x1 stride 2, c2 = 3x3
 void launch_down32x(const ConvDesc& cs2, const ConvDesc& csc, const ConvDesc& c2, const float* in, float* out, int n_img,
                     hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;     // handles on several host threads (msf_multi) may arrive here together
+  std::call_once(attr_once, [&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_down32x), hipFuncAttributeMaxDynamicSharedMemorySize, down32::LDS_BYTES);
-    attr_set = true;
-  }
+  });
   DownW dw{cs2.d_wx, csc.d_wx, c2.d_wx, cs2.d_b, csc.d_b, c2.d_b};
   const int n_strips = (c2.wout + down32::S - 1) / down32::S;
   hipLaunchKernelGGL(k_down32x, dim3(n_strips * n_img), dim3(64 * down32::WAVES), down32::LDS_BYTES, st, in, dw, out, c2.hout,
@@ -4159,11 +4162,10 @@ void launch_down32x(const ConvDesc& cs2, const ConvDesc& csc, const ConvDesc& c2
 
 // a 32-channel BasicBlock as one streaming pass (k_strip32x)
 void launch_strip32x(const ConvDesc& ca, const ConvDesc& cb, const float* in, float* out, int n_img, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;     // handles on several host threads (msf_multi) may arrive here together
+  std::call_once(attr_once, [&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_strip32x), hipFuncAttributeMaxDynamicSharedMemorySize, strip32::LDS_BYTES);
-    attr_set = true;
-  }
+  });
   const int n_strips = (ca.wout + strip32::S - 1) / strip32::S;
   hipLaunchKernelGGL(k_strip32x, dim3(n_strips * n_img), dim3(64 * strip32::WAVES), strip32::LDS_BYTES, st, in, ca.d_wx, ca.d_b,
                      cb.d_wx, cb.d_b, out, ca.hout, ca.wout, n_strips);
@@ -4174,11 +4176,10 @@ template <int C, bool RES>
 void launch_convx(const ConvDesc& c, const float* in, const float* res, float* out, int n_img, hipStream_t st) {
   using F = cvx::Cfg<C>;
   auto kern = k_convx<C, RES>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;     // handles on several host threads (msf_multi) may arrive here together
+  std::call_once(attr_once, [&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, F::LDS_BYTES);
-    attr_set = true;
-  }
+  });
   const int n_bands = (c.hout + cvx::OTH - 1) / cvx::OTH;
   hipLaunchKernelGGL(kern, dim3(n_bands * n_img), dim3(256), F::LDS_BYTES, st, in, c.d_wx, c.d_b, res, out, c.hout, c.wout,
                      n_bands);
@@ -4189,11 +4190,10 @@ template <int CIN>
 void launch_convx2(const ConvDesc& c, const ConvDesc& sc, const float* in, float* out, float* out_sc, int n_img, hipStream_t st) {
   using F = cvx2::Cfg<CIN>;
   auto kern = k_convx2<CIN>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;     // handles on several host threads (msf_multi) may arrive here together
+  std::call_once(attr_once, [&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, F::LDS_BYTES);
-    attr_set = true;
-  }
+  });
   const int n_bands = (c.hout + F::OTH - 1) / F::OTH;
   hipLaunchKernelGGL(kern, dim3(n_bands * n_img), dim3(256), F::LDS_BYTES, st, in, c.d_wx, c.d_b, sc.d_wx, sc.d_b, out, out_sc,
                      c.hin, c.win, c.hout, c.wout, n_bands);
@@ -4202,11 +4202,10 @@ void launch_convx2(const ConvDesc& c, const ConvDesc& sc, const float* in, float
 // the same for a 16-channel, stride-1 BasicBlock at 120 x 160 (k_block16)
 void launch_block16(const ConvDesc& ca, const ConvDesc& cb, const float* in, float* out, int n_img, hipStream_t st) {
   const size_t lds = (size_t)blk16::LDS_FLOATS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;     // handles on several host threads (msf_multi) may arrive here together
+  std::call_once(attr_once, [&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_block16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  });
   const int n_bands = ca.hout / blk16::R;     // 120 / 8
   hipLaunchKernelGGL(k_block16, dim3(n_bands * n_img), dim3(256), lds, st, in, ca.d_w, ca.d_b, cb.d_w, cb.d_b, out, ca.hout,
                      ca.wout, n_bands);
@@ -4259,7 +4258,7 @@ hipError_t LoftrPipeline::extract(int n_frames, const uint8_t* d_frames, long lo
 }
 
 hipError_t LoftrPipeline::match_slots(int n_pairs, const int32_t* d_slot_a, const int32_t* d_slot_b, float threshold,
-                                      msf_match* d_out, int cap, int32_t* d_n_out, hipStream_t st) {
+                                      msf_match* d_out, int cap, int32_t* d_n_out, hipStream_t st, int slot_limit) {
   if (!p_) return hipErrorNotInitialized;
   Impl& P = *p_;
   if (n_pairs > P.max_pairs) return hipErrorInvalidValue;
@@ -4269,7 +4268,11 @@ hipError_t LoftrPipeline::match_slots(int n_pairs, const int32_t* d_slot_a, cons
   hipLaunchKernelGGL(k_gather_tokens, dim3(NTOK * DM / 4 / 256 + 1, n_pairs, 2), dim3(256), 0, st, P.tok_cache,
                      d_slot_a, d_slot_b, P.n_slots, P.tok[0], P.tok[1]);
   if (ev) hipEventRecord(ev[1], st);
-  return transformer_and_head(n_pairs, threshold, d_out, cap, d_n_out, st);
+  const hipError_t e = transformer_and_head(n_pairs, threshold, d_out, cap, d_n_out, st);
+  if (e != hipSuccess) return e;
+  const int limit = slot_limit > 0 && slot_limit < P.n_slots ? slot_limit : P.n_slots;
+  hipLaunchKernelGGL(k_mark_bad_slots, dim3((n_pairs + 255) / 256), dim3(256), 0, st, n_pairs, d_slot_a, d_slot_b, limit, d_n_out);
+  return hipGetLastError();
 }
 
 int LoftrPipeline::max_slots() const { return p_ ? p_->n_slots : 0; }

@@ -27,8 +27,10 @@ class LoftrPipeline {
   // per-frame token cache: frame -> slot [0, 2*max_pairs), then pairs of slots
   hipError_t extract(int n_frames, const uint8_t* d_frames, long long frame_stride, int row_stride, int first_slot,
                      hipStream_t st);
+  // slot_limit > 0: slots at or beyond it give n_out = -1 for the pair (the public entry points pass 2 * max_pairs, so a
+  // caller cannot reach the handle's private cache slots); 0: every slot of the pipeline
   hipError_t match_slots(int n_pairs, const int32_t* d_slot_a, const int32_t* d_slot_b, float threshold,
-                         msf_match* d_out, int cap_per_pair, int32_t* d_n_out, hipStream_t st);
+                         msf_match* d_out, int cap_per_pair, int32_t* d_n_out, hipStream_t st, int slot_limit = 0);
   int max_slots() const;
   int debug_get(int what, int slot, int level, void* host_out, size_t cap, size_t* n_bytes, std::string* err);
   int stage_times(const char** names, float* ms, int cap);

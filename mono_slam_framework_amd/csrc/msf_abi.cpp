@@ -61,6 +61,10 @@ struct msf_handle {
   uint8_t* d_hyp_inl = nullptr;  // [hyp_cap * hyp_match_cap]
   msf_match* d_hyp_m = nullptr;  // [hyp_match_cap]
   int hyp_cap = 0, hyp_match_cap = 0;
+  // msf_render_match_image workspace: the RGB image (allocated once) and the match list + flags (grown on demand)
+  uint8_t* d_render = nullptr;      // [H][2 * W][3]
+  msf_match* d_render_m = nullptr;  // [render_cap] matches, then 2 * render_cap flag bytes
+  int render_cap = 0;
   // Transparent per-frame cache of the drop-in MatchFrames call: the callers loop
   // MatchFrames(X, KF_i) with X fixed (Tracking.cc:595-632, LocalMapping.cc:176,329, KeyFrameDatabase.cc:32,64) and the
   // reference re-extracts both frames every time.  Key = 64-bit content hash of the frame, confirmed by comparing the
@@ -330,8 +334,9 @@ int msf_create(const msf_config* cfg, msf_handle** out) {
     h->cfg.weights_path = nullptr;
     std::string err;
     const bool profile = (cfg->flags & MSF_FLAG_PROFILE) != 0;
-    int n_cache = (cfg->flags & MSF_FLAG_NO_FRAME_CACHE) ? 0 : kFrameCacheSlots;
+    int n_cache = kFrameCacheSlots;
     if (const char* ev = getenv("MSF_FRAME_CACHE_SLOTS")) n_cache = atoi(ev);
+    if (cfg->flags & MSF_FLAG_NO_FRAME_CACHE) n_cache = 0;          // the flag wins over the environment
     n_cache = n_cache < 2 ? 0 : n_cache > 4096 ? 4096 : n_cache;   // a pair needs two entries
     if (const char* ev = getenv("MSF_FRAME_CACHE_HASH_BITS")) {    // tests: a few bits make hash collisions the rule
       const int bits = atoi(ev);
@@ -341,7 +346,8 @@ int msf_create(const msf_config* cfg, msf_handle** out) {
       h->fc_slot0 = 4 * cfg->max_batch_pairs;
       err = h->orb.init(cfg->image_width, cfg->image_height, 4 * cfg->max_batch_pairs + n_cache,
                         (cfg->flags & MSF_FLAG_BLUR_TIE_HALF_UP) != 0, profile, (cfg->flags & MSF_FLAG_FAST_DENSE) != 0,
-                        (cfg->flags & MSF_FLAG_LEVEL_SIZE_MUL_INV) != 0, (cfg->flags & MSF_FLAG_FAST_STREAM) ? 1 : 8);
+                        (cfg->flags & MSF_FLAG_LEVEL_SIZE_MUL_INV) != 0, (cfg->flags & MSF_FLAG_FAST_STREAM) ? 1 : 8,
+                        (cfg->flags & MSF_FLAG_BLUR_SUM256) != 0);
     } else {
       if (cfg->image_width != 640 || cfg->image_height != 480) {
           return fail(nullptr, MSF_ERR_UNSUPPORTED, "LoFTR_teacher is a fixed-shape 1x1x480x640 graph (model/LoFTR_teacher.onnx)");
@@ -392,6 +398,8 @@ void msf_destroy(msf_handle* h) {
   hipFree(h->d_hyp);
   hipFree(h->d_hyp_inl);
   hipFree(h->d_hyp_m);
+  hipFree(h->d_render);
+  hipFree(h->d_render_m);
   hipFree(h->d_fc_slots);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
@@ -501,8 +509,9 @@ int msf_extract_device(msf_handle* h, int32_t n_frames, const uint8_t* d_frames,
     if (!h) return MSF_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(h->mu);
     const bool is_orb = h->cfg.kind == MSF_KIND_ORB;
-    if (n_frames < 0 || !d_frames || first_slot < 0 ||
-        first_slot + n_frames > (is_orb ? 2 * h->cfg.max_batch_pairs : h->loftr.max_slots()))
+    // both kinds: the caller's slots are [0, 2P); what lies beyond (scratch of the stateless calls, the transparent
+    // frame cache) belongs to the handle
+    if (n_frames < 0 || !d_frames || first_slot < 0 || (long long)first_slot + n_frames > 2ll * h->cfg.max_batch_pairs)
       return fail(h, MSF_ERR_INVALID_ARG, "msf_extract_device: slot range outside [0, 2*max_batch_pairs)");
     if (((uintptr_t)d_frames | (uintptr_t)frame_stride | (uintptr_t)row_stride) & 15)
       return fail(h, MSF_ERR_INVALID_ARG, "device frames must be 16-byte aligned with strides multiple of 16");
@@ -537,9 +546,10 @@ int msf_match_slots_device(msf_handle* h, int32_t n_pairs, const int32_t* d_slot
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     if (h->cfg.kind != MSF_KIND_ORB && n_pairs > h->cfg.max_batch_pairs)   // LoFTR works on per-pair token buffers
       return fail(h, MSF_ERR_INVALID_ARG, "n_pairs exceeds max_batch_pairs");
+    const int public_slots = 2 * h->cfg.max_batch_pairs;
     e = h->cfg.kind == MSF_KIND_ORB
-            ? h->orb.match(n_pairs, d_slot_a, d_slot_b, h->cfg.threshold, d_out, cap_per_pair, d_n_out, st)
-            : h->loftr.match_slots(n_pairs, d_slot_a, d_slot_b, h->cfg.threshold, d_out, cap_per_pair, d_n_out, st);
+            ? h->orb.match(n_pairs, d_slot_a, d_slot_b, h->cfg.threshold, d_out, cap_per_pair, d_n_out, st, 0, public_slots)
+            : h->loftr.match_slots(n_pairs, d_slot_a, d_slot_b, h->cfg.threshold, d_out, cap_per_pair, d_n_out, st, public_slots);
     if (e != hipSuccess) return hip_fail(h, "match slots", e);
     if (!stream && (e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(h, "hipStreamSynchronize", e);
     return MSF_OK;
@@ -765,34 +775,36 @@ int msf_render_match_image(msf_handle* h, const msf_image* f1, const msf_image* 
     if (e != hipSuccess) return hip_fail(h, "hipSetDevice", e);
     if (int rc = ensure_stage(h)) return rc;
     hipStream_t st = h->stream;
-    // workspace: the two frames use the staging buffers; the list, flags and the RGB image are allocated per call
+    // workspace: the two frames use the staging buffers; the RGB image is allocated by the first call, the list + flags
+    // buffer grows when a call brings more matches than any before it (no allocation in the steady state)
     uint8_t* dA = h->d_stage;
     uint8_t* dB = h->d_stage + (size_t)h->cfg.max_batch_pairs * h->stage_frame;
-    uint8_t* d_out = nullptr;
-    msf_match* d_m = nullptr;
-    uint8_t* d_flags = nullptr;
     const size_t out_bytes = (size_t)6 * W * H;
-    int rc = MSF_OK;
-    do {
-      if ((e = hipMalloc(&d_out, out_bytes)) != hipSuccess) { rc = hip_fail(h, "hipMalloc", e); break; }
-      if (n_matches) {
-        if ((e = hipMalloc(&d_m, (size_t)n_matches * sizeof(msf_match))) != hipSuccess) { rc = hip_fail(h, "hipMalloc", e); break; }
-        if ((e = hipMalloc(&d_flags, (size_t)2 * n_matches)) != hipSuccess) { rc = hip_fail(h, "hipMalloc", e); break; }
-        hipMemcpyAsync(d_m, matches, (size_t)n_matches * sizeof(msf_match), hipMemcpyHostToDevice, st);
-        hipMemsetAsync(d_flags, 0, (size_t)2 * n_matches, st);
-        if (has_mp1) hipMemcpyAsync(d_flags, has_mp1, n_matches, hipMemcpyHostToDevice, st);
-        if (has_mp2) hipMemcpyAsync(d_flags + n_matches, has_mp2, n_matches, hipMemcpyHostToDevice, st);
-      }
-      hipMemcpy2DAsync(dA, h->stage_pitch, f1->data, f1->stride, W, H, hipMemcpyHostToDevice, st);
-      hipMemcpy2DAsync(dB, h->stage_pitch, f2->data, f2->stride, W, H, hipMemcpyHostToDevice, st);
-      if ((e = msf::render_match_image(dA, dB, W, H, h->stage_pitch, d_m, d_flags, d_flags ? d_flags + n_matches : nullptr,
-                                       n_matches, d_out, 6ll * W, st)) != hipSuccess) { rc = hip_fail(h, "render_match_image", e); break; }
-      if ((e = hipMemcpy2DAsync(out_rgb, out_stride, d_out, (size_t)6 * W, (size_t)6 * W, H, hipMemcpyDeviceToHost, st)) != hipSuccess) { rc = hip_fail(h, "hipMemcpy2DAsync", e); break; }
-      if ((e = hipStreamSynchronize(st)) != hipSuccess) { rc = hip_fail(h, "hipStreamSynchronize", e); break; }
-    } while (0);
-    hipStreamSynchronize(st);
-    hipFree(d_out); hipFree(d_m); hipFree(d_flags);
-    return rc;
+    if (!h->d_render && (e = hipMalloc(&h->d_render, out_bytes)) != hipSuccess) return hip_fail(h, "hipMalloc(render image)", e);
+    if (n_matches > h->render_cap) {
+      if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(h, "hipStreamSynchronize", e);
+      hipFree(h->d_render_m);
+      h->d_render_m = nullptr;
+      h->render_cap = 0;
+      const int cap = n_matches > 4096 ? n_matches : 4096;
+      if ((e = hipMalloc(&h->d_render_m, (size_t)cap * (sizeof(msf_match) + 2))) != hipSuccess) return hip_fail(h, "hipMalloc(render list)", e);
+      h->render_cap = cap;
+    }
+    msf_match* d_m = n_matches ? h->d_render_m : nullptr;
+    uint8_t* d_flags = n_matches ? reinterpret_cast<uint8_t*>(h->d_render_m + h->render_cap) : nullptr;
+    if (n_matches) {
+      if ((e = hipMemcpyAsync(d_m, matches, (size_t)n_matches * sizeof(msf_match), hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(h, "hipMemcpyAsync", e);
+      if ((e = hipMemsetAsync(d_flags, 0, (size_t)2 * n_matches, st)) != hipSuccess) return hip_fail(h, "hipMemsetAsync", e);
+      if (has_mp1 && (e = hipMemcpyAsync(d_flags, has_mp1, n_matches, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(h, "hipMemcpyAsync", e);
+      if (has_mp2 && (e = hipMemcpyAsync(d_flags + n_matches, has_mp2, n_matches, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(h, "hipMemcpyAsync", e);
+    }
+    if ((e = hipMemcpy2DAsync(dA, h->stage_pitch, f1->data, f1->stride, W, H, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(h, "hipMemcpy2DAsync", e);
+    if ((e = hipMemcpy2DAsync(dB, h->stage_pitch, f2->data, f2->stride, W, H, hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(h, "hipMemcpy2DAsync", e);
+    if ((e = msf::render_match_image(dA, dB, W, H, h->stage_pitch, d_m, d_flags, d_flags ? d_flags + n_matches : nullptr,
+                                     n_matches, h->d_render, 6ll * W, st)) != hipSuccess) return hip_fail(h, "render_match_image", e);
+    if ((e = hipMemcpy2DAsync(out_rgb, out_stride, h->d_render, (size_t)6 * W, (size_t)6 * W, H, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(h, "hipMemcpy2DAsync", e);
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(h, "hipStreamSynchronize", e);   // the one wait of the call
+    return MSF_OK;
   } catch (...) {
     return host_exception(h, "msf_render_match_image");
   }
@@ -844,7 +856,8 @@ int msf_frame_cache_stats(msf_handle* h, uint64_t* hits, uint64_t* misses, int32
 int msf_weights_info(const char* path, uint64_t* digest, int32_t* n_tensors, int64_t* n_floats) {
   try {
     if (!path) return fail(nullptr, MSF_ERR_INVALID_ARG, "msf_weights_info: null path");
-    if (std::strcmp(path, "::throw::") == 0) throw std::bad_alloc();   // test hook for the no-exceptions guarantee
+    // test hook for the no-exceptions guarantee, armed only by the test's environment
+    if (std::strcmp(path, "::throw::") == 0 && getenv("MSF_TEST_HOOKS")) throw std::bad_alloc();
     msf::WeightMap w;
     const std::string err = msf::load_weights(path, &w);
     if (!err.empty()) return fail(nullptr, MSF_ERR_IO, err);

@@ -498,7 +498,8 @@ constexpr int kTauBins = 64;             // score histogram bins of width 4 (k_f
 constexpr int kQStat = kTauBins + 2;     // per (slot, level): the quarter's histogram, its strips done, spare
 constexpr int RK = 16;                   // ring rows (power of two)
 constexpr int kWkMaxPx = 244;            // strip pitch <= 244: a group of 4 output px reads two aligned 8-byte pairs <= 8 B apart
-constexpr int kWkRowsTarget = 80, kWkMaxRows = 112;   // owned rows per strip (the emit table of a strip lives in two registers per lane)
+constexpr int kWkMaxRows = 112;          // owned rows per strip at most (a strip's emit table lives in two registers per lane);
+                                         // 80 measured best at 720p (48 / 64 / 80 / 96 / 112 rows: 8.19 / 7.97 / 7.83 / 7.88 / 7.96 ms per step)
 constexpr int kSGCap = 288, kSPCap = 256, kSHCap = 64, kSOCap = 48;   // 10 224 B of LDS per wave: 16 waves per CU
 constexpr uint32_t kSGFlush = 32;        // records that trigger a flush at the end of a four-step group (<= 4 x 64 more arrive)
 static_assert(kSGCap >= (int)kSGFlush + 256, "record list capacity");
@@ -890,6 +891,7 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
     {
       const uint32_t row = (uint32_t)(s + 3) & (RK - 1);
       const uint32_t C = scw[(row << 6) + lane];
+      if (__ballot(C != 0u) != 0ull)               // most rows hold no scored corner at a high threshold
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const bool hit = ((C >> (8 * j)) & 255u) != 0u;
@@ -1533,7 +1535,7 @@ constexpr int HP = 40;
 
 __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
                                                   msf_keypoint* kp, const uint32_t* kp_cnt, uint8_t* desc,
-                                                  int half_up) {
+                                                  int half_up, int sum256) {
   __shared__ __attribute__((aligned(16))) uint8_t raw_s[4][PD * PP + 16];
   __shared__ __attribute__((aligned(16))) uint16_t hb_s[4][PD * HP];
   __shared__ uint32_t disc_s[2 * kDiscTasks];
@@ -1622,8 +1624,10 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
       angle = fast_atan2_deg((float)m01, (float)m10);
       // 7-tap row pass of GaussianBlur(7x7, sigma 2) in its 8u integer form (18 34 49 55 49 34 18): 4 outputs per
       // lane from three aligned dwords, taps applied with v_dot4_u32_u8 on byte windows cut by v_alignbyte
-      constexpr uint32_t kTapLo = 18u | (34u << 8) | (49u << 16) | (55u << 24);
-      constexpr uint32_t kTapHi = 49u | (34u << 8) | (18u << 16);
+      // (MSF_FLAG_BLUR_SUM256: OpenCV's bit-exact fixed-point kernel 18 34 48 56 48 34 18 instead)
+      const uint32_t k2 = sum256 ? 48u : 49u, k3 = sum256 ? 56u : 55u;
+      const uint32_t kTapLo = 18u | (34u << 8) | (k2 << 16) | (k3 << 24);
+      const uint32_t kTapHi = k2 | (34u << 8) | (18u << 16);
       uint32_t* hb32 = reinterpret_cast<uint32_t*>(hb);
       // 45 rows x 10 groups = 450 tasks; the last two (row 44, columns 32..39) would need a sample at x >= 13, y = 19,
       // outside the pattern's reach (bit_pattern_31 has radius <= 18.4): 448 tasks are exactly 7 passes of the wave
@@ -1665,8 +1669,8 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
           const int iy = __float2int_rn(px * b + py * a);
           // column pass at the sampled pixel only
           const uint16_t* q = hb + (PR + iy - 3) * HP + (PR + ix - 3);
-          const uint32_t s = 18u * (q[0] + q[6 * HP]) + 34u * (q[HP] + q[5 * HP]) + 49u * (q[2 * HP] + q[4 * HP]) +
-                             55u * q[3 * HP];
+          const uint32_t s = 18u * (q[0] + q[6 * HP]) + 34u * (q[HP] + q[5 * HP]) + (sum256 ? 48u : 49u) * (q[2 * HP] + q[4 * HP]) +
+                             (sum256 ? 56u : 55u) * q[3 * HP];
           uint32_t r;
           if (half_up) {
             r = (s + 32768u) >> 16;
@@ -1932,11 +1936,12 @@ void OrbPipeline::destroy() {
   } while (0)
 
 std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_half_up, bool profile, bool dense_fast,
-                              bool level_size_mul_inv, int stream_min_frames) {
+                              bool level_size_mul_inv, int stream_min_frames, bool blur_sum256) {
   if (width < 64 || height < 64 || width > 8192 || height > 8192) return "arg: ORB image size must be in [64, 8192] x [64, 8192]";
   if (max_slots < 2) return "arg: ORB max_slots < 2";
   max_slots_ = max_slots;
   half_up_ = blur_half_up;
+  blur_sum256_ = blur_sum256;
   profile_ = profile;
   // MSF_ORB_FAST_TAU forces the first-pass FAST threshold (tests: a value no level can reach sends every level through
   // the check + dense second pass); MSF_FLAG_FAST_DENSE = 20 = the plain dense detector
@@ -1957,6 +1962,11 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   // MSF_ORB_WALK_ROUND: a walker launch whose sampled quarter has fewer strips than this runs as two launches (tests: 0
   // = always one launch, refinement depending on dispatch timing; a huge value = always two)
   if (const char* e = getenv("MSF_ORB_WALK_ROUND")) walk_round_ = atoll(e);
+  // MSF_ORB_WALK_ROWS: rows a walker strip owns (tuning; 32 .. 112)
+  if (const char* e = getenv("MSF_ORB_WALK_ROWS")) {
+    const int v = atoi(e);
+    if (v >= 32 && v <= kWkMaxRows) wk_rows_target_ = v;
+  }
   // MSF_ORB_TAU2_MARGIN_PCT: the second estimate's safety margin in percent of 2N (tests: a few percent makes it overshoot,
   // so that levels fail the check and take the dense second pass)
   tau2_margin_pct_ = kTau2MarginPct;
@@ -2031,7 +2041,7 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     // walker strips over the whole level: 256-px windows wk_px apart ((nx - 1) * wk_px + 256 >= w), wk_rows owned rows
     L.wk_nx = L.w > 256 ? (L.w - 256 + kWkMaxPx - 1) / kWkMaxPx + 1 : 1;
     L.wk_px = L.wk_nx > 1 ? (((L.w - 256 + L.wk_nx - 2) / (L.wk_nx - 1)) + 3) & ~3 : kWkMaxPx;
-    L.wk_ny = (L.h + kWkRowsTarget - 1) / kWkRowsTarget;
+    L.wk_ny = (L.h + wk_rows_target_ - 1) / wk_rows_target_;
     L.wk_rows = (((L.h + L.wk_ny - 1) / L.wk_ny) + 3) & ~3;
     L.wk_ny = (L.h + L.wk_rows - 1) / L.wk_rows;
     L.wk_base = strips;
@@ -2382,15 +2392,16 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
     int bx = 2048 / n;
     bx = bx < 8 ? 8 : bx > 128 ? 128 : bx;
     hipLaunchKernelGGL(k_describe, dim3(bx, n), dim3(256), 0, st, g, src, d_pyr_, d_kp_, d_kp_cnt_, d_desc_,
-                       half_up_ ? 1 : 0);
+                       (half_up_ || blur_sum256_) ? 1 : 0, blur_sum256_ ? 1 : 0);
   }
   if (evs) hipEventRecord(evs[4], st);
   return hipGetLastError();
 }
 
 hipError_t OrbPipeline::match(int n_pairs, const int32_t* d_slot_a, const int32_t* d_slot_b, float ratio,
-                              msf_match* d_out, int cap, int32_t* d_n_out, hipStream_t st, int slot_base) {
+                              msf_match* d_out, int cap, int32_t* d_n_out, hipStream_t st, int slot_base, int slot_limit) {
   if (n_pairs <= 0) return hipSuccess;
+  const int limit = slot_limit > 0 && slot_limit < max_slots_ ? slot_limit : max_slots_;
   // train descriptors go through LDS in chunks of kTrainChunk; MSF_ORB_TRAIN_CHUNK shrinks the chunk so tests can
   // exercise the multi-chunk path with ordinary keypoint counts
   if (ev_ok_ && !ev_extract_pending_) hipEventRecord(ev_[4], st);
@@ -2401,10 +2412,10 @@ hipError_t OrbPipeline::match(int n_pairs, const int32_t* d_slot_a, const int32_
   }();
   if (n_pairs <= kSplitMaxPairs && d_qres_)
     hipLaunchKernelGGL(k_match_split, dim3(kSplitBlocks, n_pairs), dim3(256), 0, st, n_pairs, d_slot_a, d_slot_b, d_kp_,
-                       d_kp_cnt_, d_desc_, d_status_, ratio, d_out, cap, d_n_out, chunk, d_qres_, d_done_, slot_base, max_slots_);
+                       d_kp_cnt_, d_desc_, d_status_, ratio, d_out, cap, d_n_out, chunk, d_qres_, d_done_, slot_base, limit);
   else
     hipLaunchKernelGGL(k_match, dim3(n_pairs), dim3(256), 0, st, n_pairs, d_slot_a, d_slot_b, d_kp_, d_kp_cnt_,
-                       d_desc_, d_status_, ratio, d_out, cap, d_n_out, chunk, slot_base, max_slots_);
+                       d_desc_, d_status_, ratio, d_out, cap, d_n_out, chunk, slot_base, limit);
   if (ev_ok_) {
     hipEventRecord(ev_[5], st);
     ev_recorded_ = true;

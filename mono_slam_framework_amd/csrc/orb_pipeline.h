@@ -68,14 +68,16 @@ class OrbPipeline {
   ~OrbPipeline();
   // returns empty string on success
   std::string init(int width, int height, int max_slots, bool blur_half_up, bool profile, bool dense_fast = false,
-                   bool level_size_mul_inv = false, int stream_min_frames = 8);
+                   bool level_size_mul_inv = false, int stream_min_frames = 8, bool blur_sum256 = false);
   void destroy();
 
   // extract features of n frames into slots [src.slot0, src.slot0 + n)
   hipError_t extract(const FrameSrc& src, int n_frames, hipStream_t st);
   // match slot pairs; d_slot_a/d_slot_b may be null => pair i = (slot_base + i, slot_base + n_pairs + i)
+  // slot_limit > 0: slots at or beyond it give n_out = -1 (public entry points: 2 * max_batch_pairs); 0: max_slots()
   hipError_t match(int n_pairs, const int32_t* d_slot_a, const int32_t* d_slot_b, float ratio,
-                   msf_match* d_out, int cap_per_pair, int32_t* d_n_out, hipStream_t st, int slot_base = 0);
+                   msf_match* d_out, int cap_per_pair, int32_t* d_n_out, hipStream_t st, int slot_base = 0,
+                   int slot_limit = 0);
 
   const OrbGeometry& geom() const { return g_; }
   int max_slots() const { return max_slots_; }
@@ -85,7 +87,7 @@ class OrbPipeline {
  private:
   OrbGeometry g_{};
   int max_slots_ = 0;
-  bool half_up_ = false, profile_ = false;
+  bool half_up_ = false, profile_ = false, blur_sum256_ = false;
   int stream_min_frames_ = 8;      // calls with fewer frames take the dense FAST kernel (latency), others the streaming pass
   int force_tau_ = 0;              // > 0: every (frame, level) starts at this FAST score threshold (20 = dense)
   // device storage
@@ -95,6 +97,7 @@ class OrbPipeline {
   uint32_t* d_qstat_ = nullptr;           // [slots][levels][kTauBins + 2]: score histogram of the sampled quarter's corners,
                                           // its strips done (in-launch threshold refinement, see k_walk)
   bool fast_two_part_ = true;             // MSF_ORB_FAST_ONE_PART=1 clears it: no refinement of the sampler's threshold
+  int wk_rows_target_ = 80;               // owned rows per walker strip (MSF_ORB_WALK_ROWS)
   long long walk_round_ = 4096;           // strips the chip runs at once (16 waves x 256 CUs): see launch_walk
   bool fused_ = true;                     // MSF_ORB_UNFUSED=1 clears it: k_resize x 7, then one FAST-only walker launch
   int tau2_margin_pct_ = 200;             // MSF_ORB_TAU2_MARGIN_PCT

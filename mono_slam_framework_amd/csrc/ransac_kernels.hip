@@ -6,6 +6,8 @@
 // built with -ffp-contract=off and correctly rounded division), and the score is accumulated by ONE lane in match
 // order, two additions per match, exactly like the reference's `score +=` loop -- f32 addition is not associative.
 #include <hip/hip_runtime.h>
+
+#include <mutex>
 #include <stdint.h>
 
 #include "msf_abi.h"
@@ -23,7 +25,7 @@ __global__ __launch_bounds__(256) void k_check_hypotheses(int model, const float
   const int hyp = blockIdx.x, tid = threadIdx.x;
   const float* M = m21 + 9 * hyp;
   const float a11 = M[0], a12 = M[1], a13 = M[2], a21 = M[3], a22 = M[4], a23 = M[5], a31 = M[6], a32 = M[7], a33 = M[8];
-  const float invSigmaSquare = 1.0f / (sigma * sigma);
+  const float inv_var = 1.0f / (sigma * sigma);
   if (model == MSF_MODEL_HOMOGRAPHY) {
     const float* I = m12 + 9 * hyp;
     const float i11 = I[0], i12 = I[1], i13 = I[2], i21 = I[3], i22 = I[4], i23 = I[5], i31 = I[6], i32 = I[7], i33 = I[8];
@@ -31,54 +33,54 @@ __global__ __launch_bounds__(256) void k_check_hypotheses(int model, const float
     for (int i = tid; i < n; i += 256) {
       const msf_match q = matches[i];
       const float u1 = (float)q.x1, v1 = (float)q.y1, u2 = (float)q.x2, v2 = (float)q.y2;
-      bool bIn = true;
+      bool consistent = true;
       // reprojection error in the first image, x2in1 = H12 * x2 (Initializer.cc:368-381)
-      const float w2in1inv = 1.0f / (i31 * u2 + i32 * v2 + i33);
-      const float u2in1 = (i11 * u2 + i12 * v2 + i13) * w2in1inv;
-      const float v2in1 = (i21 * u2 + i22 * v2 + i23) * w2in1inv;
-      const float squareDist1 = (u1 - u2in1) * (u1 - u2in1) + (v1 - v2in1) * (v1 - v2in1);
-      const float chiSquare1 = squareDist1 * invSigmaSquare;
+      const float back_w = 1.0f / (i31 * u2 + i32 * v2 + i33);
+      const float back_x = (i11 * u2 + i12 * v2 + i13) * back_w;
+      const float back_y = (i21 * u2 + i22 * v2 + i23) * back_w;
+      const float d2_first = (u1 - back_x) * (u1 - back_x) + (v1 - back_y) * (v1 - back_y);
+      const float chi_first = d2_first * inv_var;
       float t1 = 0.f;
-      if (chiSquare1 > th) bIn = false; else t1 = th - chiSquare1;
+      if (chi_first > th) consistent = false; else t1 = th - chi_first;
       // reprojection error in the second image, x1in2 = H21 * x1 (:386-399)
-      const float w1in2inv = 1.0f / (a31 * u1 + a32 * v1 + a33);
-      const float u1in2 = (a11 * u1 + a12 * v1 + a13) * w1in2inv;
-      const float v1in2 = (a21 * u1 + a22 * v1 + a23) * w1in2inv;
-      const float squareDist2 = (u2 - u1in2) * (u2 - u1in2) + (v2 - v1in2) * (v2 - v1in2);
-      const float chiSquare2 = squareDist2 * invSigmaSquare;
+      const float fwd_w = 1.0f / (a31 * u1 + a32 * v1 + a33);
+      const float fwd_x = (a11 * u1 + a12 * v1 + a13) * fwd_w;
+      const float fwd_y = (a21 * u1 + a22 * v1 + a23) * fwd_w;
+      const float d2_second = (u2 - fwd_x) * (u2 - fwd_x) + (v2 - fwd_y) * (v2 - fwd_y);
+      const float chi_second = d2_second * inv_var;
       float t2 = 0.f;
-      if (chiSquare2 > th) bIn = false; else t2 = th - chiSquare2;
+      if (chi_second > th) consistent = false; else t2 = th - chi_second;
       terms[2 * i] = t1;
       terms[2 * i + 1] = t2;
-      inliers[(long long)hyp * n + i] = bIn;
+      inliers[(long long)hyp * n + i] = consistent;
     }
   } else {
-    const float th = 3.841f, thScore = 5.991f;
+    const float th = 3.841f, gain_cut = 5.991f;
     for (int i = tid; i < n; i += 256) {
       const msf_match q = matches[i];
       const float u1 = (float)q.x1, v1 = (float)q.y1, u2 = (float)q.x2, v2 = (float)q.y2;
-      bool bIn = true;
+      bool consistent = true;
       // l2 = F21 x1 (Initializer.cc:443-456)
-      const float a2 = a11 * u1 + a12 * v1 + a13;
-      const float b2 = a21 * u1 + a22 * v1 + a23;
-      const float c2 = a31 * u1 + a32 * v1 + a33;
-      const float num2 = a2 * u2 + b2 * v2 + c2;
-      const float squareDist1 = num2 * num2 / (a2 * a2 + b2 * b2);
-      const float chiSquare1 = squareDist1 * invSigmaSquare;
+      const float l2a = a11 * u1 + a12 * v1 + a13;
+      const float l2b = a21 * u1 + a22 * v1 + a23;
+      const float l2c = a31 * u1 + a32 * v1 + a33;
+      const float line2_dot = l2a * u2 + l2b * v2 + l2c;
+      const float d2_first = line2_dot * line2_dot / (l2a * l2a + l2b * l2b);
+      const float chi_first = d2_first * inv_var;
       float t1 = 0.f;
-      if (chiSquare1 > th) bIn = false; else t1 = thScore - chiSquare1;
+      if (chi_first > th) consistent = false; else t1 = gain_cut - chi_first;
       // l1 = x2' F21 (:461-474)
-      const float a1 = a11 * u2 + a21 * v2 + a31;
-      const float b1 = a12 * u2 + a22 * v2 + a32;
-      const float c1 = a13 * u2 + a23 * v2 + a33;
-      const float num1 = a1 * u1 + b1 * v1 + c1;
-      const float squareDist2 = num1 * num1 / (a1 * a1 + b1 * b1);
-      const float chiSquare2 = squareDist2 * invSigmaSquare;
+      const float l1a = a11 * u2 + a21 * v2 + a31;
+      const float l1b = a12 * u2 + a22 * v2 + a32;
+      const float l1c = a13 * u2 + a23 * v2 + a33;
+      const float line1_dot = l1a * u1 + l1b * v1 + l1c;
+      const float d2_second = line1_dot * line1_dot / (l1a * l1a + l1b * l1b);
+      const float chi_second = d2_second * inv_var;
       float t2 = 0.f;
-      if (chiSquare2 > th) bIn = false; else t2 = thScore - chiSquare2;
+      if (chi_second > th) consistent = false; else t2 = gain_cut - chi_second;
       terms[2 * i] = t1;
       terms[2 * i + 1] = t2;
-      inliers[(long long)hyp * n + i] = bIn;
+      inliers[(long long)hyp * n + i] = consistent;
     }
   }
   __syncthreads();
@@ -97,12 +99,11 @@ hipError_t check_hypotheses(int model, int n_hyp, const float* d_m21, const floa
   if (n_hyp <= 0) return hipSuccess;
   if (n > kMaxRansacMatches) return hipErrorInvalidValue;
   const size_t lds = (size_t)2 * (n > 0 ? n : 1) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;     // handles on several host threads (msf_multi) may arrive here together
+  std::call_once(attr_once, [] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_check_hypotheses), hipFuncAttributeMaxDynamicSharedMemorySize,
                         2 * kMaxRansacMatches * (int)sizeof(float));
-    attr_set = true;
-  }
+  });
   hipLaunchKernelGGL(k_check_hypotheses, dim3(n_hyp), dim3(256), lds, st, model, d_m21, d_m12, n, d_matches, sigma,
                      d_scores, d_inliers);
   return hipGetLastError();

@@ -20,7 +20,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("response", "<f4"), ("angle", 
 class Opts(C.Structure):
     _fields_ = [("nfeatures", C.c_int32), ("nlevels", C.c_int32), ("fast_threshold", C.c_int32),
                 ("edge_threshold", C.c_int32), ("blur_tie_even", C.c_int32),
-                ("level_size_mul_inv", C.c_int32)]
+                ("level_size_mul_inv", C.c_int32), ("blur_kernel_sum256", C.c_int32)]
 
 
 def build(force=False):
@@ -57,6 +57,7 @@ def lib():
         L.orb_oracle_level_blurred.argtypes = [C.c_void_p, C.c_int]
         L.orb_oracle_fast_candidates.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.orb_oracle_stage1_keypoints.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.orb_oracle_fast_score_map.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orb_oracle_knn_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                            C.c_float, C.c_void_p, C.c_int]
         L.orb_oracle_knn2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
@@ -80,9 +81,9 @@ class OrbOracle:
     """cv::ORB::create() defaults, as the reference constructs it (featurematcher.cpp:4)."""
 
     def __init__(self, width, height, nfeatures=500, nlevels=8, fast_threshold=20, edge_threshold=31,
-                 blur_tie_even=1, level_size_mul_inv=0):
+                 blur_tie_even=1, level_size_mul_inv=0, blur_kernel_sum256=0):
         self.L = lib()
-        o = Opts(nfeatures, nlevels, fast_threshold, edge_threshold, blur_tie_even, level_size_mul_inv)
+        o = Opts(nfeatures, nlevels, fast_threshold, edge_threshold, blur_tie_even, level_size_mul_inv, blur_kernel_sum256)
         self.nlevels = nlevels
         self.w, self.h = width, height
         self.ctx = self.L.orb_oracle_create(width, height, C.byref(o))
@@ -124,6 +125,14 @@ class OrbOracle:
         p = C.c_void_p()
         n = self.L.orb_oracle_fast_candidates(self.ctx, l, C.byref(p))
         return _arr(p.value, n * 3, np.int32).reshape(n, 3)
+
+    def fast_score_map(self, l):
+        """uint8 [h, w]: FAST score of every pixel before NMS and border reject (0 = not a corner); after extract()"""
+        w, h = self.level_size(l)
+        out = np.zeros((h, w), np.uint8)
+        if self.L.orb_oracle_fast_score_map(self.ctx, l, out.ctypes.data):
+            raise ValueError("bad level")
+        return out
 
     def stage1_keypoints(self):
         p = C.c_void_p()

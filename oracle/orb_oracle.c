@@ -84,6 +84,7 @@ void orb_oracle_default_opts(orb_oracle_opts* o) {
   o->edge_threshold = 31;
   o->blur_tie_even = 1;
   o->level_size_mul_inv = 0;
+  o->blur_kernel_sum256 = 0;
 }
 
 /* Deterministic sin/cos for t in [0, ~2*pi]: Cody-Waite reduction by pi/2 and
@@ -425,7 +426,15 @@ static float ic_angle_at(const orb_oracle_ctx* c, const uint8_t* img, int step, 
  * int32 row pass, int32 column pass, 16 fractional bits dropped with rounding.
  * Out-of-level taps are reflect-101 of the unblurred level (the pyramid's own
  * border holds exactly that). */
-static const int blur_k[7] = {18, 34, 49, 55, 49, 34, 18};
+static const int blur_k257[7] = {18, 34, 49, 55, 49, 34, 18};
+/* blur_kernel_sum256: the kernel of OpenCV's bit-exact fixed-point Gaussian (smooth.dispatch.cpp,
+ * getGaussianKernelFixedPoint_ED, 8 fraction bits): the softdouble weights 256 * g = 17.9607 33.5552 48.8225 55.3231
+ * rounded with error diffusion from the outside in (18, err -0.039; 34, err -0.484; 48, err +0.338) and the centre
+ * tap taking what is left of 256: 18 34 48 56 48 34 18.  That path (fixedSmoothInvoker, ufixedpoint16 rows,
+ * ufixedpoint32 columns) rounds half up, (sum + 32768) >> 16.  cv::ORB does NOT reach it in OpenCV 4.x (its level is a
+ * sub-matrix with a non-isolated border); the switch exists so that a real OpenCV, the day one is
+ * reachable, can be compared against both forms. */
+static const int blur_k256[7] = {18, 34, 48, 56, 48, 34, 18};
 static int reflect101(int i, int n) {
   if (n == 1) return 0;
   while (i < 0 || i >= n) {
@@ -438,6 +447,8 @@ static void blur_level(orb_oracle_ctx* c, int l) {
   int w = c->lw[l], h = c->lh[l];
   const uint8_t* src = c->lvl[l];
   uint8_t* dst = c->blr[l];
+  const int* blur_k = c->o.blur_kernel_sum256 ? blur_k256 : blur_k257;
+  const int tie_even = c->o.blur_tie_even && !c->o.blur_kernel_sum256;   /* the fixed-point path rounds half up */
   int32_t* rows = (int32_t*)malloc(sizeof(int32_t) * (size_t)w * h);
   for (int y = 0; y < h; y++)
     for (int x = 0; x < w; x++) {
@@ -450,7 +461,7 @@ static void blur_level(orb_oracle_ctx* c, int l) {
       int32_t s = 0;
       for (int k = -3; k <= 3; k++) s += blur_k[k + 3] * rows[(size_t)reflect101(y + k, h) * w + x];
       int32_t r;
-      if (c->o.blur_tie_even) {
+      if (tie_even) {
         /* OpenCV's SymmColumnVec_32s8u evaluates sum * 2^-16 in f32 (exact below
          * 256) and rounds to nearest even */
         r = s >> 16;
@@ -586,6 +597,18 @@ const uint8_t* orb_oracle_level_blurred(const orb_oracle_ctx* c, int l) { return
 int orb_oracle_fast_candidates(const orb_oracle_ctx* c, int l, const int32_t** xys) {
   *xys = (const int32_t*)c->cand[l];
   return c->ncand[l];
+}
+/* FAST_t<16> + cornerScore<16> of every pixel of a level BEFORE the 3x3 NMS and the border reject (0 = no corner):
+ * the detector's segment decision on its own, for anchors that hold a FAST-9 of their own (tests/test_fast_anchor.py) */
+int orb_oracle_fast_score_map(const orb_oracle_ctx* c, int l, uint8_t* out) {
+  if (!c || !out || l < 0 || l >= c->o.nlevels) return -1;
+  int w = c->lw[l], h = c->lh[l], t = c->o.fast_threshold;
+  memset(out, 0, (size_t)w * h);
+  if (w < 7 || h < 7) return 0;
+  for (int y = 3; y < h - 3; y++)
+    for (int x = 3; x < w - 3; x++)
+      out[(size_t)y * w + x] = (uint8_t)fast_score_at(c->lvl[l] + (size_t)y * w + x, w, t);
+  return 0;
 }
 int orb_oracle_stage1_keypoints(const orb_oracle_ctx* c, const orb_oracle_kp** kps) {
   *kps = c->s1;

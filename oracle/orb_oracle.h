@@ -36,6 +36,9 @@ typedef struct orb_oracle_opts {
                               `Size sz(cvRound(image.cols/scale), cvRound(image.rows/scale))`);
                               1: cvRound(W * (1.f / scale_l)) (the 2.4-era computeImagePyramid).  The two differ for
                               139 widths in [64, 4096] (69 is the smallest), for none of 640/480/1280/720/1920/1080 */
+  int32_t blur_kernel_sum256; /* 0: the sepFilter2D integer kernel 18 34 49 55 49 34 18 (sum 257, SURVEY.md A.6 default);
+                              1: OpenCV's bit-exact fixed-point Gaussian kernel 18 34 48 56 48 34 18 (sum 256), rounding
+                              half up whatever blur_tie_even says (SURVEY.md A.6 "keep behind a switch") */
 } orb_oracle_opts;
 
 /* one keypoint, 32 bytes */
@@ -69,6 +72,8 @@ const uint8_t* orb_oracle_level_pixels(const orb_oracle_ctx* c, int level);   /*
 const uint8_t* orb_oracle_level_blurred(const orb_oracle_ctx* c, int level);  /* blurred,   stride = w */
 /* FAST candidates after NMS + border reject, row-major; triplets (x, y, score) */
 int orb_oracle_fast_candidates(const orb_oracle_ctx* c, int level, const int32_t** xys);
+/* uint8 [h][w] FAST score of every pixel of a level before NMS / border reject (0 = not a corner); after extract */
+int orb_oracle_fast_score_map(const orb_oracle_ctx* c, int level, uint8_t* out);
 /* keypoints after retainBest(2N) by FAST score + Harris, before the Harris cull (all levels) */
 int orb_oracle_stage1_keypoints(const orb_oracle_ctx* c, const orb_oracle_kp** kps);
 

@@ -33,9 +33,39 @@ int main() {
     matcher.SetThreshold(0.8f);
     msf::MatchResult r2 = matcher.MatchFrames({a.data(), W, H, STEP}, {b.data(), W, H, STEP});
     if (r2.GetNumMatches() < r.GetNumMatches()) return 1;
-    // wrong-size frame: empty result, no throw (reference error behaviour)
-    msf::MatchResult r3 = matcher.MatchFrames({a.data(), 320, 240, STEP}, {b.data(), 320, 240, STEP});
+    // Frames of another size through the SAME object (the reference matcher takes whatever imGray it is given,
+    // src/featurematcher.cpp:10-17): views of 333 x 251 cut out of the same buffers, checked against the oracle at
+    // that size; then the first size again (its handle and frame cache are untouched).
+    {
+      const int W2 = 333, H2 = 251;
+      matcher.SetThreshold(0.6f);
+      const uint8_t* a2 = a.data() + 40 * STEP + 24;
+      const uint8_t* b2 = b.data() + 40 * STEP + 24;
+      msf::MatchResult q = matcher.MatchFrames({a2, W2, H2, STEP}, {b2, W2, H2, STEP});
+      orb_oracle_ctx* c2a = orb_oracle_create(W2, H2, &o);
+      orb_oracle_ctx* c2b = orb_oracle_create(W2, H2, &o);
+      const int n2 = orb_oracle_match_frames(c2a, c2b, a2, STEP, b2, STEP, 0.6f, exp.data(), 4096);
+      orb_oracle_destroy(c2a);
+      orb_oracle_destroy(c2b);
+      if (n2 < 10 || n2 != (int)q.GetNumMatches()) { std::printf("second size: count %d vs %zu\n", n2, q.GetNumMatches()); return 1; }
+      for (int i = 0; i < n2; i++)
+        if (exp[4 * i] != q.keyPoints1[i].x || exp[4 * i + 1] != q.keyPoints1[i].y || exp[4 * i + 2] != q.keyPoints2[i].x ||
+            exp[4 * i + 3] != q.keyPoints2[i].y) { std::printf("second size: mismatch at %d\n", i); return 1; }
+      if (matcher.extra_sizes() != 1) return 1;
+      msf::MatchResult again = matcher.MatchFrames({a.data(), W, H, STEP}, {b.data(), W, H, STEP});
+      if (again.GetNumMatches() != r.GetNumMatches()) return 1;
+      // six more sizes: the set of extra handles stays bounded (least recently used size replaced)
+      for (int k = 0; k < 6; k++) {
+        msf::MatchResult t = matcher.MatchFrames({a2, 200 + 16 * k, 160, STEP}, {b2, 200 + 16 * k, 160, STEP});
+        (void)t;
+      }
+      if (matcher.extra_sizes() > msf::HipFeatureMatcher::kMaxExtraSizes) return 1;
+    }
+    // frames of two different sizes in one call, or a size no handle can be built for: empty result, no throw
+    msf::MatchResult r3 = matcher.MatchFrames({a.data(), 320, 240, STEP}, {b.data(), 640, 480, STEP});
     if (r3.GetNumMatches() != 0) return 1;
+    msf::MatchResult r4 = matcher.MatchFrames({a.data(), 32, 32, STEP}, {b.data(), 32, 32, STEP});
+    if (r4.GetNumMatches() != 0) return 1;
     std::printf("host mirror ok: %d matches\n", n);
     return 0;
   } catch (const std::exception& e) {

@@ -163,6 +163,18 @@ def test_token_cache_extract_once_match_many():
     assert cnt[1] > 100                                # a frame matches itself on (nearly) every cell
     with pytest.raises(Exception):
         dm.extract_device(dF[:2], first_slot=159)      # slots are [0, 2*max_batch_pairs)
+    with pytest.raises(Exception):
+        dm.extract_device(dF[:1], first_slot=160)      # the first slot of the handle's private frame cache
+    # a slot index outside [0, 2 * max_batch_pairs) gives n_out = -1 for that pair (the handle's own cache slots
+    # included: they exist in the pipeline, but not for the caller); the other pairs are unaffected
+    sa2 = np.array([3, 160, 3, -1], np.int32)
+    sb2 = np.array([137, 5, 223, 5], np.int32)
+    out3 = torch.zeros((4, 2048, 4), dtype=torch.int32, device="cuda")
+    cnt3 = torch.zeros((4,), dtype=torch.int32, device="cuda")
+    dm.match_slots_device(torch.from_numpy(sa2).cuda(), torch.from_numpy(sb2).cuda(), out3, cnt3)
+    cnt3 = cnt3.cpu().numpy()
+    assert cnt3[1] == -1 and cnt3[2] == -1 and cnt3[3] == -1, cnt3
+    np.testing.assert_array_equal(out3[0, :cnt3[0]].cpu().numpy(), G["matches_ii_015"])
 
 
 def test_sparse_head_equals_dense_head(monkeypatch):

@@ -76,5 +76,10 @@ def test_malformed_files_are_io_errors(tmp_path):
 def test_no_exception_crosses_the_abi():
     """msf_abi.h promises plain status codes: a host exception inside an entry point (std::bad_alloc, forced here by a
     test hook) comes back as MSF_ERR_HIP with a message, not as a C++ exception through the C caller."""
-    rc, _, _, _, msg = _info("::throw::")
+    os.environ["MSF_TEST_HOOKS"] = "1"       # arms the hook (the library reads it at the call)
+    try:
+        rc, _, _, _, msg = _info("::throw::")
+    finally:
+        del os.environ["MSF_TEST_HOOKS"]
     assert rc == _lib.MSF_ERR_HIP and "host exception" in msg
+    assert _info("::throw::")[0] == _lib.MSF_ERR_IO       # unarmed: an ordinary missing file
