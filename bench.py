@@ -103,40 +103,95 @@ def cpu_baseline_loftr(args, A, B, gpu_lists):
             "host": host, "match_list_mismatches_vs_gpu": mism}
 
 
+ORB_SWITCHES = ("blur_tie_even", "level_size_mul_inv", "blur_kernel_sum256")   # the oracle's / product's open choices
+
+
 def opencv_probe(args, A, B, gpu_lists):
     """SURVEY.md H1 / BASELINE.md 3.2: if a real OpenCV happens to be importable on this box, run the literal reference
-    sequence (cv::ORB::create() defaults, detectAndCompute x2, BFMatcher(NORM_HAMMING).knnMatch(k=2), ratio test,
-    int truncation: src/featurematcher.cpp:3-45) on the same pairs and record how the GPU lists compare with it.
-    Never required: absent -> {"opencv": "absent"}."""
+    sequence (cv::ORB::create() defaults, detectAndCompute x2 with an all-255 mask, BFMatcher(NORM_HAMMING).knnMatch(k=2),
+    ratio test, int truncation: src/featurematcher.cpp:3-45) on the same pairs and record (a) how the GPU lists compare
+    with it and (b) WHICH combination of the restatement's documented open choices (blur rounding, blur
+    kernel, level-size formula) reproduces the library -- key-point set, descriptor bytes and match set are scored
+    for all 8 combinations, not just the default.  Never required: absent -> {"opencv": "absent"}."""
     try:
         import cv2
     except Exception:
         return {"opencv": "absent"}
+    import itertools
     import numpy as np
-    n = min(len(A), 16)
+    from oracle import orb as oracle_orb
+    n = min(len(A), 8)
     orb = cv2.ORB_create()
     bf = cv2.BFMatcher(cv2.NORM_HAMMING)
     t0 = time.perf_counter()
-    same_list = same_set = 0
-    jacc = []
+    ref = []          # per pair: (features of A, features of B, match list); features = {key: descriptor bytes}
     for i in range(n):
-        k1, d1 = orb.detectAndCompute(A[i], np.full(A[i].shape, 255, np.uint8))
-        k2, d2 = orb.detectAndCompute(B[i], np.full(B[i].shape, 255, np.uint8))
+        feats = []
+        kd = []
+        for im in (A[i], B[i]):
+            k, d = orb.detectAndCompute(im, np.full(im.shape, 255, np.uint8))
+            d = np.zeros((0, 32), np.uint8) if d is None else np.asarray(d)
+            kd.append((k, d))
+            feats.append({(int(q.octave) & 255, np.float32(q.pt[0]).tobytes(), np.float32(q.pt[1]).tobytes()): d[j].tobytes()
+                          for j, q in enumerate(k)})
+        (k1, d1), (k2, d2) = kd
         m = []
-        if d1 is not None and d2 is not None and len(k2) >= 2:
+        if len(k1) and len(k2) >= 2:
             for pr in bf.knnMatch(d1, d2, k=2):
                 if len(pr) == 2 and pr[0].distance < args.ratio * pr[1].distance:
                     p1, p2 = k1[pr[0].queryIdx].pt, k2[pr[0].trainIdx].pt
                     m.append((int(p1[0]), int(p1[1]), int(p2[0]), int(p2[1])))
-        g = [tuple(r) for r in gpu_lists[i].tolist()]
-        same_list += int(g == m)
-        same_set += int(set(g) == set(m))
-        u = len(set(g) | set(m))
-        jacc.append(len(set(g) & set(m)) / u if u else 1.0)
+        ref.append((feats[0], feats[1], m))
     dt = time.perf_counter() - t0
+
+    def score(lists_of, feats_of):
+        kp_same = desc_same = desc_all = set_same = list_same = 0
+        jacc = []
+        for i in range(n):
+            ra, rb, rm = ref[i]
+            for mine, theirs in zip(feats_of(i), (ra, rb)):
+                kp_same += int(set(mine) == set(theirs))
+                common = set(mine) & set(theirs)
+                desc_all += len(common)
+                desc_same += sum(1 for k_ in common if mine[k_] == theirs[k_])
+            g = [tuple(r) for r in np.asarray(lists_of(i)).reshape(-1, 4).tolist()]
+            list_same += int(g == rm)
+            set_same += int(set(g) == set(rm))
+            u = len(set(g) | set(rm))
+            jacc.append(len(set(g) & set(rm)) / u if u else 1.0)
+        return {"frames_with_identical_keypoint_set": kp_same, "of_frames": 2 * n,
+                "descriptors_identical": desc_same, "of_common_keypoints": desc_all,
+                "identical_match_sets": set_same, "identical_ordered_lists": list_same, "of_pairs": n,
+                "mean_match_set_jaccard": round(float(np.mean(jacc)), 4)}
+
+    sweep = []
+    for combo in itertools.product((0, 1), repeat=len(ORB_SWITCHES)):
+        kw = dict(zip(ORB_SWITCHES, combo))
+        orc = oracle_orb.FeatureMatcherOracle(args.ratio, **kw)
+        cache = {}
+
+        def run(i, orc=orc, cache=cache):
+            if i not in cache:
+                (ka, da), (kb, db) = orc.extract_both(A[i], B[i])
+                f = [{(int(q["octave"]), np.float32(q["x"]).tobytes(), np.float32(q["y"]).tobytes()): d_[j].tobytes()
+                      for j, q in enumerate(k_)} for k_, d_ in ((ka, da), (kb, db))]
+                cache[i] = (f, oracle_orb.knn_match(ka, da, kb, db, args.ratio))
+            return cache[i]
+        r = score(lambda i: run(i)[1], lambda i: run(i)[0])
+        r["switches"] = kw
+        sweep.append(r)
+    rank = lambda r: (r["frames_with_identical_keypoint_set"], r["descriptors_identical"], r["identical_match_sets"])
+    best = max(sweep, key=rank)
+    default = next(r for r in sweep if r["switches"] == {"blur_tie_even": 1, "level_size_mul_inv": 0, "blur_kernel_sum256": 0})
+    gpu = score(lambda i: gpu_lists[i], lambda i: ({}, {}))
     return {"opencv": cv2.__version__, "pairs": n, "pairs_per_sec_1thread": round(n / dt, 3),
-            "identical_ordered_lists": same_list, "identical_match_sets": same_set,
-            "mean_match_set_jaccard": round(float(np.mean(jacc)), 4)}
+            "gpu_default_vs_opencv": {k: gpu[k] for k in ("identical_match_sets", "identical_ordered_lists", "of_pairs",
+                                                          "mean_match_set_jaccard")},
+            "restatement_default_vs_opencv": default,
+            "best_switches": best["switches"], "best_is_exact": bool(
+                best["frames_with_identical_keypoint_set"] == 2 * n and best["descriptors_identical"] == best["of_common_keypoints"]
+                and best["identical_match_sets"] == n),
+            "default_is_best": rank(default) == rank(best), "sweep": sweep}
 
 
 def run_workload(args, matcher, W, H, P, ratio_or_thr, loftr_f32, rank, world, local_rank, dev, cdev, with_cpu):

@@ -248,6 +248,33 @@ int msf_multi_match_batch_device(msf_multi* m, const int32_t* n_pairs, const uin
                                  const uint8_t* const* d_b, int64_t frame_stride, int64_t row_stride,
                                  msf_match* const* d_out, int32_t cap_per_pair, int32_t* const* d_n_out);
 
+/* -------- multi-process gather of the match lists --------
+ * One process per GPU; rank r owns the contiguous block of pairs msf_multi_shard_range reports and computes it with no
+ * data-path collective.  The one exchange step is the gather of the packed lists (msf_pack_matches_device) to rank 0:
+ * an ncclAllGather of the per-pair offsets (pairs_per_rank + 1 int32 per rank), then exact-size ncclSend / ncclRecv of
+ * the int32[4] records in one group call -- RCCL over xGMI, never an all-reduce.  The reference has no counterpart (one
+ * matcher, one thread: src/main.cpp:65,78-82).  RCCL is bound at first use (dlopen), so libmsf.so does not depend on it.
+ *   msf_gather_unique_id   rank 0: 128 bytes to hand to every rank through the job's own channel (ncclGetUniqueId)
+ *   msf_gather_create      every rank, collectively (ncclCommInitRank on `device`)
+ *   msf_gather_matches_device  every rank, collectively, asynchronous on `stream` except for ONE wait (the totals are
+ *       needed on the host to size the transfers): d_packed / d_offsets as msf_pack_matches_device wrote them;
+ *       d_all_offsets [n_ranks][pairs_per_rank + 1] (device, every rank) receives every rank's offsets; totals
+ *       [n_ranks] (HOST) the record counts; on rank 0 d_recv [n_ranks * cap_records] receives the lists densely packed
+ *       in rank order (pair p of rank r starts at sum(totals[0..r)) + d_all_offsets[r][p]); other ranks pass NULL.
+ *       MSF_ERR_CAPACITY if a rank holds more than cap_records records (nothing is transferred then).
+ *   msf_gather_plan        the placement arithmetic on its own (host only; unit-tested without a GPU).
+ * Executed so far: on one MI355X with a one-rank communicator; the send / recv leg has not run on more than one GPU. */
+typedef struct msf_gather msf_gather;
+int msf_gather_unique_id(uint8_t* id128);
+int msf_gather_create(int32_t device, int32_t rank, int32_t n_ranks, const uint8_t* id128, int32_t pairs_per_rank,
+                      int64_t cap_records, msf_gather** out);
+void msf_gather_destroy(msf_gather* g);
+const char* msf_gather_last_error(const msf_gather* g); /* g may be NULL: error of the last failed create / unique_id */
+int msf_gather_plan(int32_t n_ranks, int32_t pairs_per_rank, const int32_t* all_offsets, int64_t cap_records,
+                    int32_t* totals, int64_t* recv_first);
+int msf_gather_matches_device(msf_gather* g, const msf_match* d_packed, const int32_t* d_offsets, int32_t* d_all_offsets,
+                              msf_match* d_recv, int32_t* totals, void* stream);
+
 /* -------- introspection used by the parity tests and bench.py (not by the drop-in path) -------- */
 typedef enum msf_debug_what {
   MSF_DBG_LEVEL_SIZES = 0,   /* int32 [nlevels][4] = w, h, row pitch, quota */

@@ -38,7 +38,9 @@ ABI_SYMBOLS = ["msf_abi_version", "msf_default_config", "msf_create", "msf_destr
                "msf_render_match_image", "msf_weights_info", "msf_convert_weights",
                "msf_frame_cache_stats", "msf_multi_create", "msf_multi_destroy", "msf_multi_device_count",
                "msf_multi_handle", "msf_multi_set_threshold", "msf_multi_last_error", "msf_multi_shard_range",
-               "msf_multi_match_batch", "msf_multi_match_batch_device"]
+               "msf_multi_match_batch", "msf_multi_match_batch_device",
+               "msf_gather_unique_id", "msf_gather_create", "msf_gather_destroy", "msf_gather_last_error",
+               "msf_gather_plan", "msf_gather_matches_device"]
 
 
 class Config(C.Structure):
@@ -111,6 +113,14 @@ def load():
     L.msf_multi_match_batch.argtypes = [vp, i32, C.POINTER(Image), C.POINTER(Image), vp, i32, vp]
     L.msf_multi_match_batch_device.argtypes = [vp, C.POINTER(i32), C.POINTER(vp), C.POINTER(vp), i64, i64, C.POINTER(vp), i32,
                                                C.POINTER(vp)]
+    L.msf_gather_unique_id.argtypes = [vp]
+    L.msf_gather_create.argtypes = [i32, i32, i32, vp, i32, i64, C.POINTER(vp)]
+    L.msf_gather_destroy.argtypes = [vp]
+    L.msf_gather_destroy.restype = None
+    L.msf_gather_last_error.argtypes = [vp]
+    L.msf_gather_last_error.restype = C.c_char_p
+    L.msf_gather_plan.argtypes = [i32, i32, vp, i64, vp, vp]
+    L.msf_gather_matches_device.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     _lib = L
     return L
 

@@ -9,7 +9,7 @@ LIB = os.path.join(_HERE, "libmsf.so")
 SYNTH = os.path.join(_HERE, "libmsf_synth.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-HIP_SOURCES = ["msf_abi.cpp", "msf_multi.cpp", "weights_io.cpp", "orb_kernels.hip", "loftr_kernels.hip", "pack_kernels.hip",
+HIP_SOURCES = ["msf_abi.cpp", "msf_multi.cpp", "msf_gather.cpp", "weights_io.cpp", "orb_kernels.hip", "loftr_kernels.hip", "pack_kernels.hip",
                "ransac_kernels.hip"]
 # -ffp-contract=off + correctly rounded f32 divide: the few f32 steps inside ORB
 # (Harris response, fastAtan2, pattern rotation) must round exactly like the CPU.
@@ -42,7 +42,7 @@ def build_lib(force=False, verbose=False):
     """hipcc cross-compiles for gfx950 without a GPU."""
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     if force or _stale(LIB, _deps()):
-        cmd = [HIPCC] + HIP_FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB] + srcs
+        cmd = [HIPCC] + HIP_FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB] + srcs + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
