@@ -224,7 +224,11 @@ int msf_pack_matches_device(msf_handle* h, int32_t n_pairs, const msf_match* d_i
  * per entry of device_ids (NULL = devices 0 .. n_devices-1; an id may repeat: two shards then share a card) and
  * msf_multi_match_batch gives shard r the contiguous block of ceil(n_pairs / G) pairs msf_multi_shard_range reports --
  * the partition of bench.py's ranks -- on one host thread per shard; every shard writes its block of out / n_out, which
- * therefore come back in pair order, exactly as from msf_match_batch on one handle with the same cfg.
+ * therefore come back in pair order, exactly as from msf_match_batch on one handle with the same cfg -- bit for bit for
+ * ORB, and for LoFTR under MSF_FLAG_LOFTR_F32.  On LoFTR's default split-bf16 path the kernel family follows the size of
+ * a call (streaming ResNet kernels from 64 images, the three-tile similarity pass from 8 pairs), and the families agree
+ * to ~1e-5 in confidence (bar 1e-3): a shard of another size than the whole batch can gain or lose a match whose
+ * confidence lies that close to the threshold (tests/test_multi_device.py::test_loftr_lists_do_not_depend_on_...).
  * Returns MSF_OK, MSF_ERR_CAPACITY if that is the only failure of any shard, else the first hard error
  * (msf_multi_last_error names the shard).  msf_multi_handle: the shard's own handle, for callers that keep frames
  * resident per device and drive the *_device entry points themselves (one host thread per device); owned by the

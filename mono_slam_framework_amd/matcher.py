@@ -286,7 +286,9 @@ class DNNFeatureMatcher(_Matcher):
 class MultiDeviceMatcher:
     """One matcher over several GPUs of one process (msf_multi_*, include/msf_abi.h): a batch is cut into contiguous
     blocks of ceil(n / G) pairs, one per device, each run by that device's own handle on its own host thread; the lists
-    come back in pair order, identical to one handle's.  `devices` may name a device twice (two shards share the card).
+    come back in pair order, identical to one handle's (bit for bit for ORB and for LoFTR with MSF_FLAG_LOFTR_F32; LoFTR's
+    default split-bf16 kernels depend on the call size and agree to ~1e-5 in confidence: include/msf_abi.h).  `devices`
+    may name a device twice (two shards share the card).
     kind: "orb" (::FeatureMatcher) or "loftr" (::DNNFeatureMatcher).  The reference has no multi-GPU form; a
     multi-process job (bench.py --gpus N) uses ordinary matchers, one per rank."""
 

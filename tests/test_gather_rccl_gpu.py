@@ -13,7 +13,7 @@ def test_one_rank_communicator_round_trip():
     from mono_slam_framework_amd import synth
     from mono_slam_framework_amd.gather import RcclMatchListGather
     from mono_slam_framework_amd.matcher import FeatureMatcher
-    n, w, h, cap = 6, 333, 251, 1024
+    n, w, h, cap = 6, 320, 240, 1024
     A, B = synth.synth_batch(4200, n, w, h)
     dev = torch.device("cuda", 0)
     fm = FeatureMatcher(0.7, w, h, max_batch_pairs=n)

@@ -86,6 +86,42 @@ def test_loftr_three_shards_equal_one_handle():
 
 
 @pytest.mark.gpu
+def test_loftr_lists_do_not_depend_on_the_call_size():
+    """A LoFTR call of >= 64 images takes the streaming ResNet kernels, a smaller one the banded ones; calls of >= 8 pairs
+    the three-tile similarity pass, smaller ones the one-tile pass.  With MSF_FLAG_LOFTR_F32 every variant is the same
+    k-ordered f32 chain: one batch of 40 pairs, 40 single-pair calls and four shards of 10 give bit-equal confidences
+    (pair 0's matrix) and identical lists.  On the default split-bf16 path the variants agree to ~1e-5 in confidence
+    (msf_abi.h says so): lists are identical except where a confidence lies that close to the threshold."""
+    from mono_slam_framework_amd.matcher import DNNFeatureMatcher, MultiDeviceMatcher
+    n = 40
+    A, B = synth.synth_batch(4700, n, 640, 480, mode=1)
+    for f32 in (True, False):
+        fl = _lib.MSF_FLAG_NO_FRAME_CACHE | _lib.MSF_FLAG_KEEP_DEBUG | (_lib.MSF_FLAG_LOFTR_F32 if f32 else 0)
+        big = DNNFeatureMatcher(None, 0.15, 640, 480, max_batch_pairs=n, flags=fl)
+        ref = big.match_batch(list(A), list(B), cap=4096)               # one call: 80 images
+        conf_big = big.conf_matrix(0).copy()
+        one = DNNFeatureMatcher(None, 0.15, 640, 480, max_batch_pairs=1, flags=fl)
+        single = [one.MatchFrames(A[i], B[i], cap=4096) for i in range(n)]
+        one.MatchFrames(A[0], B[0], cap=4096)
+        conf_one = one.conf_matrix(0).copy()
+        multi = MultiDeviceMatcher("loftr", 0.15, 640, 480, devices=(0, 0, 0, 0), max_batch_pairs=n, flags=fl)
+        sharded = multi.match_batch(list(A), list(B), cap=4096)         # four shards of 10 pairs
+        assert sum(len(r) for r in ref) > 20 * n
+        if f32:
+            np.testing.assert_array_equal(conf_big.view(np.uint32), conf_one.view(np.uint32))
+            for r, s_, m in zip(ref, single, sharded):
+                np.testing.assert_array_equal(r, s_)
+                np.testing.assert_array_equal(r, m)
+        else:
+            assert np.abs(conf_big - conf_one).max() < 1e-4
+            differ = sum(1 for r, s_, m in zip(ref, single, sharded)
+                         if not (r.shape == s_.shape == m.shape and np.array_equal(r, s_) and np.array_equal(r, m)))
+            assert differ <= 2, differ          # a list may gain / lose an entry whose confidence is within 1e-5 of 0.15
+        for x in (big, one, multi):
+            x.close()
+
+
+@pytest.mark.gpu
 def test_shard_errors_name_the_shard():
     from mono_slam_framework_amd.matcher import MsfError, MultiDeviceMatcher
     multi = MultiDeviceMatcher("orb", 0.7, 320, 240, devices=(0, 0), max_batch_pairs=4)
