@@ -730,6 +730,11 @@ constexpr int RROWS = 12;                          // six row pairs per ring (fi
 constexpr int RING = RROWS * XP;                   // pixel slots per plane
 constexpr int TAIL = 16;                           // the fifth M tile of a stage reads up to 10 slots past a ring row
 constexpr int WAVES = 8;
+// k_strip8x: a step of one block has 5 + 4 M-tile jobs (stage 1 writes two halo columns more than stage 2), so with 8
+// waves one wave of stage 1 takes two jobs.  Tried (r03): 10 waves, 5 per stage, every wave at most one job -- the kernel
+// needs 118 VGPRs (24 of weight fragments, 32 of load queue), two workgroups per CU would need <= 96: forced there it
+// spills 60 B per lane and runs 1.47 ms against 0.62 (one workgroup per CU, unforced: not faster either).  8 it stays.
+constexpr int BLK_WAVES = 8;
 template <int NB>
 constexpr int lds_bytes() { return 16 * (2 * NB * 2 * RING + TAIL); }
 __device__ __forceinline__ int ring_row(int r) {   // r mod 12 for r >= -24 (multiply-shift exact below 1200)
@@ -743,10 +748,11 @@ struct StripW {
   const float* b[4];
 };
 
-template <int NB>
-__global__ __launch_bounds__(64 * strip8::WAVES) void k_strip8x(const float* __restrict__ in, StripW sw, float* __restrict__ out,
-                                                                int H, int W, int n_strips) {
+template <int NB, int WV>
+__global__ __launch_bounds__(64 * WV) void k_strip8x(const float* __restrict__ in, StripW sw, float* __restrict__ out,
+                                                     int H, int W, int n_strips) {
   using namespace strip8;
+  constexpr int WAVES = WV;                        // (hides strip8::WAVES, the stem kernel's count)
   constexpr int NS = 2 * NB;                       // convolution stages
   constexpr int WPS = WAVES / NS;                  // waves per stage
   constexpr int MAXJOBS = (5 + WPS - 1) / WPS;
@@ -4085,7 +4091,8 @@ void launch_block8x(const ConvDesc& ca, const ConvDesc& cb, const float* in, flo
 // NB chained 8-channel BasicBlocks as one streaming pass (k_strip8x): convolutions cv[0 .. 2 NB)
 template <int NB>
 void launch_strip8x(const ConvDesc* cv, const float* in, float* out, int n_img, hipStream_t st) {
-  auto kern = k_strip8x<NB>;
+  constexpr int WVW = strip8::BLK_WAVES;
+  auto kern = k_strip8x<NB, WVW>;
   constexpr int lds = strip8::lds_bytes<NB>();
   static std::once_flag attr_once;     // handles on several host threads (msf_multi) may arrive here together
   std::call_once(attr_once, [&] {
@@ -4094,8 +4101,7 @@ void launch_strip8x(const ConvDesc* cv, const float* in, float* out, int n_img, 
   StripW sw{};
   for (int c = 0; c < 2 * NB; c++) { sw.wx[c] = cv[c].d_wx; sw.b[c] = cv[c].d_b; }
   const int n_strips = cv[0].wout / strip8::S;
-  hipLaunchKernelGGL(kern, dim3(n_strips * n_img), dim3(64 * strip8::WAVES), lds, st, in, sw, out, cv[0].hout, cv[0].wout,
-                     n_strips);
+  hipLaunchKernelGGL(kern, dim3(n_strips * n_img), dim3(64 * WVW), lds, st, in, sw, out, cv[0].hout, cv[0].wout, n_strips);
 }
 
 // stem + first 8-channel BasicBlock as one streaming pass over u8 frames (k_stem_strip8x): convolutions cv[0 .. 3)

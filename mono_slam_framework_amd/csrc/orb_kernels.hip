@@ -608,7 +608,13 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
   const uint8_t* img = level_ptr(g, src, pyr, fi, l, &pitch);
   // lanes right of the row's end re-read its last dword (weight-0 taps, never scored); rows outside the image re-read
   // its first / last row (warm-up above row 0, the idle tail steps, the weight-0 lower tap of the last output row)
-  const uint8_t* gp = img + (xb + 4 <= pitch ? xb : pitch - 4);
+  // Lanes whose pixels nobody needs -- the windows of neighbouring strips overlap by 256 - wk_px columns, of which FAST
+  // needs 4 and the resize at most 16 -- re-read the nearest needed dword instead of their own: the overlap is then
+  // fetched once (the neighbour runs at another time: what it shares with this strip has left the L2 by then).
+  const int need_lo = RESIZE ? xs : max(ox0 - 4, xs);
+  const int need_hi = sx == L.wk_nx - 1 ? pitch : (RESIZE ? xs + L.wk_px + 16 : ox1 + 4);     // exclusive, multiples of 4
+  const int xl = min(max(xb, need_lo & ~3), ((need_hi + 3) & ~3) - 4);
+  const uint8_t* gp = img + (xl + 4 <= pitch ? xl : pitch - 4);
   const int ylim = L.h - 1;
 #define LOAD_ROW(y_) (*reinterpret_cast<const uint32_t*>(gp + (long long)max(min((y_), ylim), 0) * pitch))
   // the first ten pixel rows are requested before anything else: the state of the (frame, level) below is one more

@@ -12,8 +12,10 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STAGE = {"k_resize": "pyramid", "k_fast": "fast_nms", "k_fast_tau": "fast_nms", "k_fast_stream": "fast_nms",
-         "k_fast_check": "fast_nms", "k_fast_tau2": "fast_nms", "k_fast_redo": "fast_nms", "k_thr_harris": "select_harris", "k_select": "select_harris",
+# r03: the fused walker (k_walk<true> of levels 0..6, k_walk<false> of the last level) and the threshold samplers between
+# its launches are the stage "pyramid_fast"; what is left of "fast_nms" is the check and the dense redo
+STAGE = {"k_resize": "pyramid", "k_fast": "fast_nms", "k_fast_tau": "pyramid_fast", "k_walk": "pyramid_fast",
+         "k_fast_check": "fast_nms", "k_fast_redo": "fast_nms", "k_thr_harris": "select_harris", "k_select": "select_harris",
          "k_describe": "orient_describe", "k_match": "match", "k_conv": "backbone_convs", "k_tokens": "backbone_convs",
          "k_block8": "backbone_convs", "k_block16": "backbone_convs", "k_block8x": "backbone_convs",
          "k_block16x": "backbone_convs", "k_convx": "backbone_convs", "k_down16x": "backbone_convs",
@@ -60,7 +62,7 @@ def mfma_busy(write):
     return out
 
 
-def main(tag="r02", steps=6):
+def main(tag="r03", steps=6):
     base = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     for which in ("orb", "loftr", "loftr_f32"):
         if not os.path.isdir(os.path.join(base, which + "_fetch")):
