@@ -739,8 +739,8 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
 #define RZ_EMIT(j_, hu_, hl_)                                                                                          \
   do {                                                                                                                 \
     const int jj_ = (j_);                                                                                              \
-    const uint32_t em_ = jj_ < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)em_lo, jj_ & 63)                          \
-                                  : (uint32_t)__builtin_amdgcn_readlane((int)em_hi, jj_ & 63);                         \
+    /* one select + one v_readlane (a ternary of two readlanes compiles to branches) */                                 \
+    const uint32_t em_ = (uint32_t)__builtin_amdgcn_readlane((int)(jj_ < 64 ? em_lo : em_hi), jj_ & 63);               \
     if ((int)em_ < 0) {                                                                                                \
       const uint32_t wy1_ = (em_ >> 16) & 0x1FFu, wy0_ = 256u - wy1_;                                                  \
       const uint32_t v0_ = mad_u24(hu_[0], wy0_, mad_u24(hl_[0], wy1_, 32768u));                                       \
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
   //  2. the cardinal prefilters of the four rows (ring indices s_, s_ + 3, s_ + 6; see fast_tile for the SWAR form):
   //     the row three below comes from the register just stored, the others from the ring;
   //  3. the four record appends.
-#define STREAM_PRE(U_, C_, D_, s_, cb_, cd_)                                                                           \
+#define STREAM_PRE(U_, C_, D_, vmr_, cb_, cd_)                                                                          \
   do {                                                                                                                 \
     const uint32_t Lf_ = __builtin_amdgcn_update_dpp(0u, C_, 0x138, 0xf, 0xf, true); /* wave_shr:1: lane i <- i-1 */   \
     const uint32_t Rt_ = __builtin_amdgcn_update_dpp(0u, C_, 0x130, 0xf, 0xf, true); /* wave_shl:1: lane i <- i+1 */   \
@@ -945,9 +945,8 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
     const uint32_t b8_ = __builtin_amdgcn_lerp(l8_, lerp_bright, 0), b12_ = __builtin_amdgcn_lerp(l12_, lerp_bright, 0);   \
     const uint32_t n0_ = __builtin_amdgcn_lerp(l0_, lerp_not_dark, 0), n4_ = __builtin_amdgcn_lerp(l4_, lerp_not_dark, 0); \
     const uint32_t n8_ = __builtin_amdgcn_lerp(l8_, lerp_not_dark, 0), n12_ = __builtin_amdgcn_lerp(l12_, lerp_not_dark, 0); \
-    const uint32_t vmr_ = ((s_) >= s_lo && (s_) <= s_hi) ? vm : 0u;      /* rows outside the strip's scored rows */       \
-    cb_ = ((b0_ | b8_) & (b4_ | b12_)) & vmr_;                                                                         \
-    cd_ = ~((n0_ & n8_) | (n4_ & n12_)) & vmr_;                                                                        \
+    cb_ = ((b0_ | b8_) & (b4_ | b12_)) & (vmr_);                                                                       \
+    cd_ = ~((n0_ & n8_) | (n4_ & n12_)) & (vmr_);                                                                      \
   } while (0)
 #define STREAM_APPEND(s_, cb_, cd_)                                                                                    \
   do {                                                                                                                 \
@@ -985,10 +984,18 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
       for (int k = 0; k < 4; k++) hp[k] = hd[k];
     }
     uint32_t cb0, cd0, cb1, cd1, cb2, cd2, cb3, cd3;
-    STREAM_PRE(u0, u3, d0, s, cb0, cd0);
-    STREAM_PRE(u1, c1, d1, s + 1, cb1, cd1);
-    STREAM_PRE(u2, c2, d2, s + 2, cb2, cd2);
-    STREAM_PRE(u3, d0, d3, s + 3, cb3, cd3);       // the centre row of step s + 3 is the row stored first in this group
+    // rows outside the strip's scored rows [s_lo, s_hi] only occur in its first and last groups: one test per group
+    uint32_t vm0 = vm, vm1 = vm, vm2 = vm, vm3 = vm;
+    if (s < s_lo || s + 3 > s_hi) {
+      vm0 = (s >= s_lo && s <= s_hi) ? vm : 0u;
+      vm1 = (s + 1 >= s_lo && s + 1 <= s_hi) ? vm : 0u;
+      vm2 = (s + 2 >= s_lo && s + 2 <= s_hi) ? vm : 0u;
+      vm3 = (s + 3 >= s_lo && s + 3 <= s_hi) ? vm : 0u;
+    }
+    STREAM_PRE(u0, u3, d0, vm0, cb0, cd0);
+    STREAM_PRE(u1, c1, d1, vm1, cb1, cd1);
+    STREAM_PRE(u2, c2, d2, vm2, cb2, cd2);
+    STREAM_PRE(u3, d0, d3, vm3, cb3, cd3);         // the centre row of step s + 3 is the row stored first in this group
     STREAM_APPEND(s, cb0, cd0);
     STREAM_APPEND(s + 1, cb1, cd1);
     STREAM_APPEND(s + 2, cb2, cd2);
