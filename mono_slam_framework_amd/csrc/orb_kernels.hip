@@ -1934,6 +1934,10 @@ void OrbPipeline::destroy() {
     hipFree(d_redo2_);
     d_redo2_ = nullptr;
   }
+  for (int k = 1; k < kMaxChains - 1; k++)
+    if (chain_stream_[k]) { hipStreamSynchronize(chain_stream_[k]); hipStreamDestroy(chain_stream_[k]); chain_stream_[k] = nullptr; }
+  for (auto& e : chain_ev_) if (e) { hipEventDestroy(e); e = nullptr; }
+  chain_stream_[0] = nullptr;
   if (tau_stream_) {
     hipStreamSynchronize(tau_stream_);
     for (auto& e : tau_ev_) hipEventDestroy(e);
@@ -1975,6 +1979,11 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   // MSF_ORB_WALK_ROUND: a walker launch whose sampled quarter has fewer strips than this runs as two launches (tests: 0
   // = always one launch, refinement depending on dispatch timing; a huge value = always two)
   if (const char* e = getenv("MSF_ORB_WALK_ROUND")) walk_round_ = atoll(e);
+  // MSF_ORB_TAU_SITES: sampled runs of 4 px per (frame, level) of the threshold sampler (tuning; default 1024)
+  if (const char* e = getenv("MSF_ORB_TAU_SITES")) {
+    const int v = atoi(e);
+    if (v >= 128 && v <= 65536) tau_sites_ = v;
+  }
   // MSF_ORB_WALK_ROWS: rows a walker strip owns (tuning; 32 .. 112)
   if (const char* e = getenv("MSF_ORB_WALK_ROWS")) {
     const int v = atoi(e);
@@ -2070,7 +2079,7 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     if (L.tiles_x > 0) {
       const int rh = L.h - 2 * kEdge;
       const int n_dw = (L.w - kEdge - ((kEdge + 3) & ~3)) >> 2;          // aligned dwords fully inside [31, w - 31)
-      const double s2 = (double)n_dw * rh / 1024.0;                      // (dword, row) sites per sampled run
+      const double s2 = (double)n_dw * rh / (double)tau_sites_;         // (dword, row) sites per sampled run
       int sx = (int)(sqrt(s2 > 1.0 ? s2 : 1.0) / 4.0);
       sx = (sx < 1 ? 1 : sx) | 1;
       int sy = (int)(s2 / sx + 0.5);
@@ -2199,6 +2208,14 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   }
   if (!getenv("MSF_ORB_NO_SIDE_STREAM")) {
     MSF_HIP_TRY(hipStreamCreateWithFlags(&tau_stream_, hipStreamNonBlocking));
+    chain_stream_[0] = tau_stream_;
+    for (int k = 1; k < kMaxChains - 1; k++) MSF_HIP_TRY(hipStreamCreateWithFlags(&chain_stream_[k], hipStreamNonBlocking));
+    for (auto& e : chain_ev_) MSF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (getenv("MSF_ORB_ONE_CHAIN")) chains_ = 1;
+    if (const char* e = getenv("MSF_ORB_CHAINS")) {
+      const int v = atoi(e);
+      if (v >= 1 && v <= kMaxChains) chains_ = v;
+    }
     const int parts = getenv("MSF_ORB_SPLIT2") ? atoi(getenv("MSF_ORB_SPLIT2")) : 0;   // opt-in: see orb_pipeline.h
     if (parts >= 2) {
       MSF_HIP_TRY(hipStreamCreateWithFlags(&split_stream_, hipStreamNonBlocking));
@@ -2332,15 +2349,23 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
       }
       launch_walk(false, g.nlevels - 1, g.nlevels - 1, fs, nf, s_);
     };
-    const bool halves = allow_side && tau_stream_ != nullptr && n >= 256 && !getenv("MSF_ORB_ONE_CHAIN");
-    if (halves) {
-      const int n0 = n / 2;
+    // chains_ parts of the batch (default 2; MSF_ORB_CHAINS, MSF_ORB_ONE_CHAIN=1), each at least 128 frames
+    int K = (allow_side && tau_stream_ != nullptr) ? chains_ : 1;
+    while (K > 1 && n / K < 128) K--;
+    if (K > 1) {
       hipEventRecord(tau_ev_[0], st);
-      hipStreamWaitEvent(tau_stream_, tau_ev_[0], 0);
-      chain(src, n0, 0, st);
-      chain(sub_src(n0), n - n0, n0, tau_stream_);
-      hipEventRecord(tau_ev_[kOrbLevels], tau_stream_);
-      hipStreamWaitEvent(st, tau_ev_[kOrbLevels], 0);
+      int f0 = 0;
+      for (int k = 0; k < K; k++) {
+        const int f1 = (int)((long long)n * (k + 1) / K);
+        hipStream_t sk = k == 0 ? st : chain_stream_[k - 1];
+        if (k > 0) hipStreamWaitEvent(sk, tau_ev_[0], 0);
+        chain(k == 0 ? src : sub_src(f0), f1 - f0, f0, sk);
+        if (k > 0) {
+          hipEventRecord(chain_ev_[k - 1], sk);
+          hipStreamWaitEvent(st, chain_ev_[k - 1], 0);
+        }
+        f0 = f1;
+      }
     } else {
       chain(src, n, 0, st);
     }

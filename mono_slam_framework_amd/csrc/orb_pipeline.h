@@ -97,6 +97,7 @@ class OrbPipeline {
   uint32_t* d_qstat_ = nullptr;           // [slots][levels][kTauBins + 2]: score histogram of the sampled quarter's corners,
                                           // its strips done (in-launch threshold refinement, see k_walk)
   bool fast_two_part_ = true;             // MSF_ORB_FAST_ONE_PART=1 clears it: no refinement of the sampler's threshold
+  int tau_sites_ = 1024;                  // sample sites of k_fast_tau per (frame, level) (MSF_ORB_TAU_SITES)
   int wk_rows_target_ = 80;               // owned rows per walker strip (MSF_ORB_WALK_ROWS)
   long long walk_round_ = 4096;           // strips the chip runs at once (16 waves x 256 CUs): see launch_walk
   bool fused_ = true;                     // MSF_ORB_UNFUSED=1 clears it: k_resize x 7, then one FAST-only walker launch
@@ -118,6 +119,10 @@ class OrbPipeline {
   hipEvent_t ev_[kOrbStages + 2] = {};
   bool ev_ok_ = false, ev_recorded_ = false, ev_extract_pending_ = false, ev_match_only_ = false;
   FrameSrc last_src_{};
+  static constexpr int kMaxChains = 4;          // chains of a fused extraction: the caller's stream + up to 3 of these
+  hipStream_t chain_stream_[kMaxChains - 1] = {};   // [0] = tau_stream_
+  hipEvent_t chain_ev_[kMaxChains - 1] = {};
+  int chains_ = 2;
   hipStream_t tau_stream_ = nullptr;            // k_fast_tau of a batch runs here, underneath the pyramid kernels
   hipEvent_t tau_ev_[kOrbLevels + 1] = {};      // level l exists (fork points), all thresholds written (join)
   // Opt-in (MSF_ORB_SPLIT2=K, K = 2 .. 8): a batch of >= 256 frames is extracted as K sub-batches, alternately on the
