@@ -2148,7 +2148,13 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
       int c = (int)(b0 / (uint32_t)Ls.wk_px);
       if (c > Ls.wk_nx - 1) c = Ls.wk_nx - 1;
       const uint32_t xs = (uint32_t)(c * Ls.wk_px);
-      if (b0 < xs || b3 < b0 || b3 + 8u > xs + 256u) fused = false;   // both 8-byte pairs inside the 256-px window
+      // every tap that counts lies inside the 256-px window; the second dword of a pair may stick out of it (it then
+      // holds only weight-0 taps: the replicated last pixel) -- the read stays inside the wave's LDS block
+      if (b0 < xs || b3 < b0 || b3 + 4u > xs + 256u) fused = false;
+      for (int k = 0; k < 4; k++) {
+        const uint32_t cx = xt[4 * gq + k] & 0xFFFFu, w1 = xt[4 * gq + k] >> 16;
+        if (cx < xs || cx >= xs + 256u || (cx + 1u >= xs + 256u && w1 != 0u)) fused = false;
+      }
       for (int cc = 0; cc <= c; cc++) xstrip[cc] = (uint32_t)gq;       // groups are monotone in b0: the last write is the first group
     }
     for (int c = 0; c < Ls.wk_nx; c++)

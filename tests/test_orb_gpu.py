@@ -547,6 +547,8 @@ def test_split_extraction_equals_single_pass(monkeypatch):
     split = FeatureMatcher(0.7, 320, 240, max_batch_pairs=n, flags=fl)
     got = split.match_batch(list(A), list(B), cap=1024)
     st = split.stage_times()
-    assert set(st) == {"pyramid", "fast_nms", "select_harris", "orient_describe", "match"} and all(v > 0 for v in st.values())
+    # (the first stage is "pyramid_fast" when the walker makes the pyramid, "pyramid" in the unfused form)
+    assert set(st) in ({"pyramid_fast", "fast_nms", "select_harris", "orient_describe", "match"},
+                       {"pyramid", "fast_nms", "select_harris", "orient_describe", "match"}) and all(v > 0 for v in st.values())
     for r, g in zip(ref, got):
         np.testing.assert_array_equal(r, g)
