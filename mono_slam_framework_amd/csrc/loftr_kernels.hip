@@ -725,7 +725,11 @@ __global__ __launch_bounds__(256, 2) void k_block8x(const float* __restrict__ in
 // contiguous bytes per channel row).  A wave holds only its own stage's weight fragments (24 VGPRs).
 namespace strip8 {
 constexpr int S = 64;                              // output columns per strip
-constexpr int XP = 72;                             // ring row pitch in pixels (widest ring: 64 + 2 * 4 columns)
+// ring row pitch in pixels (widest ring: 64 + 2 * 4 columns).  r03 counters for k_strip8x: waves wait 52 % of their
+// cycles (barrier / s_waitcnt), issue in 26 %; SQ_LDS_BANK_CONFLICT is 45 % of the LDS cycles.  A pitch of 80 slots (rows a
+// multiple of 256 B apart, so that the 16 slots a ds_read_b128 lane group takes from two ring rows meet no bank twice)
+// changed nothing: 642 vs 617 us -- the conflicts are not in the fragment reads, and they are not what bounds the step.
+constexpr int XP = 72;
 constexpr int RROWS = 12;                          // six row pairs per ring (five are live in a step)
 constexpr int RING = RROWS * XP;                   // pixel slots per plane
 constexpr int TAIL = 16;                           // the fifth M tile of a stage reads up to 10 slots past a ring row
