@@ -739,6 +739,12 @@ constexpr int WAVES = 8;
 // needs 118 VGPRs (24 of weight fragments, 32 of load queue), two workgroups per CU would need <= 96: forced there it
 // spills 60 B per lane and runs 1.47 ms against 0.62 (one workgroup per CU, unforced: not faster either).  8 it stays.
 constexpr int BLK_WAVES = 8;
+// Tried (r03): strips of 62 columns (MSF_LOFTR_STRIP8_S=62) -- stage 1 then writes 64 columns = 4 M tiles and stage 2
+// 62 = 4 tiles, 8 jobs for 8 waves in ONE round per step instead of 5 + 4 jobs in two; six strips instead of five, the last
+// overlapping its neighbour.  774 vs 617 us: exactly the 6 / 5 more strips, i.e. a step costs the same with one job less
+// on its busiest wave.  The kernel moves 2.46 GB in 0.617 ms = 4.0 TB/s of mixed read + write traffic: it runs at what
+// the memory system gives, and the step time is the prefetch distance (4 steps) into the loaded-memory latency.
+constexpr int SB_NARROW = 62;
 template <int NB>
 constexpr int lds_bytes() { return 16 * (2 * NB * 2 * RING + TAIL); }
 __device__ __forceinline__ int ring_row(int r) {   // r mod 12 for r >= -24 (multiply-shift exact below 1200)
@@ -752,11 +758,12 @@ struct StripW {
   const float* b[4];
 };
 
-template <int NB, int WV>
+template <int NB, int WV, int SB>
 __global__ __launch_bounds__(64 * WV) void k_strip8x(const float* __restrict__ in, StripW sw, float* __restrict__ out,
                                                      int H, int W, int n_strips) {
   using namespace strip8;
   constexpr int WAVES = WV;                        // (hides strip8::WAVES, the stem kernel's count)
+  constexpr int S = SB;                            // output columns per strip (hides strip8::S, the stem kernel's 64)
   constexpr int NS = 2 * NB;                       // convolution stages
   constexpr int WPS = WAVES / NS;                  // waves per stage
   constexpr int MAXJOBS = (5 + WPS - 1) / WPS;
@@ -765,7 +772,9 @@ __global__ __launch_bounds__(64 * WV) void k_strip8x(const float* __restrict__ i
   const int nwg = gridDim.x, per = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7;
   const int unit = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);     // XCD-contiguous (image, strip) order
   const int img = __builtin_amdgcn_readfirstlane(unit / n_strips);              // SGPRs: uniform base pointers below
-  const int X0 = __builtin_amdgcn_readfirstlane((unit - img * n_strips) * S);
+  // strips are S columns apart; the last one is moved left to end at the image's edge (it recomputes columns of its
+  // neighbour: the same values, written twice)
+  const int X0 = __builtin_amdgcn_readfirstlane(min((unit - img * n_strips) * S, W - S));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int HW = H * W;                            // one image is 8 HW floats: 32-bit offsets from wave-uniform bases
@@ -775,7 +784,7 @@ __global__ __launch_bounds__(64 * WV) void k_strip8x(const float* __restrict__ i
   // this wave's stage (1-based) and its share of the stage's M tiles
   const int cst = __builtin_amdgcn_readfirstlane(wave / WPS) + 1, ws = __builtin_amdgcn_readfirstlane(wave % WPS);
   const bool last = cst == NS, has_res = (cst & 1) == 0;
-  const int MT = last ? 4 : 5;                     // M tiles: 64 (+ 2 (NS - c) halo) columns
+  const int MT = (S + 2 * (NS - cst) + 15) / 16;   // M tiles: S (+ 2 (NS - c) halo) columns
 
   bf16x8 wh[3], wl[3];
   {
@@ -881,7 +890,7 @@ __global__ __launch_bounds__(64 * WV) void k_strip8x(const float* __restrict__ i
       }
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       if (last) {
-        {
+        if (j < S) {                               // (the last tile of a 62-column strip holds two columns of the next strip)
           const int orow = 2 * p + (kq >> 1);
           const uint32_t oo = 4u * (uint32_t)((4 * (kq & 1) * H + orow) * W + X0 + j);   // byte offset from the SGPR base
           char* ob = reinterpret_cast<char*>(outf);
@@ -4096,16 +4105,23 @@ void launch_block8x(const ConvDesc& ca, const ConvDesc& cb, const float* in, flo
 template <int NB>
 void launch_strip8x(const ConvDesc* cv, const float* in, float* out, int n_img, hipStream_t st) {
   constexpr int WVW = strip8::BLK_WAVES;
-  auto kern = k_strip8x<NB, WVW>;
+  static const bool narrow = NB == 1 && getenv("MSF_LOFTR_STRIP8_S") && atoi(getenv("MSF_LOFTR_STRIP8_S")) == 62;
+  auto kern_n = k_strip8x<NB, WVW, strip8::SB_NARROW>;
+  auto kern_w = k_strip8x<NB, WVW, strip8::S>;
   constexpr int lds = strip8::lds_bytes<NB>();
   static std::once_flag attr_once;     // handles on several host threads (msf_multi) may arrive here together
   std::call_once(attr_once, [&] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern_n), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern_w), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   });
   StripW sw{};
   for (int c = 0; c < 2 * NB; c++) { sw.wx[c] = cv[c].d_wx; sw.b[c] = cv[c].d_b; }
-  const int n_strips = cv[0].wout / strip8::S;
-  hipLaunchKernelGGL(kern, dim3(n_strips * n_img), dim3(64 * WVW), lds, st, in, sw, out, cv[0].hout, cv[0].wout, n_strips);
+  const int Wd = cv[0].wout, Sd = narrow ? strip8::SB_NARROW : strip8::S;
+  const int n_strips = (Wd - Sd + Sd - 1) / Sd + 1;
+  if (narrow)
+    hipLaunchKernelGGL(kern_n, dim3(n_strips * n_img), dim3(64 * WVW), lds, st, in, sw, out, cv[0].hout, Wd, n_strips);
+  else
+    hipLaunchKernelGGL(kern_w, dim3(n_strips * n_img), dim3(64 * WVW), lds, st, in, sw, out, cv[0].hout, Wd, n_strips);
 }
 
 // stem + first 8-channel BasicBlock as one streaming pass over u8 frames (k_stem_strip8x): convolutions cv[0 .. 3)
