@@ -1071,17 +1071,50 @@ constexpr int kTauListCap = 2048;     // prefilter survivors kept per (frame, le
                                       // lower, still valid, tau)
 __global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, const uint8_t* pyr, int force_tau,
                                                   uint32_t* tau, uint32_t* tau_first, uint32_t* redo_cnt,
-                                                  uint32_t* redo_list, int level0, uint32_t* qstat, int fi_base) {
+                                                  uint32_t* redo_list, int level0, uint32_t* qstat, int fi_base,
+                                                  int predict_pct) {
   __shared__ uint32_t hist[kTauBins];
   __shared__ uint32_t list[kTauListCap];
   __shared__ uint32_t nlist;
+  __shared__ int predicted;
   const int l = level0 + blockIdx.x, fi = blockIdx.y, slot = src.slot0 + fi, tid = threadIdx.x;
   const OrbLevelInfo L = g.lv[l];
   // the walker's refinement state of this (frame, level): histogram and done count start at 0, word kTauBins + 1 is the
   // threshold in force (written below; the walker raises it with atomicMax, k_fast_check copies it to tau[])
   if (tid <= kTauBins) qstat[(size_t)(slot * kOrbLevels + l) * kQStat + tid] = 0;
   int tv = kFastT, pre_used = kTauPre;
-  if (force_tau > 0) {
+  // Prediction from the level above (predict_pct > 0; fused chain only: the walker of level l - 1 has finished).  The
+  // sampled quarter of level l - 1 left the histogram of its exact corners; level l shows the same scene 1.2 x smaller,
+  // so the first threshold of level l is the largest multiple of 4 at which level l - 1 -- scaled from the quarter to
+  // the level -- still holds predict_pct % of the corner DENSITY level l needs for its 2N.  It only steers the quarter of
+  // level l (the rest refines from that quarter's own corners) and k_fast_check + the dense redo catch an overshoot, so
+  // whatever comes out here the result is the dense one.  No usable histogram (a dense level above, fewer than two
+  // sampled strips, too few corners): the sampler below runs as before.
+  if (tid == 0) predicted = 0;
+  __syncthreads();
+  if (predict_pct > 0 && force_tau == 0 && l > 0 && L.tiles_x > 0 && tid < 64) {
+    const OrbLevelInfo Lp = g.lv[l - 1];
+    const uint32_t* pq = qstat + (size_t)(slot * kOrbLevels + l - 1) * kQStat;
+    const int n_strips = Lp.wk_nx * Lp.wk_ny, qa = (n_strips + 3) / 4;    // a fused launch covers one level: its quarter
+    const uint32_t done = pq[kTauBins], t_q = tau_first[slot * kOrbLevels + l - 1];
+    uint32_t c = pq[tid];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_down(c, o);
+      if (tid + o < 64) c += up;
+    }
+    if (qa >= kTau2MinStrips && done >= (uint32_t)qa && t_q > (uint32_t)kFastT) {
+      const long long a_prev = (long long)(Lp.w - 2 * kEdge) * (Lp.h - 2 * kEdge), a_cur = (long long)(L.w - 2 * kEdge) * (L.h - 2 * kEdge);
+      // corners the QUARTER must hold at or above t: predict_pct % x 2N_l x (area above / area here) x (quarter / level)
+      const long long need = ((long long)predict_pct * 2 * L.quota * a_prev * qa + 100ll * a_cur * n_strips - 1) / (100ll * a_cur * n_strips);
+      const unsigned long long ok = __ballot((long long)c >= need && 4u * tid >= t_q);
+      if (ok && tid == 0) predicted = 4 * (63 - __builtin_clzll(ok));
+    }
+  }
+  __syncthreads();
+  if (predicted > kFastT) {
+    tv = predicted;
+  } else if (force_tau > 0) {
     tv = force_tau;
   } else if (L.samp_rows > 0) {
     if (tid < kTauBins) hist[tid] = 0;
@@ -1979,6 +2012,12 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   // MSF_ORB_WALK_ROUND: a walker launch whose sampled quarter has fewer strips than this runs as two launches (tests: 0
   // = always one launch, refinement depending on dispatch timing; a huge value = always two)
   if (const char* e = getenv("MSF_ORB_WALK_ROUND")) walk_round_ = atoll(e);
+  // MSF_ORB_TAU_PREDICT: percent of the needed corner density the prediction of a level's first threshold from the level
+  // above keeps (0 = sample every level, the r02 behaviour)
+  if (const char* e = getenv("MSF_ORB_TAU_PREDICT")) {
+    const int v = atoi(e);
+    if (v >= 0 && v <= 2000) tau_predict_pct_ = v;
+  }
   // MSF_ORB_TAU_SITES: sampled runs of 4 px per (frame, level) of the threshold sampler (tuning; default 1024)
   if (const char* e = getenv("MSF_ORB_TAU_SITES")) {
     const int v = atoi(e);
@@ -2347,11 +2386,11 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
     // half's walkers.  Both chains lie between the same two stage events.
     auto chain = [&](const FrameSrc& fs, int nf, int f0, hipStream_t s_) {
       hipLaunchKernelGGL(k_fast_tau, dim3(1, nf), dim3(256), 0, s_, g, fs, d_pyr_, force_tau, tau, tau_first, d_redo_,
-                         d_redo_ + 1, 0, d_qstat_, f0);
+                         d_redo_ + 1, 0, d_qstat_, f0, 0);
       for (int l = 1; l < g.nlevels; l++) {
         launch_walk(true, l - 1, l - 1, fs, nf, s_);
         hipLaunchKernelGGL(k_fast_tau, dim3(1, nf), dim3(256), 0, s_, g, fs, d_pyr_, force_tau, tau, tau_first, d_redo_,
-                           d_redo_ + 1, l, d_qstat_, f0);
+                           d_redo_ + 1, l, d_qstat_, f0, dyn ? tau_predict_pct_ : 0);
       }
       launch_walk(false, g.nlevels - 1, g.nlevels - 1, fs, nf, s_);
     };
@@ -2385,7 +2424,7 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
       hipEventRecord(tau_ev_[0], st);
       hipStreamWaitEvent(tau_stream_, tau_ev_[0], 0);
       hipLaunchKernelGGL(k_fast_tau, dim3(1, n), dim3(256), 0, tau_stream_, g, src, d_pyr_, force_tau, tau, tau_first, d_redo_,
-                         d_redo_ + 1, 0, d_qstat_, 0);
+                         d_redo_ + 1, 0, d_qstat_, 0, 0);
     }
     for (int l = 1; l < g.nlevels; l++) {
       launch_resize(l);
@@ -2393,7 +2432,7 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
         hipEventRecord(tau_ev_[l], st);
         hipStreamWaitEvent(tau_stream_, tau_ev_[l], 0);
         hipLaunchKernelGGL(k_fast_tau, dim3(1, n), dim3(256), 0, tau_stream_, g, src, d_pyr_, force_tau, tau, tau_first,
-                           d_redo_, d_redo_ + 1, l, d_qstat_, 0);
+                           d_redo_, d_redo_ + 1, l, d_qstat_, 0, 0);
       }
     }
     if (evs) hipEventRecord(evs[1], st);
@@ -2404,7 +2443,7 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
         hipStreamWaitEvent(st, tau_ev_[kOrbLevels], 0);
       } else {
         hipLaunchKernelGGL(k_fast_tau, dim3(g.nlevels, n), dim3(256), 0, st, g, src, d_pyr_, force_tau, tau, tau_first, d_redo_,
-                           d_redo_ + 1, 0, d_qstat_, 0);
+                           d_redo_ + 1, 0, d_qstat_, 0, 0);
       }
       if (dense) {   // MSF_FLAG_FAST_DENSE / a call of a few frames: the plain detector over every tile, nothing to verify
         hipLaunchKernelGGL(k_fast, dim3((unsigned)g.total_tiles * (unsigned)n), dim3(kFastThreads), 0, st, g, src, d_pyr_,

@@ -97,6 +97,7 @@ class OrbPipeline {
   uint32_t* d_qstat_ = nullptr;           // [slots][levels][kTauBins + 2]: score histogram of the sampled quarter's corners,
                                           // its strips done (in-launch threshold refinement, see k_walk)
   bool fast_two_part_ = true;             // MSF_ORB_FAST_ONE_PART=1 clears it: no refinement of the sampler's threshold
+  int tau_predict_pct_ = 300;             // MSF_ORB_TAU_PREDICT (0 = sample every level)
   int tau_sites_ = 1024;                  // sample sites of k_fast_tau per (frame, level) (MSF_ORB_TAU_SITES)
   int wk_rows_target_ = 80;               // owned rows per walker strip (MSF_ORB_WALK_ROWS)
   long long walk_round_ = 4096;           // strips the chip runs at once (16 waves x 256 CUs): see launch_walk

@@ -464,13 +464,34 @@ def test_refined_fast_threshold_equals_unrefined_and_survives_an_overshooting_es
     tau_one = np.stack([one.fast_tau(s) for s in range(2 * n)])
     assert sum(len(m) for m in ref) > 50 * n
     monkeypatch.delenv("MSF_ORB_FAST_ONE_PART")
+    # refinement alone (every level's first estimate from the sampler, as in the unrefined run): thresholds only rise
+    monkeypatch.setenv("MSF_ORB_TAU_PREDICT", "0")
+    samp = FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=fl)
+    got = samp.match_batch(list(A), list(B), cap=1024)
+    tau_s = np.stack([samp.fast_tau(s) for s in range(2 * n)])
+    for r, g in zip(ref, got):
+        np.testing.assert_array_equal(r, g)
+    assert (tau_s[:, :, 0] >= tau_one[:, :, 0]).all() and (tau_s[:, :3, 0] > tau_one[:, :3, 0]).mean() > 0.5
+    assert (tau_s[:, :, 0] == tau_s[:, :, 1]).all()                        # nothing redone at the default margin
+    samp.close()
+    monkeypatch.delenv("MSF_ORB_TAU_PREDICT")
+    # the default: the first estimate of levels >= 1 predicted from the level above, then refined
     two = FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=fl)
     got = two.match_batch(list(A), list(B), cap=1024)
     tau_two = np.stack([two.fast_tau(s) for s in range(2 * n)])
     for r, g in zip(ref, got):
         np.testing.assert_array_equal(r, g)
-    assert (tau_two[:, :, 0] >= tau_one[:, :, 0]).all() and (tau_two[:, :3, 0] > tau_one[:, :3, 0]).mean() > 0.5
-    assert (tau_two[:, :, 0] == tau_two[:, :, 1]).all()                    # nothing redone at the default margin
+    assert (tau_two[:, :3, 0] > tau_one[:, :3, 0]).mean() > 0.5
+    assert (tau_two[:, :, 0] == tau_two[:, :, 1]).all()                    # nothing redone
+    # an absurd prediction margin (5 % of the needed density: thresholds far too high) only costs dense passes
+    monkeypatch.setenv("MSF_ORB_TAU_PREDICT", "5")
+    wildp = FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=fl)
+    got_p = wildp.match_batch(list(A), list(B), cap=1024)
+    assert (np.stack([wildp.fast_tau(s) for s in range(2 * n)])[:, 1:, 0] == 20).sum() > n
+    for r, g in zip(ref, got_p):
+        np.testing.assert_array_equal(r, g)
+    wildp.close()
+    monkeypatch.delenv("MSF_ORB_TAU_PREDICT")
     orc = oracle_orb.FeatureMatcherOracle(0.7)
     np.testing.assert_array_equal(got[0], orc.MatchFrames(A[0], B[0]))
     for l in range(1, 8):                                                  # the walker's pyramid is k_resize's

@@ -14,11 +14,11 @@ from oracle import orb as oracle_orb                           # noqa: E402
 
 
 def sweep(w, h, n, mode, first, ratio=0.6, threads=16):
-    fm = FeatureMatcher(ratio, w, h, max_batch_pairs=64)
+    fm = FeatureMatcher(ratio, w, h, max_batch_pairs=128)   # 256 frames per call: the fused walker in two chains
     bad = 0
     tot = 0
-    for p0 in range(0, n, 64):
-        m = min(64, n - p0)
+    for p0 in range(0, n, 128):
+        m = min(128, n - p0)
         A, B = synth.synth_batch(first + p0, m, w, h, mode=mode)
         got = fm.match_batch(list(A), list(B), cap=4096)
 
