@@ -500,7 +500,8 @@ constexpr int RK = 16;                   // ring rows (power of two)
 constexpr int kWkMaxPx = 244;            // strip pitch <= 244: a group of 4 output px reads two aligned 8-byte pairs <= 8 B apart
 constexpr int kWkMaxRows = 112;          // owned rows per strip at most (a strip's emit table lives in two registers per lane);
                                          // 80 measured best at 720p (48 / 64 / 80 / 96 / 112 rows: 8.19 / 7.97 / 7.83 / 7.88 / 7.96 ms per step)
-constexpr int kSGCap = 288, kSPCap = 256, kSHCap = 64, kSOCap = 48;   // 10 224 B of LDS per wave: 16 waves per CU
+constexpr int kSGCap = 288, kSPCap = 256, kSHCap = 64, kSOCap = 32;   // 10 240 B of LDS per wave: exactly 16 waves per CU
+constexpr int kRespCap = 8192;           // per (slot, level): Harris responses of the walker's first kRespCap candidates
 constexpr uint32_t kSGFlush = 32;        // records that trigger a flush at the end of a four-step group (<= 4 x 64 more arrive)
 static_assert(kSGCap >= (int)kSGFlush + 256, "record list capacity");
 // x = sum b_i 2^(8i) with 2-bit b_i: (x * kFlagGather) >> 24 = b0 | b1 << 2 | b2 << 4 | b3 << 6.  The cross terms below
@@ -519,9 +520,10 @@ struct StreamSmem {
   uint32_t g[kSGCap];        // lane | rel row << 6 | (brighter, darker) flag pairs of the 4 px << 16
   uint16_t p[kSPCap];        // pixel entries: byte in row | ring row << 8 | darker-type << 12
   uint16_t h[kSHCap];        // scored corners: byte in row | ring row << 8 (the rel row follows from the ring row)
-  uint32_t okey[kSOCap];
-  uint8_t osc[kSOCap];
+  uint32_t opk[kSOCap];      // kept corners waiting for the next flush to global memory: byte in row | rel row << 8 | score << 16
+  float oresp[kSOCap];       // ... and their Harris responses
 };
+static_assert(sizeof(StreamSmem) == 10240, "16 waves per CU need 10 240 B per wave");
 
 // cornerScore<16> of the pixel at byte x of ring row r0 (rows wrap modulo RK), both polarities in one routine:
 // darker-type = brighter-type on 255 - p.  Returns score (>= tau) or 0.
@@ -555,8 +557,8 @@ __device__ __forceinline__ int stream_score(const uint8_t* ring, uint32_t r0, ui
 template <bool RESIZE>
 __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_t* pyr, const uint32_t* __restrict__ tab,
                                              uint32_t* tau, uint32_t* qstat, uint32_t* cand_cnt, uint32_t* cand_key,
-                                             uint8_t* cand_sc, int l_lo, int l_hi, int n_frames, int margin_pct, int dyn,
-                                             int part) {
+                                             uint8_t* cand_sc, float* cand_resp, int l_lo, int l_hi, int n_frames,
+                                             int margin_pct, int dyn, int part, int harris) {
   __shared__ StreamSmem sm;
   const int lane = threadIdx.x;
   int fi, t;
@@ -675,6 +677,7 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
   uint32_t* const out_cnt = cand_cnt + idx;
   uint32_t* const outk = cand_key + (long long)slot * g.cand_total + L.cand_off;
   uint8_t* const outs = cand_sc + (long long)slot * g.cand_total + L.cand_off;
+  float* const outr = cand_resp + ((long long)slot * kOrbLevels + l) * kRespCap;
   const uint32_t out_cap = (uint32_t)L.cand_cap;
   uint32_t* pxw = reinterpret_cast<uint32_t*>(sm.px);
   uint32_t* scw = reinterpret_cast<uint32_t*>(sm.sc);
@@ -754,24 +757,59 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
 
   auto flush_out = [&]() {
     if (nO == 0) return;
+    MSF_WAVE_SYNC();                       // the responses lane 0 wrote are read by every lane below
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(out_cnt, nO);
     base = __builtin_amdgcn_readfirstlane(base);
     for (uint32_t i = lane; i < nO; i += 64) {
+      const uint32_t pk = sm.opk[i], sc_ = pk >> 16;
       if (base + i < out_cap) {
-        outk[base + i] = sm.okey[i];
-        outs[base + i] = sm.osc[i];
+        outk[base + i] = ((uint32_t)(y0 + (int)((pk >> 8) & 255u)) << 16) | (uint32_t)(xs + (int)(pk & 255u));
+        outs[base + i] = (uint8_t)sc_;
       }
-      if (count_me) atomicAdd(&qs[sm.osc[i] >> 2], 1u);     // the quarter's exact scores: what the other strips refine tau from
+      if (harris && base + i < (uint32_t)kRespCap) outr[base + i] = sm.oresp[i];
+      if (count_me) atomicAdd(&qs[sc_ >> 2], 1u);     // the quarter's exact scores: what the other strips refine tau from
     }
     MSF_WAVE_SYNC();
     nO = 0;
   };
 
+  // HarrisResponses (orb.cpp; blockSize 7) of buffered corner e, by the whole wave while the corner's 9 x 9 pixels are in
+  // the ring (a corner is kept in the flush that follows its row by at most 8 rows: rows rr - 4 .. rr + 4 are still there,
+  // and an owned column has 4 px of window either side).  Lane t < 49 takes block position (t / 7 - 3, t % 7 - 3): its
+  // Sobel pair from 8 ring bytes, Ix^2, Iy^2, Ix Iy, three wave sums (exact integers, any order), then the reference's
+  // f32 expression on one lane -- bit for bit harris_at's result (the stage-1 parity tests compare the bits).
+  // OPT-IN (MSF_ORB_WALKER_HARRIS=1): it removes k_thr_harris' 9-row patch fetches (HBM traffic of the step 22.3 -> 20.4 GB,
+  // select_harris 0.56 -> 0.17 ms) but costs the walker 0.70 ms -- a strip emits ~15 corners, each ~80 dependent
+  // instructions on a latency-bound wave, and half of them never survive retainBest(2N): 7.52 -> 7.89 ms per step.
+  auto harris_entry = [&](uint32_t e) {
+    const uint32_t pk = sm.opk[e];
+    const int t = lane < 49 ? lane : 48;
+    const int ty = (t * 37) >> 8;                                   // t / 7 for t < 49
+    const int xc = (int)(pk & 255u) + (t - 7 * ty) - 3, rc = (int)((pk >> 8) & 255u) + ty;   // ring index of the row = rel row + 3
+    const uint8_t* r0 = pxb + (((rc - 1) & (RK - 1)) << 8) + xc;
+    const uint8_t* r1 = pxb + ((rc & (RK - 1)) << 8) + xc;
+    const uint8_t* r2 = pxb + (((rc + 1) & (RK - 1)) << 8) + xc;
+    const int p00 = r0[-1], p01 = r0[0], p02 = r0[1], p10 = r1[-1], p12 = r1[1], p20 = r2[-1], p21 = r2[0], p22 = r2[1];
+    int ix = 2 * (p12 - p10) + (p02 - p00) + (p22 - p20);
+    int iy = 2 * (p21 - p01) + (p20 - p00) + (p22 - p02);
+    if (lane >= 49) ix = iy = 0;
+    const uint32_t a = __builtin_amdgcn_readlane(wave_incl_scan((uint32_t)(ix * ix)), 63);
+    const uint32_t b = __builtin_amdgcn_readlane(wave_incl_scan((uint32_t)(iy * iy)), 63);
+    const int c = (int)__builtin_amdgcn_readlane(wave_incl_scan((uint32_t)(ix * iy)), 63);
+    if (lane == 0) {
+      const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+      const float scale_sq_sq = scale * scale * scale * scale;
+      const float fa = (float)(int)a, fb = (float)(int)b, fc = (float)c;
+      sm.oresp[e] = (fa * fb - fc * fc - 0.04f * (fa + fb) * (fa + fb)) * scale_sq_sq;
+    }
+  };
+
   // append (keep ? one output : nothing) of every lane, in lane order; the two half-waves one after the other, so
-  // that a call adds at most 32 entries and the buffer (kSOCap >= 32) can always take them after a flush
+  // that a call adds at most 32 entries and the buffer (kSOCap >= 32) can always take them after a flush.
+  // xl = byte of the corner inside the ring row, rr = its rel row.
   static_assert(kSOCap >= 32, "output buffer smaller than one half-wave");
-  auto emit = [&](bool keep, uint32_t key, uint32_t score) {
+  auto emit = [&](bool keep, uint32_t xl, uint32_t rr, uint32_t score) {
     if (__ballot(keep) == 0ull) return;
 #pragma unroll
     for (int half = 0; half < 2; half++) {
@@ -780,11 +818,10 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
       if (bal == 0ull) continue;
       const uint32_t cnt = (uint32_t)__popcll(bal);
       if (nO + cnt > (uint32_t)kSOCap) flush_out();
-      if (kh) {
-        const uint32_t k = nO + mbcnt64(bal);
-        sm.okey[k] = key;
-        sm.osc[k] = (uint8_t)score;
-      }
+      if (kh) sm.opk[nO + mbcnt64(bal)] = xl | (rr << 8) | (score << 16);
+      MSF_WAVE_SYNC();
+      if (harris)
+        for (uint32_t e = nO; e < nO + cnt; e++) harris_entry(e);
       nO += cnt;
     }
   };
@@ -847,7 +884,7 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
       for (uint32_t i0 = 0; i0 < nH; i0 += 64) {
         const uint32_t i = i0 + lane;
         bool keep = false;
-        uint32_t key = 0, c = 0;
+        uint32_t key = 0, krr = 0, c = 0;
         if (i < nH) {
           const uint32_t he = sm.h[i];
           const uint32_t xl = he & 255u, row = (he >> 8) & 15u;                 // byte inside the row = 4 * lane + j
@@ -857,13 +894,14 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
           const uint8_t* qu = scb + (((row + RK - 1) & (RK - 1)) << 8) + xl;
           const uint8_t* qd = scb + (((row + 1) & (RK - 1)) << 8) + xl;
           c = qc[0];
-          const int x = xs + (int)xl, y = y0 + rr;
+          const int x = xs + (int)xl;
           keep = rr >= nms_lo && rr <= hi && rr >= o_lo && rr < o_hi && x >= ox_lo && x < ox_hi;
           keep = keep && c > qc[-1] && c > qc[1] && c > qu[-1] && c > qu[0] && c > qu[1] && c > qd[-1] && c > qd[0] &&
                  c > qd[1];
-          key = ((uint32_t)y << 16) | (uint32_t)x;
+          key = xl;
+          krr = (uint32_t)rr;
         }
-        emit(keep, key, c);
+        emit(keep, key, krr, c);
       }
     } else {
       for (int rr = nms_lo; rr <= hi; rr++) {
@@ -887,9 +925,8 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
 #undef SHR1
 #undef SHL1
         keep &= om;
-        const uint32_t ykey = (uint32_t)(y0 + rr) << 16;
 #pragma unroll
-        for (int j = 0; j < 4; j++) emit((keep >> (8 * j + 7)) & 1u, ykey | (uint32_t)(xb + j), (C >> (8 * j)) & 255u);
+        for (int j = 0; j < 4; j++) emit((keep >> (8 * j + 7)) & 1u, (uint32_t)(4 * lane + j), (uint32_t)rr, (C >> (8 * j)) & 255u);
       }
     }
     // the list restarts with the scored corners of row s (their NMS needs row s + 1)
@@ -1338,7 +1375,8 @@ __device__ __forceinline__ float harris_at(const uint8_t* img, int step, int x0,
 __global__ __launch_bounds__(256) void k_thr_harris(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
                                                     const uint32_t* cand_cnt, const uint32_t* cand_key,
                                                     const uint8_t* cand_sc,
-                                                    uint32_t* s1_cnt, uint4* s1, uint32_t* status) {
+                                                    uint32_t* s1_cnt, uint4* s1, uint32_t* status,
+                                                    const uint32_t* __restrict__ tau, const float* __restrict__ cand_resp) {
   __shared__ uint32_t hist[256];
   __shared__ uint32_t thr_s, lcount;
   // Launched with 256 threads when the candidate lists are the dense ones (tens of thousands per level) and with one
@@ -1355,6 +1393,11 @@ __global__ __launch_bounds__(256) void k_thr_harris(OrbGeometry g, FrameSrc src,
   }
   const uint32_t* keys = cand_key + (long long)slot * g.cand_total + L.cand_off;
   const uint8_t* scs = cand_sc + (long long)slot * g.cand_total + L.cand_off;   // 16-byte aligned (cand_off % 16 == 0)
+  // A list the streaming walker made (threshold above fastThreshold, not redone densely) carries the Harris response of
+  // every candidate: the walker computed it while the pixels were in its ring (k_walk, harris_entry).  Lists of the dense
+  // tile kernel (and a walker list longer than kRespCap) get theirs here, from the pyramid.
+  const bool have_resp = tau != nullptr && tau[slot * kOrbLevels + l] > (uint32_t)kFastT && n <= (uint32_t)kRespCap;
+  const float* resp = cand_resp + ((long long)slot * kOrbLevels + l) * kRespCap;
   uint4* out = s1 + (long long)slot * g.s1_total + L.s1_off;
   for (uint32_t b = tid; b < 256u; b += nt) hist[b] = 0;
   if (tid == 0) lcount = 0;
@@ -1413,13 +1456,14 @@ __global__ __launch_bounds__(256) void k_thr_harris(OrbGeometry g, FrameSrc src,
     while (mask) {
       const int b = __ffs(mask) - 1;
       mask &= mask - 1;
-      if (k < (uint32_t)kS1Cap) out[k] = make_uint4(keys[i + b], 0u, (w[b >> 2] >> (8 * (b & 3))) & 255u, 0u);
+      if (k < (uint32_t)kS1Cap)
+        out[k] = make_uint4(keys[i + b], have_resp ? __float_as_uint(resp[i + b]) : 0u, (w[b >> 2] >> (8 * (b & 3))) & 255u, 0u);
       k++;
     }
   }
   __syncthreads();
-  // pass 2: Harris response on dense lanes
-  const uint32_t kept = min(lcount, (uint32_t)kS1Cap);
+  // pass 2: Harris response on dense lanes (lists without stored responses)
+  const uint32_t kept = have_resp ? 0u : min(lcount, (uint32_t)kS1Cap);
   for (uint32_t i = tid; i < kept; i += nt) {
     const uint32_t key = out[i].x;
     const float r = harris_at(img, pitch, key & 0xFFFF, key >> 16);
@@ -1949,7 +1993,7 @@ OrbPipeline::~OrbPipeline() { destroy(); }
 
 void OrbPipeline::destroy() {
   hipFree(d_tau_); hipFree(d_redo_); hipFree(d_qstat_); d_tau_ = nullptr; d_redo_ = nullptr; d_qstat_ = nullptr;
-  hipFree(d_pyr_); hipFree(d_tab_); hipFree(d_cand_cnt_); hipFree(d_cand_); hipFree(d_cand_sc_); hipFree(d_qres_); hipFree(d_done_); hipFree(d_s1_cnt_); hipFree(d_s1_);
+  hipFree(d_pyr_); hipFree(d_tab_); hipFree(d_cand_cnt_); hipFree(d_cand_); hipFree(d_cand_sc_); hipFree(d_cand_resp_); d_cand_resp_ = nullptr; hipFree(d_qres_); hipFree(d_done_); hipFree(d_s1_cnt_); hipFree(d_s1_);
   hipFree(d_kp_); hipFree(d_desc_); hipFree(d_kp_cnt_); hipFree(d_status_);
   d_pyr_ = nullptr; d_tab_ = nullptr; d_cand_cnt_ = nullptr; d_cand_ = nullptr; d_cand_sc_ = nullptr; d_qres_ = nullptr; d_done_ = nullptr; d_s1_cnt_ = nullptr;
   d_s1_ = nullptr; d_kp_ = nullptr; d_desc_ = nullptr; d_kp_cnt_ = nullptr; d_status_ = nullptr;
@@ -2012,6 +2056,9 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   // MSF_ORB_WALK_ROUND: a walker launch whose sampled quarter has fewer strips than this runs as two launches (tests: 0
   // = always one launch, refinement depending on dispatch timing; a huge value = always two)
   if (const char* e = getenv("MSF_ORB_WALK_ROUND")) walk_round_ = atoll(e);
+  // MSF_ORB_WALKER_HARRIS=1: the walker computes the Harris response of every corner it emits from its pixel ring and
+  // k_thr_harris only ranks (default 0: k_thr_harris computes the responses of the kept candidates from the pyramid)
+  if (const char* e = getenv("MSF_ORB_WALKER_HARRIS")) walker_harris_ = atoi(e);
   // MSF_ORB_TAU_PREDICT: percent of the needed corner density the prediction of a level's first threshold from the level
   // above keeps (0 = sample every level, the r02 behaviour)
   if (const char* e = getenv("MSF_ORB_TAU_PREDICT")) {
@@ -2213,6 +2260,7 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   MSF_HIP_TRY(hipMemset(d_qstat_, 0, S * kOrbLevels * kQStat * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMalloc(&d_cand_, S * g.cand_total * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMalloc(&d_cand_sc_, S * g.cand_total));
+  MSF_HIP_TRY(hipMalloc(&d_cand_resp_, S * kOrbLevels * kRespCap * sizeof(float)));
   MSF_HIP_TRY(hipMalloc(&d_s1_cnt_, S * kOrbLevels * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMalloc(&d_s1_, S * g.s1_total * sizeof(uint4)));
   MSF_HIP_TRY(hipMalloc(&d_kp_, S * kKpCap * sizeof(msf_keypoint)));
@@ -2363,10 +2411,10 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
       const unsigned units = part < 0 ? (unsigned)S : part == 0 ? (unsigned)Sq : (unsigned)Sr;
       if (resize)
         hipLaunchKernelGGL(k_walk<true>, dim3(f8 * units), dim3(64), 0, s_, g, fs, d_pyr_, d_tab_, tau, d_qstat_, d_cand_cnt_,
-                           d_cand_, d_cand_sc_, l_lo, l_hi, nf, tau2_margin_pct_, dyn, part);
+                           d_cand_, d_cand_sc_, d_cand_resp_, l_lo, l_hi, nf, tau2_margin_pct_, dyn, part, walker_harris_);
       else
         hipLaunchKernelGGL(k_walk<false>, dim3(f8 * units), dim3(64), 0, s_, g, fs, d_pyr_, d_tab_, tau, d_qstat_, d_cand_cnt_,
-                           d_cand_, d_cand_sc_, l_lo, l_hi, nf, tau2_margin_pct_, dyn, part);
+                           d_cand_, d_cand_sc_, d_cand_resp_, l_lo, l_hi, nf, tau2_margin_pct_, dyn, part, walker_harris_);
     }
   };
   // frames [f0, f0 + cnt) of src as a source of their own
@@ -2465,7 +2513,8 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
   }
   if (evs) hipEventRecord(evs[2], st);
   hipLaunchKernelGGL(k_thr_harris, dim3(g.nlevels, n), dim3(dense ? 256 : 64), 0, st, g, src, d_pyr_,
-                     d_cand_cnt_, d_cand_, d_cand_sc_, d_s1_cnt_, d_s1_, d_status_);
+                     d_cand_cnt_, d_cand_, d_cand_sc_, d_s1_cnt_, d_s1_, d_status_,
+                     (const uint32_t*)(dense || walker_harris_ == 0 ? nullptr : d_tau_), (const float*)d_cand_resp_);
   hipLaunchKernelGGL(k_select, dim3(n), dim3(256), 0, st, g, src.slot0, d_s1_cnt_, d_s1_, d_kp_, d_kp_cnt_,
                      d_status_);
   if (evs) hipEventRecord(evs[3], st);

@@ -109,6 +109,8 @@ class OrbPipeline {
   uint32_t* d_redo_ = nullptr;     // [1 + slots * 8] dense-pass queue: count, entries (frame * 8 + level)
   uint32_t* d_cand_ = nullptr;     // [slots][cand_total] key = y << 16 | x
   uint8_t* d_cand_sc_ = nullptr;   // [slots][cand_total] FAST score
+  float* d_cand_resp_ = nullptr;   // [slots][levels][kRespCap] Harris response of the walker's candidates
+  int walker_harris_ = 0;          // MSF_ORB_WALKER_HARRIS (opt-in: less HBM traffic, more walker time)
   uint32_t* d_s1_cnt_ = nullptr;   // [slots][8]
   uint4* d_s1_ = nullptr;          // [slots][s1_total] (key, response bits, score, 0)
   msf_keypoint* d_kp_ = nullptr;   // [slots][kKpCap]

@@ -504,7 +504,9 @@ def test_refined_fast_threshold_equals_unrefined_and_survives_an_overshooting_es
     for r, g in zip(ref, got2):
         np.testing.assert_array_equal(r, g)
     monkeypatch.delenv("MSF_ORB_TAU2_MARGIN_PCT")
-    for env in ({"MSF_ORB_WALK_ROUND": "0"}, {"MSF_ORB_UNFUSED": "1"}, {"MSF_ORB_UNFUSED": "1", "MSF_ORB_WALK_ROUND": "0"}):
+    # ... and with the Harris responses computed by the walker from its pixel ring (opt-in) instead of by k_thr_harris
+    for env in ({"MSF_ORB_WALK_ROUND": "0"}, {"MSF_ORB_UNFUSED": "1"}, {"MSF_ORB_UNFUSED": "1", "MSF_ORB_WALK_ROUND": "0"},
+                {"MSF_ORB_WALKER_HARRIS": "1"}, {"MSF_ORB_WALKER_HARRIS": "1", "MSF_ORB_UNFUSED": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         alt = FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=fl)
@@ -513,6 +515,11 @@ def test_refined_fast_threshold_equals_unrefined_and_survives_an_overshooting_es
             np.testing.assert_array_equal(r, g, err_msg=str(env))
         for l in range(1, 8):
             np.testing.assert_array_equal(alt.level_pixels(1, l), one.level_pixels(1, l), err_msg="%s pyramid L%d" % (env, l))
+        for s_ in (0, 5, 2 * n - 1):                                       # key points with their Harris response bits
+            np.testing.assert_array_equal(alt.keypoints(s_), one.keypoints(s_), err_msg=str(env))
+            for l in (0, 3, 7):
+                a_, b_ = alt.stage1(s_, l), one.stage1(s_, l)
+                np.testing.assert_array_equal(np.sort(a_, order=["ly", "lx"]), np.sort(b_, order=["ly", "lx"]), err_msg="%s stage 1 L%d" % (env, l))
         alt.close()
         for k in env:
             monkeypatch.delenv(k)
