@@ -49,8 +49,25 @@ def build_lib(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, defines=()):
+    """Developer A/B builds: the same sources with extra -D flags into _variants/libmsf_<name>.so (git-ignored, travels
+    with the gpurun snapshot); selected at run time with MSF_LIB_PATH."""
+    out_dir = os.path.join(_HERE, "_variants")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "libmsf_%s.so" % name)
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    cmd = [HIPCC] + HIP_FLAGS + ["-D" + d for d in defines] + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", out] + srcs + ["-ldl"]
+    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+    return out
+
+
 def lib_path():
     """Path of the library; rebuilds when sources are newer and hipcc exists, else fails loudly."""
+    override = os.environ.get("MSF_LIB_PATH")      # developer A/B builds (build_variant); never set in production
+    if override:
+        if not os.path.exists(override):
+            raise RuntimeError("MSF_LIB_PATH=%s does not exist" % override)
+        return override
     if os.path.exists(LIB) and not _stale(LIB, _deps()):
         return LIB
     if os.path.exists(HIPCC):

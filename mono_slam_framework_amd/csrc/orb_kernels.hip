@@ -8,6 +8,7 @@
 // Integer/byte work, HBM- and VALU-bound: no MFMA here.  This TU is compiled with
 // -ffp-contract=off so the few f32 steps (Harris response, fastAtan2, pattern rotation)
 // round exactly as the CPU restatement does.
+#include <type_traits>
 #include "orb_pipeline.h"
 
 #include <math.h>
@@ -35,6 +36,18 @@ constexpr int kDiscTasks = 256;
 __constant__ uint32_t c_disc[2 * kDiscTasks];
 
 // ------------------------------------------------------------------ helpers
+// a pointer / integer the caller knows to be the same in every lane, pinned to scalar registers.  A buffer descriptor
+// built from such values gives loads and stores of the form buffer_load v, v_off, s[desc], s_off: the row offset is SALU
+// work and no vector instruction is spent on addresses (the walker's VALU pipe is its bound); accesses past `bytes` are
+// dropped by the hardware range check.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, uint32_t bytes) {
+  const unsigned long long v = (unsigned long long)p;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0,
+                                           (int)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ const uint8_t* level_ptr(const OrbGeometry& g, const FrameSrc& src,
                                                     const uint8_t* pyr, int fi, int l, int* pitch) {
   if (l == 0) {
@@ -56,6 +69,13 @@ __device__ __forceinline__ uint32_t udot2_u16(uint32_t a, uint32_t b, uint32_t c
 __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c) {
   uint32_t r;
   asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// the same with a wave-uniform multiplier taken from a scalar register (no v_mov to get it into a vector register)
+__device__ __forceinline__ uint32_t mad_u24_s(uint32_t a, uint32_t b_uniform, uint32_t c) {
+  uint32_t r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
   return r;
 }
 
@@ -497,6 +517,9 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
 constexpr int kTauBins = 64;             // score histogram bins of width 4 (k_fast_tau's sample, the emitted corners)
 constexpr int kQStat = kTauBins + 2;     // per (slot, level): the quarter's histogram, its strips done, spare
 constexpr int RK = 16;                   // ring rows (power of two)
+#ifndef MSF_WALK_PREFETCH8
+#define MSF_WALK_PREFETCH8 1
+#endif
 constexpr int kWkMaxPx = 244;            // strip pitch <= 244: a group of 4 output px reads two aligned 8-byte pairs <= 8 B apart
 constexpr int kWkMaxRows = 112;          // owned rows per strip at most (a strip's emit table lives in two registers per lane);
                                          // 80 measured best at 720p (48 / 64 / 80 / 96 / 112 rows: 8.19 / 7.97 / 7.83 / 7.88 / 7.96 ms per step)
@@ -504,9 +527,6 @@ constexpr int kSGCap = 288, kSPCap = 256, kSHCap = 64, kSOCap = 32;   // 10 240 
 constexpr int kRespCap = 8192;           // per (slot, level): Harris responses of the walker's first kRespCap candidates
 constexpr uint32_t kSGFlush = 32;        // records that trigger a flush at the end of a four-step group (<= 4 x 64 more arrive)
 static_assert(kSGCap >= (int)kSGFlush + 256, "record list capacity");
-// x = sum b_i 2^(8i) with 2-bit b_i: (x * kFlagGather) >> 24 = b0 | b1 << 2 | b2 << 4 | b3 << 6.  The cross terms below
-// bit 24 sum to at most 3 * (2^18 + 2^12 + 2^6 + 2^20 + 2^14 + 2^22) < 2^24, so nothing carries into the result.
-constexpr uint32_t kFlagGather = (1u << 24) | (1u << 18) | (1u << 12) | (1u << 6);
 // A row put at step s overwrites rel row s - 13; pending records read pixel rows >= last_flush - 2 and pending NMS
 // score rows >= last_flush - 1: the flush interval (a multiple of the four-step group) must stay below 11 rows.
 constexpr int kFlushRows = 8;
@@ -517,7 +537,8 @@ constexpr int kTau2MarginPctMany = 150, kTau2ManyStrips = 8;
 struct StreamSmem {
   __attribute__((aligned(16))) uint8_t px[RK * 256];
   __attribute__((aligned(16))) uint8_t sc[RK * 256];
-  uint32_t g[kSGCap];        // lane | rel row << 6 | (brighter, darker) flag pairs of the 4 px << 16
+  uint32_t g[kSGCap];        // per byte j: bit 7 = px j passed the brighter-type prefilter, bit 6 = the darker-type one; in
+                             // the low six bits of bytes 0 / 1 / 2: lane, rel row & 63, rel row >> 6
   uint16_t p[kSPCap];        // pixel entries: byte in row | ring row << 8 | darker-type << 12
   uint16_t h[kSHCap];        // scored corners: byte in row | ring row << 8 (the rel row follows from the ring row)
   uint32_t opk[kSOCap];      // kept corners waiting for the next flush to global memory: byte in row | rel row << 8 | score << 16
@@ -616,14 +637,23 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
   const int need_lo = RESIZE ? xs : max(ox0 - 4, xs);
   const int need_hi = sx == L.wk_nx - 1 ? pitch : (RESIZE ? xs + L.wk_px + 16 : ox1 + 4);     // exclusive, multiples of 4
   const int xl = min(max(xb, need_lo & ~3), ((need_hi + 3) & ~3) - 4);
-  const uint8_t* gp = img + (xl + 4 <= pitch ? xl : pitch - 4);
+  // wave-uniform row base (scalar registers) + the lane's 32-bit byte offset: the load takes its address as
+  // s[base] + v_off, no vector arithmetic per row
+  const uint32_t xoff = (uint32_t)(xl + 4 <= pitch ? xl : pitch - 4);
   const int ylim = L.h - 1;
-#define LOAD_ROW(y_) (*reinterpret_cast<const uint32_t*>(gp + (long long)max(min((y_), ylim), 0) * pitch))
+  const uint32_t pitch_u = uniform_u32((uint32_t)pitch);       // a level is far below 4 GB: 32-bit row offsets
+  const __amdgpu_buffer_rsrc_t img_rs = uniform_rsrc(img, (uint32_t)L.h * (uint32_t)pitch);
+#define LOAD_ROW(y_) ((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(img_rs, xoff, (uint32_t)max(min((y_), ylim), 0) * pitch_u, 0))
   // the first ten pixel rows are requested before anything else: the state of the (frame, level) below is one more
   // memory latency, and the two overlap (they were serial: +10 us on a 40-us strip)
   uint32_t w0_ = LOAD_ROW(y0 - 3), w1_ = LOAD_ROW(y0 - 2), w2_ = LOAD_ROW(y0 - 1), w3_ = LOAD_ROW(y0), w4_ = LOAD_ROW(y0 + 1),
            w5_ = LOAD_ROW(y0 + 2);
   uint32_t q0 = LOAD_ROW(y0 + 3), q1 = LOAD_ROW(y0 + 4), q2 = LOAD_ROW(y0 + 5), q3 = LOAD_ROW(y0 + 6);
+#if MSF_WALK_PREFETCH8
+  // second queue: the rows of the group after (a group consumes and refills ONE of the two queues, so a load is requested
+  // two groups = eight rows before its use: one group's time is about the loaded memory latency)
+  uint32_t p0 = LOAD_ROW(y0 + 7), p1 = LOAD_ROW(y0 + 8), p2 = LOAD_ROW(y0 + 9), p3 = LOAD_ROW(y0 + 10);
+#endif
 
   // ---- threshold: the sampler's, raised from the quarter's exact corners when they are all in.  The whole state of the
   // (frame, level) -- 64 bins, strips done, threshold in force -- comes in with two independent loads (one latency).
@@ -686,9 +716,10 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
 
   // ---- resize state: this lane's group of 4 output columns of level l + 1
   uint32_t rsel[4] = {0, 0, 0, 0}, rwxp[4] = {0, 0, 0, 0}, roff0 = 0, roff3 = 0, em_lo = 0, em_hi = 0;
-  uint8_t* dcol = nullptr;
+  __amdgpu_buffer_rsrc_t dst_rs = img_rs;         // level l + 1 of this frame (set below)
+  uint32_t dxoff = 0;                             // the lane's byte offset inside an output row
   bool rz_lane = false;
-  int dpitch = 0;
+  uint32_t dpitch = 0;
   if (RESIZE) {
     const OrbLevelInfo Ld = g.lv[l + 1];
     const int groups = (Ld.w + 3) >> 2;
@@ -706,8 +737,9 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
     // pair offsets relative to the window (host-checked: 0 <= off <= 248 for the groups of this strip)
     roff0 = rz_lane ? qov.x - (uint32_t)xs : 0u;
     roff3 = rz_lane ? qov.w - (uint32_t)xs : 0u;
-    dpitch = Ld.pitch;
-    dcol = pyr + (long long)slot * g.pyr_bytes + Ld.pix_off + 4 * gq;
+    dpitch = uniform_u32((uint32_t)Ld.pitch);
+    dst_rs = uniform_rsrc(pyr + (long long)slot * g.pyr_bytes + Ld.pix_off, (uint32_t)Ld.h * (uint32_t)Ld.pitch);
+    dxoff = 4u * (uint32_t)gq;
     // emit entries of the source rows R0 - 4 + j, j = lane (em_lo) and 64 + lane (em_hi): output row | w1 << 16 | 1 << 31
     // if an output row has source rows (y, y + 1) as its taps and y is owned by this strip
     const int ra = R0 - 4 + lane, rb = ra + 64;
@@ -745,13 +777,13 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
     /* one select + one v_readlane (a ternary of two readlanes compiles to branches) */                                 \
     const uint32_t em_ = (uint32_t)__builtin_amdgcn_readlane((int)(jj_ < 64 ? em_lo : em_hi), jj_ & 63);               \
     if ((int)em_ < 0) {                                                                                                \
-      const uint32_t wy1_ = (em_ >> 16) & 0x1FFu, wy0_ = 256u - wy1_;                                                  \
-      const uint32_t v0_ = mad_u24(hu_[0], wy0_, mad_u24(hl_[0], wy1_, 32768u));                                       \
-      const uint32_t v1_ = mad_u24(hu_[1], wy0_, mad_u24(hl_[1], wy1_, 32768u));                                       \
-      const uint32_t v2_ = mad_u24(hu_[2], wy0_, mad_u24(hl_[2], wy1_, 32768u));                                       \
-      const uint32_t v3_ = mad_u24(hu_[3], wy0_, mad_u24(hl_[3], wy1_, 32768u));                                       \
+      const uint32_t wy1_ = (em_ >> 16) & 0x1FFu, wy0_ = 256u - wy1_, rnd_ = 32768u;                                   \
+      const uint32_t v0_ = mad_u24_s(hu_[0], wy0_, mad_u24_s(hl_[0], wy1_, rnd_));                                     \
+      const uint32_t v1_ = mad_u24_s(hu_[1], wy0_, mad_u24_s(hl_[1], wy1_, rnd_));                                     \
+      const uint32_t v2_ = mad_u24_s(hu_[2], wy0_, mad_u24_s(hl_[2], wy1_, rnd_));                                     \
+      const uint32_t v3_ = mad_u24_s(hu_[3], wy0_, mad_u24_s(hl_[3], wy1_, rnd_));                                     \
       const uint32_t pk_ = __builtin_amdgcn_perm(v1_, v0_, 0x0c0c0602u) | __builtin_amdgcn_perm(v3_, v2_, 0x06020c0cu); \
-      if (rz_lane) *reinterpret_cast<uint32_t*>(dcol + (long long)(em_ & 0xFFFFu) * dpitch) = pk_;                     \
+      if (rz_lane) __builtin_amdgcn_raw_buffer_store_b32(pk_, dst_rs, dxoff, (em_ & 0xFFFFu) * dpitch, 0);              \
     }                                                                                                                  \
   } while (0)
 
@@ -836,11 +868,11 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
       uint32_t e0 = 0, mb = 0, md = 0;
       if (lane < 32 && c0 + lane < nG) {
         const uint32_t rec = sm.g[c0 + lane];
-        const uint32_t rr = (rec >> 6) & 127u, fl = rec >> 16;   // flags: bit 2j+1 = px j brighter-type, bit 2j = darker-type
+        // only the low four bits of the rel row matter here (ring row = (rel row + 3) mod 16)
         // pixel entry: byte in row (8 bits) | ring row (4 bits) << 8 | dark << 12
-        e0 = ((rec & 63u) << 2) | (((rr + 3u) & (uint32_t)(RK - 1)) << 8);
-        mb = ((fl & 2u) << 6) | ((fl & 8u) << 12) | ((fl & 32u) << 18) | ((fl & 128u) << 24);
-        md = ((fl & 1u) << 7) | ((fl & 4u) << 13) | ((fl & 16u) << 19) | ((fl & 64u) << 25);
+        e0 = ((rec & 63u) << 2) | ((rec + 0x300u) & 0xF00u);
+        mb = rec & 0x80808080u;
+        md = (rec << 1) & 0x80808080u;
       }
       const uint32_t mine = __popc(mb) + __popc(md);
       const uint32_t incl = wave_incl_scan(mine);
@@ -990,29 +1022,48 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
     const bool has_ = ((cb_) | (cd_)) != 0u;                                                                           \
     const unsigned long long bal_ = __ballot(has_);                                                                    \
     if (bal_) {                                                                                                        \
-      /* the 8 flag bits (bits 7 / 6 of each byte) gathered into one byte by a multiply (no carries: see kFlagGather) */ \
-      if (has_) sm.g[nG + mbcnt64(bal_)] = (uint32_t)lane | ((uint32_t)(s_) << 6) |                                    \
-                                           (((((((cb_) | ((cd_) >> 1)) >> 6) & 0x03030303u) * kFlagGather) >> 24) << 16); \
+      /* cb_ / cd_ hold bit 7 of each byte only: the flags stay where they are, lane and row go into the free low bits */ \
+      if (has_) sm.g[nG + mbcnt64(bal_)] = (cb_) | ((cd_) >> 1) | lane_rec | ((((uint32_t)(s_) & 63u) << 8) | (((uint32_t)(s_) >> 6) << 16)); \
       nG += (uint32_t)__popcll(bal_);                                                                                  \
     }                                                                                                                  \
   } while (0)
-  for (int s = 0; s <= r_last; s += 4) {
+  const uint32_t lane_rec = (uint32_t)lane;
+  static_assert(kWkMaxRows + 8 < 128, "a record holds 7 bits of rel row");
+  static_assert(RK == 16, "the group body below exists in four copies, one per position of the group in the 16-row ring");
+  // The ring slot of a row is (ring index) mod 16 and a group starts at a multiple of 4: the body is instantiated for the
+  // four values of (s mod 16), so that every slot is a compile-time constant and every LDS access of the group is
+  // lane base + immediate offset (18 vector instructions per group went into ring addresses).  P_ = s mod 16.
+  auto group = [&](auto ph_, const int s) {
+    constexpr int P_ = decltype(ph_)::value * 4;
+#if MSF_WALK_PREFETCH8
+    constexpr bool kOdd = (decltype(ph_)::value & 1) != 0;
+    uint32_t& r0 = kOdd ? p0 : q0;
+    uint32_t& r1 = kOdd ? p1 : q1;
+    uint32_t& r2 = kOdd ? p2 : q2;
+    uint32_t& r3 = kOdd ? p3 : q3;
+    const uint32_t d0 = r0, d1 = r1, d2 = r2, d3 = r3;
+    PUT_ROW(P_ + 6, d0); r0 = LOAD_ROW(y0 + s + 11);
+    PUT_ROW(P_ + 7, d1); r1 = LOAD_ROW(y0 + s + 12);
+    PUT_ROW(P_ + 8, d2); r2 = LOAD_ROW(y0 + s + 13);
+    PUT_ROW(P_ + 9, d3); r3 = LOAD_ROW(y0 + s + 14);
+#else
     const uint32_t d0 = q0, d1 = q1, d2 = q2, d3 = q3;
-    PUT_ROW(s + 6, d0); q0 = LOAD_ROW(y0 + s + 7);
-    PUT_ROW(s + 7, d1); q1 = LOAD_ROW(y0 + s + 8);
-    PUT_ROW(s + 8, d2); q2 = LOAD_ROW(y0 + s + 9);
-    PUT_ROW(s + 9, d3); q3 = LOAD_ROW(y0 + s + 10);
-    const uint32_t u0 = pxw[((s) & (RK - 1)) * 64 + lane], u1 = pxw[((s + 1) & (RK - 1)) * 64 + lane];
-    const uint32_t u2 = pxw[((s + 2) & (RK - 1)) * 64 + lane], u3 = pxw[((s + 3) & (RK - 1)) * 64 + lane];   // = c0
-    const uint32_t c1 = pxw[((s + 4) & (RK - 1)) * 64 + lane], c2 = pxw[((s + 5) & (RK - 1)) * 64 + lane];
+    PUT_ROW(P_ + 6, d0); q0 = LOAD_ROW(y0 + s + 7);
+    PUT_ROW(P_ + 7, d1); q1 = LOAD_ROW(y0 + s + 8);
+    PUT_ROW(P_ + 8, d2); q2 = LOAD_ROW(y0 + s + 9);
+    PUT_ROW(P_ + 9, d3); q3 = LOAD_ROW(y0 + s + 10);
+#endif
+    const uint32_t u0 = pxw[((P_) & (RK - 1)) * 64 + lane], u1 = pxw[((P_ + 1) & (RK - 1)) * 64 + lane];
+    const uint32_t u2 = pxw[((P_ + 2) & (RK - 1)) * 64 + lane], u3 = pxw[((P_ + 3) & (RK - 1)) * 64 + lane];   // = c0
+    const uint32_t c1 = pxw[((P_ + 4) & (RK - 1)) * 64 + lane], c2 = pxw[((P_ + 5) & (RK - 1)) * 64 + lane];
     if (RESIZE) {
       // the four rows just stored are source rows y0 + s + 3 .. y0 + s + 6 = R0 + s + 2 .. (table entries s + 6 ..);
       // an output row between rows (y - 1, y) has the UPPER row's entry: s + 5 .. s + 8
       uint32_t ha[4], hb[4], hc[4], hd[4];
-      RZ_HSUM(s + 6, ha);
-      RZ_HSUM(s + 7, hb);
-      RZ_HSUM(s + 8, hc);
-      RZ_HSUM(s + 9, hd);
+      RZ_HSUM(P_ + 6, ha);
+      RZ_HSUM(P_ + 7, hb);
+      RZ_HSUM(P_ + 8, hc);
+      RZ_HSUM(P_ + 9, hd);
       RZ_EMIT(s + 5, hp, ha);
       RZ_EMIT(s + 6, ha, hb);
       RZ_EMIT(s + 7, hb, hc);
@@ -1037,6 +1088,14 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
     STREAM_APPEND(s + 1, cb1, cd1);
     STREAM_APPEND(s + 2, cb2, cd2);
     STREAM_APPEND(s + 3, cb3, cd3);
+  };
+  for (int s = 0; s <= r_last; s += 4) {
+    switch ((s >> 2) & 3) {
+      case 0: group(std::integral_constant<int, 0>{}, s); break;
+      case 1: group(std::integral_constant<int, 1>{}, s); break;
+      case 2: group(std::integral_constant<int, 2>{}, s); break;
+      default: group(std::integral_constant<int, 3>{}, s); break;
+    }
     const int sl = min(s + 3, r_last);
     // flushes happen between groups of four steps: at most kSGFlush + 4 x 64 records wait (kSGCap), at most 8 rows
     if (do_fast && (nG > kSGFlush || sl - last_flush >= kFlushRows || sl == r_last)) {
