@@ -517,6 +517,12 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
 constexpr int kTauBins = 64;             // score histogram bins of width 4 (k_fast_tau's sample, the emitted corners)
 constexpr int kQStat = kTauBins + 2;     // per (slot, level): the quarter's histogram, its strips done, spare
 constexpr int RK = 16;                   // ring rows (power of two)
+#ifndef MSF_ABL_DESCRIBE
+#define MSF_ABL_DESCRIBE 0       // timing-only ablations of k_describe (1: patches from the L2, 2: no descriptor tests)
+#endif
+#ifndef MSF_WALK_NOBRANCH
+#define MSF_WALK_NOBRANCH 0
+#endif
 #ifndef MSF_WALK_PREFETCH8
 #define MSF_WALK_PREFETCH8 1
 #endif
@@ -739,7 +745,7 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
     roff3 = rz_lane ? qov.w - (uint32_t)xs : 0u;
     dpitch = uniform_u32((uint32_t)Ld.pitch);
     dst_rs = uniform_rsrc(pyr + (long long)slot * g.pyr_bytes + Ld.pix_off, (uint32_t)Ld.h * (uint32_t)Ld.pitch);
-    dxoff = 4u * (uint32_t)gq;
+    dxoff = (MSF_WALK_NOBRANCH && !rz_lane) ? 0xFFFFFFF0u : 4u * (uint32_t)gq;
     // emit entries of the source rows R0 - 4 + j, j = lane (em_lo) and 64 + lane (em_hi): output row | w1 << 16 | 1 << 31
     // if an output row has source rows (y, y + 1) as its taps and y is owned by this strip
     const int ra = R0 - 4 + lane, rb = ra + 64;
@@ -771,6 +777,23 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
     h_[3] = udot2_u16(__builtin_amdgcn_perm(b1_, b0_, rsel[3]), rwxp[3], 0u);                                          \
   } while (0)
   // j_ = index of the UPPER source row in the strip's emit table (row R0 - 4 + j_); hu_ / hl_ = sums of the upper / lower row
+#if MSF_WALK_NOBRANCH
+  // straight-line form: the blend is computed whether or not an output row sits between the two source rows (5 of 6 do) and
+  // the store of a lane / row that has nothing to write is given an offset beyond the descriptor's range, which the
+  // hardware drops -- no branch, so the four rows' sums, blends and prefilters are one scheduling region
+#define RZ_EMIT(j_, hu_, hl_)                                                                                          \
+  do {                                                                                                                 \
+    const int jj_ = (j_);                                                                                              \
+    const uint32_t em_ = (uint32_t)__builtin_amdgcn_readlane((int)(jj_ < 64 ? em_lo : em_hi), jj_ & 63);               \
+    const uint32_t wy1_ = (em_ >> 16) & 0x1FFu, wy0_ = 256u - wy1_, rnd_ = 32768u;                                     \
+    const uint32_t v0_ = mad_u24_s(hu_[0], wy0_, mad_u24_s(hl_[0], wy1_, rnd_));                                       \
+    const uint32_t v1_ = mad_u24_s(hu_[1], wy0_, mad_u24_s(hl_[1], wy1_, rnd_));                                       \
+    const uint32_t v2_ = mad_u24_s(hu_[2], wy0_, mad_u24_s(hl_[2], wy1_, rnd_));                                       \
+    const uint32_t v3_ = mad_u24_s(hu_[3], wy0_, mad_u24_s(hl_[3], wy1_, rnd_));                                       \
+    const uint32_t pk_ = __builtin_amdgcn_perm(v1_, v0_, 0x0c0c0602u) | __builtin_amdgcn_perm(v3_, v2_, 0x06020c0cu);  \
+    __builtin_amdgcn_raw_buffer_store_b32(pk_, dst_rs, (int)em_ < 0 ? dxoff : 0xFFFFFFF0u, (em_ & 0xFFFFu) * dpitch, 0); \
+  } while (0)
+#else
 #define RZ_EMIT(j_, hu_, hl_)                                                                                          \
   do {                                                                                                                 \
     const int jj_ = (j_);                                                                                              \
@@ -786,6 +809,7 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
       if (rz_lane) __builtin_amdgcn_raw_buffer_store_b32(pk_, dst_rs, dxoff, (em_ & 0xFFFFu) * dpitch, 0);              \
     }                                                                                                                  \
   } while (0)
+#endif
 
   auto flush_out = [&]() {
     if (nO == 0) return;
@@ -1017,16 +1041,31 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
     cb_ = ((b0_ | b8_) & (b4_ | b12_)) & (vmr_);                                                                       \
     cd_ = ~((n0_ & n8_) | (n4_ & n12_)) & (vmr_);                                                                      \
   } while (0)
+#if MSF_WALK_NOBRANCH
+  // every lane writes: a lane without a survivor to its own dword of the pixel-entry list, which only lives inside a flush
 #define STREAM_APPEND(s_, cb_, cd_)                                                                                    \
   do {                                                                                                                 \
     const bool has_ = ((cb_) | (cd_)) != 0u;                                                                           \
     const unsigned long long bal_ = __ballot(has_);                                                                    \
-    if (bal_) {                                                                                                        \
+    uint32_t* const dst_ = has_ ? &sm.g[nG + mbcnt64(bal_)] : &dump[lane];                                             \
+    *dst_ = (cb_) | ((cd_) >> 1) | lane_rec | ((((uint32_t)(s_) & 63u) << 8) | (((uint32_t)(s_) >> 6) << 16));         \
+    nG += (uint32_t)__popcll(bal_);                                                                                    \
+  } while (0)
+#else
+#define STREAM_APPEND(s_, cb_, cd_)                                                                                    \
+  do {                                                                                                                 \
+    const bool has_ = ((cb_) | (cd_)) != 0u;                                                                           \
+    const unsigned long long bal_ = __ballot(has_);                                                                    \
+    if (MSF_WALK_NOBRANCH || bal_) {   /* nearly every row of 256 px has a survivor: no wave-level skip */               \
       /* cb_ / cd_ hold bit 7 of each byte only: the flags stay where they are, lane and row go into the free low bits */ \
       if (has_) sm.g[nG + mbcnt64(bal_)] = (cb_) | ((cd_) >> 1) | lane_rec | ((((uint32_t)(s_) & 63u) << 8) | (((uint32_t)(s_) >> 6) << 16)); \
       nG += (uint32_t)__popcll(bal_);                                                                                  \
     }                                                                                                                  \
   } while (0)
+#endif
+  uint32_t* const dump = reinterpret_cast<uint32_t*>(sm.p);
+  (void)dump;
+  static_assert(sizeof(sm.p) >= 64 * 4, "dump dwords of the branch-free append");
   const uint32_t lane_rec = (uint32_t)lane;
   static_assert(kWkMaxRows + 8 < 128, "a record holds 7 bits of rel row");
   static_assert(RK == 16, "the group body below exists in four copies, one per position of the group in the 16-row ring");
@@ -1074,7 +1113,12 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
     uint32_t cb0, cd0, cb1, cd1, cb2, cd2, cb3, cd3;
     // rows outside the strip's scored rows [s_lo, s_hi] only occur in its first and last groups: one test per group
     uint32_t vm0 = vm, vm1 = vm, vm2 = vm, vm3 = vm;
-    if (s < s_lo || s + 3 > s_hi) {
+    if (MSF_WALK_NOBRANCH) {
+      vm0 = (s >= s_lo && s <= s_hi) ? vm : 0u;
+      vm1 = (s + 1 >= s_lo && s + 1 <= s_hi) ? vm : 0u;
+      vm2 = (s + 2 >= s_lo && s + 2 <= s_hi) ? vm : 0u;
+      vm3 = (s + 3 >= s_lo && s + 3 <= s_hi) ? vm : 0u;
+    } else if (s < s_lo || s + 3 > s_hi) {
       vm0 = (s >= s_lo && s <= s_hi) ? vm : 0u;
       vm1 = (s + 1 >= s_lo && s + 1 <= s_hi) ? vm : 0u;
       vm2 = (s + 2 >= s_lo && s + 2 <= s_hi) ? vm : 0u;
@@ -1435,7 +1479,8 @@ __global__ __launch_bounds__(256) void k_thr_harris(OrbGeometry g, FrameSrc src,
                                                     const uint32_t* cand_cnt, const uint32_t* cand_key,
                                                     const uint8_t* cand_sc,
                                                     uint32_t* s1_cnt, uint4* s1, uint32_t* status,
-                                                    const uint32_t* __restrict__ tau, const float* __restrict__ cand_resp) {
+                                                    const uint32_t* __restrict__ tau, const float* __restrict__ cand_resp,
+                                                    int do_harris) {
   __shared__ uint32_t hist[256];
   __shared__ uint32_t thr_s, lcount;
   // Launched with 256 threads when the candidate lists are the dense ones (tens of thousands per level) and with one
@@ -1522,7 +1567,9 @@ __global__ __launch_bounds__(256) void k_thr_harris(OrbGeometry g, FrameSrc src,
   }
   __syncthreads();
   // pass 2: Harris response on dense lanes (lists without stored responses)
-  const uint32_t kept = have_resp ? 0u : min(lcount, (uint32_t)kS1Cap);
+  // (batches leave this pass to k_harris_flat: there the kept candidates of ALL (frame, level)s are spread evenly over
+  // waves of one round each, instead of one wave per (frame, level) walking up to four dependent rounds)
+  const uint32_t kept = (have_resp || !do_harris) ? 0u : min(lcount, (uint32_t)kS1Cap);
   for (uint32_t i = tid; i < kept; i += nt) {
     const uint32_t key = out[i].x;
     const float r = harris_at(img, pitch, key & 0xFFFF, key >> 16);
@@ -1533,6 +1580,42 @@ __global__ __launch_bounds__(256) void k_thr_harris(OrbGeometry g, FrameSrc src,
     uint32_t m = lcount;
     if (m > (uint32_t)kS1Cap) { atomicOr(&status[slot], kStatusOverflow); m = kS1Cap; }
     s1_cnt[slot * kOrbLevels + l] = m;
+  }
+}
+
+// HarrisResponses of the stage-1 lists, balanced: the lists of a frame are cut into units of 64 entries, level l getting
+// hw.n[l] units (enough for 2N x 1.25 entries: retainBest(2N) keeps 2N plus the ties of the last score; a longer list is
+// walked in steps of hw.n[l] x 64), one wave per unit.  k_thr_harris with one wave per (frame, level) spent four fifths
+// of its time here -- level 0 alone is four dependent rounds of 27 scattered loads at 4 waves per SIMD -- 0.39 ms of the
+// 0.56 ms selection stage per 2048 720p frames.
+struct HarrisUnits {
+  int base[kOrbLevels + 1];    // first unit of level l; base[nlevels] = units per frame
+  int n[kOrbLevels];
+};
+__global__ __launch_bounds__(256) void k_harris_flat(OrbGeometry g, FrameSrc src, const uint8_t* pyr, HarrisUnits hw,
+                                                     const uint32_t* __restrict__ s1_cnt, uint4* s1,
+                                                     const uint32_t* __restrict__ cand_cnt,
+                                                     const uint32_t* __restrict__ tau) {
+  const int fi = blockIdx.y, slot = src.slot0 + fi, lane = threadIdx.x & 63;
+  const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (u >= hw.base[g.nlevels]) return;
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < kOrbLevels; i++)
+    if (i < g.nlevels && u >= hw.base[i]) l = i;
+  const OrbLevelInfo L = g.lv[l];
+  const uint32_t kept = min(s1_cnt[slot * kOrbLevels + l], (uint32_t)kS1Cap);
+  // lists whose responses the walker made (MSF_ORB_WALKER_HARRIS=1): the condition k_thr_harris applies
+  if (tau != nullptr && tau[slot * kOrbLevels + l] > (uint32_t)kFastT &&
+      min(cand_cnt[slot * kOrbLevels + l], (uint32_t)L.cand_cap) <= (uint32_t)kRespCap)
+    return;
+  uint4* out = s1 + (long long)slot * g.s1_total + L.s1_off;
+  int pitch;
+  const uint8_t* img = level_ptr(g, src, pyr, fi, l, &pitch);
+  const uint32_t step = 64u * (uint32_t)hw.n[l];
+  for (uint32_t i = 64u * (uint32_t)(u - hw.base[l]) + lane; i < kept; i += step) {
+    const uint32_t key = out[i].x;
+    out[i].y = __float_as_uint(harris_at(img, pitch, key & 0xFFFF, key >> 16));
   }
 }
 
@@ -1688,9 +1771,24 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
   __shared__ __attribute__((aligned(16))) uint8_t raw_s[4][PD * PP + 16];
   __shared__ __attribute__((aligned(16))) uint16_t hb_s[4][PD * HP];
   __shared__ uint32_t disc_s[2 * kDiscTasks];
+  // the rBRIEF table sits in LDS: read from constant memory per key point it is a VECTOR load behind the next patch's
+  // prefetch, and waiting for it (vmcnt counts in order) waited for the prefetch too -- every key point then paid a full
+  // memory latency (6 us per key point and wave; the kernel was bound by neither its bytes nor its instructions)
+  __shared__ __attribute__((aligned(16))) int pat_s[256];
   const int fi = blockIdx.y, slot = src.slot0 + fi;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int i = threadIdx.x; i < 2 * kDiscTasks; i += 256) disc_s[i] = c_disc[i];
+  pat_s[threadIdx.x] = reinterpret_cast<const int*>(c_pattern)[threadIdx.x];
+  // base pointer and pitch of this frame's levels: the level of a key point is a vector register to the compiler, and the
+  // geometry struct indexed by it was two more vector loads, waited for in full, in front of every patch prefetch
+  __shared__ unsigned long long lvl_base_s[kOrbLevels];
+  __shared__ int lvl_pitch_s[kOrbLevels];
+  if (threadIdx.x < kOrbLevels) {
+    int pt = 0;
+    const uint8_t* bp = level_ptr(g, src, pyr, fi, threadIdx.x < g.nlevels ? (int)threadIdx.x : 0, &pt);
+    lvl_base_s[threadIdx.x] = (unsigned long long)bp;
+    lvl_pitch_s[threadIdx.x] = pt;
+  }
   __syncthreads();
   const uint32_t count = min(kp_cnt[slot], (uint32_t)kKpCap);
   uint8_t* raw = raw_s[wave];
@@ -1713,18 +1811,23 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
     return make_uint3((uint32_t)Kp->octave, (uint32_t)Kp->lx, (uint32_t)Kp->ly);
   };
   auto issue = [&](uint3 m) {
-    int pitch_;
-    const uint8_t* img_ = level_ptr(g, src, pyr, fi, (int)m.x, &pitch_);
+    const int pitch_ = lvl_pitch_s[m.x];
+    typedef const __attribute__((address_space(1))) uint8_t* gptr_t;   // global, not generic: a flat load counts as an LDS op too
+    gptr_t img_ = (gptr_t)lvl_base_s[m.x];
     // raw patch, radius 22, fetched as aligned dwords: columns ax .. ax+47 hold x = cx-22 .. cx+22 at byte
     // offset xo (keypoints sit >= 31 px inside the level, so this never leaves the row)
     const int ax = ((int)m.y - PR) & ~3;
     xo_pre = ((int)m.y - PR) - ax;
-    const uint8_t* base = img_ + (long long)((int)m.z - PR) * pitch_ + ax;
+#if MSF_ABL_DESCRIBE == 1
+    gptr_t base = img_ + (long long)(40 + (k & 7)) * pitch_ + (ax & 63);     // timing only: every patch from the L2
+#else
+    gptr_t base = img_ + (long long)((int)m.z - PR) * pitch_ + ax;
+#endif
 #pragma unroll
     for (int u = 0; u < NPL; u++) {
       const int i = lane + 64 * u;
       const int r = i / (PP / 4), c = i % (PP / 4);
-      pre[u] = i < PD * (PP / 4) ? *reinterpret_cast<const uint32_t*>(base + (long long)r * pitch_ + 4 * c) : 0u;
+      pre[u] = i < PD * (PP / 4) ? *(const __attribute__((address_space(1))) uint32_t*)(base + (long long)r * pitch_ + 4 * c) : 0u;
     }
   };
   uint3 m_cur = meta(k), m_next = meta(k + kstride);
@@ -1804,11 +1907,11 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
       rad *= (float)(3.14159265358979323846 / 180.f);
       det_sincosf(rad, &b, &a);  // a = cos, b = sin
       // computeOrbDescriptors (orb.cpp), WTA_K = 2: lane handles tests 4*lane .. 4*lane+3
-      const int4 pk = *reinterpret_cast<const int4*>(&c_pattern[lane * 16]);
+      const int4 pk = *reinterpret_cast<const int4*>(&pat_s[lane * 4]);
       const int words[4] = {pk.x, pk.y, pk.z, pk.w};
       uint32_t nib = 0;
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
+      for (int t = 0; t < (MSF_ABL_DESCRIBE == 2 ? 0 : 4); t++) {
         int val[2];
 #pragma unroll
         for (int e = 0; e < 2; e++) {
@@ -2118,6 +2221,7 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   // MSF_ORB_WALKER_HARRIS=1: the walker computes the Harris response of every corner it emits from its pixel ring and
   // k_thr_harris only ranks (default 0: k_thr_harris computes the responses of the kept candidates from the pyramid)
   if (const char* e = getenv("MSF_ORB_WALKER_HARRIS")) walker_harris_ = atoi(e);
+  if (const char* e = getenv("MSF_ORB_HARRIS_FLAT")) harris_flat_ = atoi(e);
   // MSF_ORB_TAU_PREDICT: percent of the needed corner density the prediction of a level's first threshold from the level
   // above keeps (0 = sample every level, the r02 behaviour)
   if (const char* e = getenv("MSF_ORB_TAU_PREDICT")) {
@@ -2573,7 +2677,23 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
   if (evs) hipEventRecord(evs[2], st);
   hipLaunchKernelGGL(k_thr_harris, dim3(g.nlevels, n), dim3(dense ? 256 : 64), 0, st, g, src, d_pyr_,
                      d_cand_cnt_, d_cand_, d_cand_sc_, d_s1_cnt_, d_s1_, d_status_,
-                     (const uint32_t*)(dense || walker_harris_ == 0 ? nullptr : d_tau_), (const float*)d_cand_resp_);
+                     (const uint32_t*)(dense || walker_harris_ == 0 ? nullptr : d_tau_), (const float*)d_cand_resp_,
+                     harris_flat_ && !dense ? 0 : 1);
+  if (harris_flat_ && !dense) {
+    HarrisUnits hw;
+    int nu = 0;
+    for (int l = 0; l < kOrbLevels; l++) {
+      hw.base[l] = nu;
+      hw.n[l] = l < g.nlevels ? (2 * g.lv[l].quota * 5 / 4 + 63) / 64 : 0;
+      if (l < g.nlevels && hw.n[l] < 1) hw.n[l] = 1;
+      nu += hw.n[l];
+    }
+    hw.base[kOrbLevels] = nu;
+    for (int l = g.nlevels; l < kOrbLevels; l++) hw.base[l] = nu;
+    hw.base[g.nlevels] = nu;
+    hipLaunchKernelGGL(k_harris_flat, dim3((nu + 3) / 4, n), dim3(256), 0, st, g, src, d_pyr_, hw, d_s1_cnt_, d_s1_, d_cand_cnt_,
+                       (const uint32_t*)(walker_harris_ == 0 ? nullptr : d_tau_));
+  }
   hipLaunchKernelGGL(k_select, dim3(n), dim3(256), 0, st, g, src.slot0, d_s1_cnt_, d_s1_, d_kp_, d_kp_cnt_,
                      d_status_);
   if (evs) hipEventRecord(evs[3], st);

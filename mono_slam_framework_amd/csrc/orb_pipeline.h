@@ -110,6 +110,7 @@ class OrbPipeline {
   uint32_t* d_cand_ = nullptr;     // [slots][cand_total] key = y << 16 | x
   uint8_t* d_cand_sc_ = nullptr;   // [slots][cand_total] FAST score
   float* d_cand_resp_ = nullptr;   // [slots][levels][kRespCap] Harris response of the walker's candidates
+  int harris_flat_ = 1;            // MSF_ORB_HARRIS_FLAT=0: Harris responses inside k_thr_harris (one wave per (frame, level))
   int walker_harris_ = 0;          // MSF_ORB_WALKER_HARRIS (opt-in: less HBM traffic, more walker time)
   uint32_t* d_s1_cnt_ = nullptr;   // [slots][8]
   uint4* d_s1_ = nullptr;          // [slots][s1_total] (key, response bits, score, 0)
