@@ -1763,13 +1763,20 @@ __device__ __forceinline__ void det_sincosf(float t, float* s, float* c) {
 constexpr int PR = 22;             // patch radius: 19 (rotated pattern reach) + 3 (blur taps)
 constexpr int PD = 2 * PR + 1;     // 45
 constexpr int PP = 48;             // raw patch pitch
-constexpr int HP = 40;
+constexpr int HP = 40;             // columns of the row-blurred patch
+constexpr int HC = 46;             // its column pitch in u16: 45 rows + 1; 92 B puts the ten column groups of a blur task on
+                                   // (nearly) distinct LDS banks (48 would put them all on one)
 
+// HALF_UP: the blur's column pass rounds half up (MSF_FLAG_BLUR_TIE_HALF_UP, and always with SUM256) instead of half to
+// even; SUM256: OpenCV's fixed-point kernel 18 34 48 56 48 34 18 instead of 18 34 49 55 49 34 18.  Compile-time: the
+// rounding is three instructions without a branch and the taps are literals.
+template <bool HALF_UP, bool SUM256>
 __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
-                                                  msf_keypoint* kp, const uint32_t* kp_cnt, uint8_t* desc,
-                                                  int half_up, int sum256) {
+                                                  msf_keypoint* kp, const uint32_t* kp_cnt, uint8_t* desc) {
   __shared__ __attribute__((aligned(16))) uint8_t raw_s[4][PD * PP + 16];
-  __shared__ __attribute__((aligned(16))) uint16_t hb_s[4][PD * HP];
+  // row-blurred patch, TRANSPOSED: column c (= sample x + 19) holds its 45 rows as consecutive u16 (pitch HC, even), so the
+  // seven vertical taps of a sample are four consecutive dwords (two LDS reads instead of seven)
+  __shared__ __attribute__((aligned(16))) uint16_t hb_s[4][HP * HC];
   __shared__ uint32_t disc_s[2 * kDiscTasks];
   // the rBRIEF table sits in LDS: read from constant memory per key point it is a VECTOR load behind the next patch's
   // prefetch, and waiting for it (vmcnt counts in order) waited for the prefetch too -- every key point then paid a full
@@ -1830,6 +1837,14 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
       pre[u] = i < PD * (PP / 4) ? *(const __attribute__((address_space(1))) uint32_t*)(base + (long long)r * pitch_ + 4 * c) : 0u;
     }
   };
+  // row blur: lane -> (row pair rl within a block of six, column group gq); dword offsets of its reads and writes
+  uint32_t* hb32 = reinterpret_cast<uint32_t*>(hb);
+  const int blur_rl = (lane * 26) >> 8, blur_gq = lane - 10 * blur_rl;       // lane / 10, lane % 10 (lanes 60..63: 6, 0..3)
+  const int blur_rd = blur_rl * (2 * (PP / 4)) + blur_gq, blur_wr = blur_gq * (4 * (HC / 2)) + blur_rl;
+  const bool blur_last = 18 + blur_rl < 23;                                    // pass 3 holds row pairs 18 .. 24
+  // descriptor samples: LDS byte address of hb[19][19 - 3], minus what the magic-constant sums carry (see there)
+  const uint32_t samp_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)hb +
+                             2u * (uint32_t)((PR - 3) * HC + (PR - 3)) - 2u * HC * 0x400000u - 2u * 0x4B400000u;
   uint3 m_cur = meta(k), m_next = meta(k + kstride);
   if (k < count) issue(m_cur);
   for (; k < count; k += kstride) {
@@ -1874,30 +1889,42 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
         m01 += __shfl_xor(m01, o);
       }
       angle = fast_atan2_deg((float)m01, (float)m10);
-      // 7-tap row pass of GaussianBlur(7x7, sigma 2) in its 8u integer form (18 34 49 55 49 34 18): 4 outputs per
-      // lane from three aligned dwords, taps applied with v_dot4_u32_u8 on byte windows cut by v_alignbyte
-      // (MSF_FLAG_BLUR_SUM256: OpenCV's bit-exact fixed-point kernel 18 34 48 56 48 34 18 instead)
-      const uint32_t k2 = sum256 ? 48u : 49u, k3 = sum256 ? 56u : 55u;
-      const uint32_t kTapLo = 18u | (34u << 8) | (k2 << 16) | (k3 << 24);
-      const uint32_t kTapHi = k2 | (34u << 8) | (18u << 16);
-      uint32_t* hb32 = reinterpret_cast<uint32_t*>(hb);
-      // 45 rows x 10 groups = 450 tasks; the last two (row 44, columns 32..39) would need a sample at x >= 13, y = 19,
-      // outside the pattern's reach (bit_pattern_31 has radius <= 18.4): 448 tasks are exactly 7 passes of the wave
-      static_assert(PD * 10 - 2 == 7 * 64, "row-blur task count");
-      for (int i = lane; i < PD * 10 - 2; i += 64) {
-        const int r = i / 10, gq = i % 10;
-        const uint32_t* d = raw32 + r * (PP / 4) + gq;
-        const uint32_t d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];
-        const uint32_t e0 = __builtin_amdgcn_alignbyte(d1, d0, xo), e1 = __builtin_amdgcn_alignbyte(d2, d1, xo);
-        const uint32_t e2 = __builtin_amdgcn_alignbyte(d3, d2, xo);
-        uint32_t sres[4];
+      // 7-tap row pass of GaussianBlur(7x7, sigma 2) in its 8u integer form (18 34 49 55 49 34 18, or OpenCV's bit-exact
+      // fixed-point kernel 18 34 48 56 48 34 18).  A task = TWO rows x 4 output columns from 2 x 4 aligned dwords: output j
+      // is the taps laid over bytes j .. j + 6 of the 12-byte window, i.e. v_dot4_u32_u8 of each window dword with the
+      // taps SHIFTED into place (10 dot products per 4 outputs, no per-output byte alignment).  Lane -> (row pair within a
+      // block of six, column group), so every LDS address of the four passes is lane base + immediate.
+      {
+        constexpr uint32_t T0 = 18, T1 = 34, T2 = SUM256 ? 48 : 49, T3 = SUM256 ? 56 : 55;      // taps T0 T1 T2 T3 T2 T1 T0
+        constexpr uint32_t A0 = T0 | T1 << 8 | T2 << 16 | T3 << 24, B0 = T2 | T1 << 8 | T0 << 16;
+        constexpr uint32_t A1 = T0 << 8 | T1 << 16 | T2 << 24, B1 = T3 | T2 << 8 | T1 << 16 | T0 << 24;
+        constexpr uint32_t A2 = T0 << 16 | T1 << 24, B2 = T2 | T3 << 8 | T2 << 16 | T1 << 24, C2 = T0;
+        constexpr uint32_t A3 = T0 << 24, B3 = T1 | T2 << 8 | T3 << 16 | T2 << 24, C3 = T1 | T0 << 8;
+        auto row4 = [&](const uint32_t* d, uint32_t* o) {
+          const uint32_t d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];
+          const uint32_t e0 = __builtin_amdgcn_alignbyte(d1, d0, xo), e1 = __builtin_amdgcn_alignbyte(d2, d1, xo);
+          const uint32_t e2 = __builtin_amdgcn_alignbyte(d3, d2, xo);
+          o[0] = __builtin_amdgcn_udot4(e0, A0, __builtin_amdgcn_udot4(e1, B0, 0u, false), false);
+          o[1] = __builtin_amdgcn_udot4(e0, A1, __builtin_amdgcn_udot4(e1, B1, 0u, false), false);
+          o[2] = __builtin_amdgcn_udot4(e0, A2, __builtin_amdgcn_udot4(e1, B2, __builtin_amdgcn_udot4(e2, C2, 0u, false), false), false);
+          o[3] = __builtin_amdgcn_udot4(e0, A3, __builtin_amdgcn_udot4(e1, B3, __builtin_amdgcn_udot4(e2, C3, 0u, false), false), false);
+        };
+        // 23 row pairs (rows 0 .. 45; row 45 is the pad row of hb and reads the 16 spare bytes behind the raw patch and
+        // whatever follows them -- never sampled) x 10 column groups = 4 passes of 60 lanes; lanes 60 .. 63 repeat what
+        // lanes 0 .. 3 do in the next pass (same values to the same place) except in the last pass, where lanes with
+        // row pair >= 23 must not write
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const uint32_t lo = __builtin_amdgcn_alignbyte(e1, e0, j), hi = __builtin_amdgcn_alignbyte(e2, e1, j);
-          sres[j] = __builtin_amdgcn_udot4(lo, kTapLo, __builtin_amdgcn_udot4(hi, kTapHi, 0u, false), false);
+        for (int it = 0; it < 4; it++) {
+          const uint32_t* d = raw32 + blur_rd + it * (12 * (PP / 4));
+          uint32_t ou[4], ol[4];
+          row4(d, ou);
+          row4(d + PP / 4, ol);
+          if (it < 3 || blur_last) {
+            uint32_t* w = hb32 + blur_wr + it * 6;
+#pragma unroll
+            for (int j = 0; j < 4; j++) w[j * (HC / 2)] = ou[j] | (ol[j] << 16);     // each <= 255 * 257 = 65535
+          }
         }
-        hb32[r * (HP / 2) + 2 * gq] = sres[0] | (sres[1] << 16);        // each <= 255 * 257 = 65535
-        hb32[r * (HP / 2) + 2 * gq + 1] = sres[2] | (sres[3] << 16);
       }
     }
     MSF_WAVE_SYNC();
@@ -1910,28 +1937,32 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
       const int4 pk = *reinterpret_cast<const int4*>(&pat_s[lane * 4]);
       const int words[4] = {pk.x, pk.y, pk.z, pk.w};
       uint32_t nib = 0;
+      constexpr uint32_t K2 = SUM256 ? 48 : 49, K3 = SUM256 ? 56 : 55;
+      constexpr uint32_t P0 = 18u | 34u << 16, P1 = K2 | K3 << 16, P2 = K2 | 34u << 16, P3 = 18u;
 #pragma unroll
       for (int t = 0; t < (MSF_ABL_DESCRIBE == 2 ? 0 : 4); t++) {
-        int val[2];
+        uint32_t val[2];
 #pragma unroll
         for (int e = 0; e < 2; e++) {
           const float px = (float)(signed char)(words[t] >> (16 * e));
           const float py = (float)(signed char)(words[t] >> (16 * e + 8));
-          const int ix = __float2int_rn(px * a - py * b);
-          const int iy = __float2int_rn(px * b + py * a);
-          // column pass at the sampled pixel only
-          const uint16_t* q = hb + (PR + iy - 3) * HP + (PR + ix - 3);
-          const uint32_t s = 18u * (q[0] + q[6 * HP]) + 34u * (q[HP] + q[5 * HP]) + (sum256 ? 48u : 49u) * (q[2 * HP] + q[4 * HP]) +
-                             (sum256 ? 56u : 55u) * q[3 * HP];
-          uint32_t r;
-          if (half_up) {
-            r = (s + 32768u) >> 16;
-          } else {
-            r = s >> 16;
-            const uint32_t frac = s & 0xFFFFu;
-            if (frac > 0x8000u || (frac == 0x8000u && (r & 1u))) r++;
-          }
-          val[e] = (int)(r > 255u ? 255u : r);
+          // cvRound by the magic constant: for |v| < 2^22, v + 1.5 * 2^23 is v rounded to the nearest integer, ties to even,
+          // in the low mantissa bits -- the sum's bit pattern is 0x4B400000 + round(v)
+          const uint32_t tx = __float_as_uint((px * a - py * b) + 12582912.f);
+          const uint32_t ty = __float_as_uint((px * b + py * a) + 12582912.f);
+          // byte address of hb[column 19 + ix][row 19 + iy - 3]: 2 * HC * ix + 2 * iy + constant; v_mad_u32_u24 takes the low
+          // 24 bits of tx (0x400000 + ix) and everything else is folded into samp_base (arithmetic modulo 2^32)
+          const uint32_t addr = mad_u24(tx, 2u * HC, (ty << 1) + samp_base);
+          const __attribute__((address_space(3))) uint32_t* q =
+              (const __attribute__((address_space(3))) uint32_t*)(addr & ~3u);
+          const uint32_t sh = addr & 2u;                 // the seven u16 start in the upper half of the first dword
+          const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
+          const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+          const uint32_t w2 = __builtin_amdgcn_alignbyte(d3, d2, sh), w3 = __builtin_amdgcn_alignbyte(0u, d3, sh);
+          const uint32_t sum = udot2_u16(w0, P0, udot2_u16(w1, P1, udot2_u16(w2, P2, udot2_u16(w3, P3, 0u))));
+          // (sum + 32768) >> 16, ties up or to even
+          const uint32_t r = HALF_UP ? (sum + 32768u) >> 16 : (sum + 0x7FFFu + ((sum >> 16) & 1u)) >> 16;
+          val[e] = min(r, 255u);
         }
         nib |= (uint32_t)(val[0] < val[1]) << t;
       }
@@ -2702,8 +2733,8 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
     // gets up to 128 so that its ~500 key points per frame are one pass instead of sixteen
     int bx = 2048 / n;
     bx = bx < 8 ? 8 : bx > 128 ? 128 : bx;
-    hipLaunchKernelGGL(k_describe, dim3(bx, n), dim3(256), 0, st, g, src, d_pyr_, d_kp_, d_kp_cnt_, d_desc_,
-                       (half_up_ || blur_sum256_) ? 1 : 0, blur_sum256_ ? 1 : 0);
+    auto kd = blur_sum256_ ? k_describe<true, true> : half_up_ ? k_describe<true, false> : k_describe<false, false>;
+    hipLaunchKernelGGL(kd, dim3(bx, n), dim3(256), 0, st, g, src, d_pyr_, d_kp_, d_kp_cnt_, d_desc_);
   }
   if (evs) hipEventRecord(evs[4], st);
   return hipGetLastError();
