@@ -31,7 +31,7 @@ constexpr uint32_t kStatusOverflow = 1u;
 
 __constant__ __attribute__((aligned(16))) signed char c_pattern[1024];
 // ICAngles disc as 31 rows x 8 dwords of 4 pixels (u = -16 + 4k .. -13 + 4k): per dword the signed byte weights u
-// (0 outside the disc) and the 0/1 membership bytes, padded to 4 x 64 tasks
+// (0 outside the disc) and the signed byte weights v (the row's, 0 outside the disc), padded to 4 x 64 tasks
 constexpr int kDiscTasks = 256;
 __constant__ uint32_t c_disc[2 * kDiscTasks];
 
@@ -1875,19 +1875,19 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
 #pragma unroll
         for (int it = 0; it < kDiscTasks / 64; it++) {
           const int t = it * 64 + lane;
-          const int row = t >> 3, k = t & 7;              // row = v + 15 (rows 31 are padding: zero weights)
-          const uint32_t* d = raw32 + min(row + 7, PD - 1) * (PP / 4) + dw0 + k;
-          const uint32_t pxw = __builtin_amdgcn_alignbyte(d[1], d[0], shf);
-          const uint32_t wu = disc_s[2 * t], w1 = disc_s[2 * t + 1];
-          m10 = __builtin_amdgcn_sdot4((int)(pxw ^ 0x80808080u), (int)wu, m10, false);
-          m01 += (row - 15) * (int)__builtin_amdgcn_udot4(pxw, w1, 0u, false);
+          const int row = t >> 3, k = t & 7;              // row = v + 15 (rows 31 are padding: zero weights); row + 7 <= 38
+          const uint32_t* d = raw32 + (row + 7) * (PP / 4) + dw0 + k;
+          const uint32_t pxw = __builtin_amdgcn_alignbyte(d[1], d[0], shf) ^ 0x80808080u;
+          const uint32_t wu = disc_s[2 * t], wv = disc_s[2 * t + 1];
+          // both moments as signed dot products of p - 128 with the byte weights u and v (0 outside the disc): the -128
+          // cancels over a row for m10 (the u of a row sum to 0) and over the disc for m01 (rows v and -v are equally long)
+          m10 = __builtin_amdgcn_sdot4((int)pxw, (int)wu, m10, false);
+          m01 = __builtin_amdgcn_sdot4((int)pxw, (int)wv, m01, false);
         }
       }
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) {
-        m10 += __shfl_xor(m10, o);
-        m01 += __shfl_xor(m01, o);
-      }
+      // wave sums by DPP (the shuffle form is twelve LDS round trips through ds_bpermute)
+      m10 = (int)__builtin_amdgcn_readlane((int)wave_incl_scan((uint32_t)m10), 63);
+      m01 = (int)__builtin_amdgcn_readlane((int)wave_incl_scan((uint32_t)m01), 63);
       angle = fast_atan2_deg((float)m01, (float)m10);
       // 7-tap row pass of GaussianBlur(7x7, sigma 2) in its 8u integer form (18 34 49 55 49 34 18, or OpenCV's bit-exact
       // fixed-point kernel 18 34 48 56 48 34 18).  A task = TWO rows x 4 output columns from 2 x 4 aligned dwords: output j
@@ -2479,7 +2479,7 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
           const int u = -16 + 4 * k + b;
           if (u >= -dmax && u <= dmax) {
             wu |= (uint32_t)(uint8_t)(int8_t)u << (8 * b);
-            w1 |= 1u << (8 * b);
+            w1 |= (uint32_t)(uint8_t)(int8_t)v << (8 * b);
           }
         }
         disc[2 * ((v + 15) * 8 + k)] = wu;
