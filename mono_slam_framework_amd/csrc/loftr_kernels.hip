@@ -3228,10 +3228,12 @@ constexpr int kCandCap = NTOK * kCandPerRow;          // per pair; cannot overfl
 struct SimCand { uint32_t ij; float s; };
 
 __global__ __launch_bounds__(256) void k_row_limits(const float* __restrict__ rstats, long long stats_stride,
-                                                    float threshold, float* __restrict__ lim, int n_pairs) {
+                                                    float threshold, float* __restrict__ lim, int n_pairs,
+                                                    const uint32_t* __restrict__ only_if) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= n_pairs * NTOK) return;
   const int pair = idx / NTOK, i = idx - pair * NTOK;
+  if (only_if && !only_if[pair]) return;
   const float* rs = rstats + (long long)pair * stats_stride;
   lim[idx] = rs[i] + __logf(threshold * rs[NTOK + i]) - 1e-2f;
 }
@@ -3241,10 +3243,12 @@ __global__ __launch_bounds__(256) void k_sim_stats(const float* __restrict__ fa,
                                                    long long pair_stride, float* __restrict__ stats /*[pair][2][1200]*/,
                                                    long long stats_stride, const float* __restrict__ lim,
                                                    SimCand* __restrict__ cand, uint32_t* __restrict__ cand_cnt,
-                                                   const __bf16* __restrict__ pa, const __bf16* __restrict__ pb) {
+                                                   const __bf16* __restrict__ pa, const __bf16* __restrict__ pb,
+                                                   const uint32_t* __restrict__ only_if) {
   const int pair = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tl = lane & 15, g = lane >> 4;
   const int it = blockIdx.x * 4 + wave;
   if (it >= NTOK / 16) return;
+  if (only_if && !only_if[pair]) return;      // the single-pass statistics held for this pair (k_sim_finish)
   const float* A = fa + (long long)pair * pair_stride;
   const float* B = fb + (long long)pair * pair_stride;
   float a[8];
@@ -3353,10 +3357,12 @@ template <bool EMIT>
 __global__ __launch_bounds__(64 * kSimWaves) void k_sim_stats3(const __bf16* __restrict__ pa, const __bf16* __restrict__ pb,
                                                                long long pair_stride, float* __restrict__ stats,
                                                                long long stats_stride, const float* __restrict__ lim,
-                                                               SimCand* __restrict__ cand, uint32_t* __restrict__ cand_cnt) {
+                                                               SimCand* __restrict__ cand, uint32_t* __restrict__ cand_cnt,
+                                                               const uint32_t* __restrict__ only_if) {
   const int pair = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tl = lane & 15, g = lane >> 4;
   const int it0 = (blockIdx.x * kSimWaves + wave) * kSimRT;
   if (it0 >= NTOK / 16) return;
+  if (only_if && !only_if[pair]) return;
   static_assert((NTOK / 16) % kSimRT == 0, "row tiles per wave");
   const bf16x8* PA = reinterpret_cast<const bf16x8*>(pa + (long long)pair * 3 * pair_stride);
   const bf16x8* PB = reinterpret_cast<const bf16x8*>(pb + (long long)pair * 3 * pair_stride);
@@ -3450,6 +3456,251 @@ __global__ __launch_bounds__(64 * kSimWaves) void k_sim_stats3(const __bf16* __r
         st[NTOK + (it0 + t) * 16 + 4 * g + r] = sx;
       }
     }
+}
+
+// ---- row AND column statistics from ONE evaluation of S (split path, batches; r03).
+// The two passes above each spend 13 VALU cycles per entry on the running-maximum soft-max (two exponentials per
+// three entries' rescale, the max, the exact division by the temperature) and are bound by that, not by their MFMAs.
+// With ONE offset G per pair -- G = 10 max|f0s_i| max|f1s_j| >= every s_ij (Cauchy-Schwarz) -- e_ij = exp(s_ij - G)
+// serves both soft-maxes: R_i = sum_j e_ij, C_j = sum_i e_ij, and the statistics the consumers read are (G, R_i) and
+// (G, C_j): exp(s - G) / R_i is the same row soft-max.  One fma + one v_exp + two adds per entry.  What the offset
+// costs is range: an entry more than ~87 below G underflows.  LoFTR's logits live in [-2, 3] with G ~ 28, but nothing
+// bounds them in principle, so k_sim_finish checks every sum and flags a pair whose sums left [1e-30, 1e30]; a
+// flagged pair is redone by the running-maximum passes (which skip every other pair).  Sums in a fixed order: a wave
+// owns three row tiles over a third of the column tiles, leaves its row sums in rpart[pair][third][1200] and its column
+// partials in cpart[pair][triple 0..24][1200]; k_sim_finish adds the 3 and the 25 in order.  Deterministic, no atomics.
+constexpr int kSimParts = NTOK / 16 / kSimRT;         // 25 row-tile triples per pair
+constexpr int kSimColParts = 3;                       // column thirds (blockIdx.z)
+constexpr int kSimColTiles = NTOK / 16 / kSimColParts;
+static_assert(kSimColTiles * kSimColParts == NTOK / 16, "column thirds");
+// Work items (pair, column third, row-tile triple), the triple running fastest, four per workgroup: a workgroup of FIVE
+// waves (k_sim_stats3's shape) puts two of its waves on one SIMD, and at four waves per SIMD (104 VGPRs) only two such
+// workgroups fit a CU -- 10 of 16 wave slots; measured occupancy of the 5-wave form: 46 %.
+constexpr int kSimItemWaves = 4;
+constexpr int kSimItemsPerPair = kSimColParts * kSimParts;    // 75
+__global__ __launch_bounds__(256) void k_pair_bound(const float* __restrict__ f0s, const float* __restrict__ f1s,
+                                                    long long pair_stride, float* __restrict__ gbound) {
+  __shared__ float red[2][4];
+  const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float m[2] = {0.f, 0.f};
+#pragma unroll
+  for (int side = 0; side < 2; side++) {
+    const float* F = (side ? f1s : f0s) + (long long)pair * pair_stride;
+    for (int tkn = tid; tkn < NTOK; tkn += 256) {
+      float q = 0.f;
+#pragma unroll
+      for (int c = 0; c < DM; c += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(F + (long long)tkn * DM + c);
+        q += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      }
+      m[side] = fmaxf(m[side], q);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m[side] = fmaxf(m[side], __shfl_xor(m[side], o));
+    if (lane == 0) red[side][wave] = m[side];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float a = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    const float b = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+    // a little above 10 |a| |b|: the bound only has to be near the logits, its rounding is of no consequence
+    gbound[pair] = 10.0001f * sqrtf(a) * sqrtf(b);
+  }
+}
+
+__global__ __launch_bounds__(64 * kSimItemWaves) void k_sim_single(const __bf16* __restrict__ pa, const __bf16* __restrict__ pb,
+                                                               long long pair_stride, const float* __restrict__ gbound,
+                                                               float* __restrict__ rpart, float* __restrict__ cpart,
+                                                               int n_items) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tl = lane & 15, g = lane >> 4;
+  const int item = blockIdx.x * kSimItemWaves + wave;
+  if (item >= n_items) return;
+  const int pair = item / kSimItemsPerPair, rem = item - pair * kSimItemsPerPair;
+  const int zpart = rem / kSimParts, part = rem - zpart * kSimParts, it0 = part * kSimRT;
+  const bf16x8* PA = reinterpret_cast<const bf16x8*>(pa + (long long)pair * 3 * pair_stride);
+  const bf16x8* PB = reinterpret_cast<const bf16x8*>(pb + (long long)pair * 3 * pair_stride);
+  constexpr int kPlane = NTOK * DM / 8;
+  bf16x8 a3[kSimRT][3];
+#pragma unroll
+  for (int t = 0; t < kSimRT; t++)
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) a3[t][pl] = PA[pl * kPlane + ((it0 + t) * 16 + tl) * (DM / 8) + g];
+  const float G = gbound[pair];
+  // exp(d / 0.1 - G) = 2^(d * 10 log2(e) - G log2(e))
+  const float c1 = 14.4269504089f, c0 = -G * 1.44269504089f;
+  float rs[kSimRT][4];
+#pragma unroll
+  for (int t = 0; t < kSimRT; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) rs[t][r] = 0.f;
+  float* cp = cpart + ((long long)pair * kSimParts + part) * NTOK;
+  // the column tile's three operand planes are requested one tile ahead: a step is 18 MFMAs and 12 exponentials, about
+  // the L2 latency it would otherwise wait for at four waves per SIMD
+  bf16x8 bn[3];
+  // zpart = which third of the column tiles: 256 pairs are 6 400 (row-tile triple, all columns) items for 4 096 wave
+  // slots, i.e. two rounds with the second 56 % full; in thirds it is 4.7 rounds of a third (1.67 instead of 2)
+  const int jt_lo = zpart * kSimColTiles, jt_hi = jt_lo + kSimColTiles;
+#pragma unroll
+  for (int pl = 0; pl < 3; pl++) bn[pl] = PB[pl * kPlane + (jt_lo * 16 + tl) * (DM / 8) + g];
+  for (int jt = jt_lo; jt < jt_hi; jt++) {
+    bf16x8 b3[3];
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) b3[pl] = bn[pl];
+    const int jn = jt + 1 < jt_hi ? jt + 1 : jt;
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) bn[pl] = PB[pl * kPlane + (jn * 16 + tl) * (DM / 8) + g];
+    float col = 0.f;
+#pragma unroll
+    for (int t = 0; t < kSimRT; t++) {
+      f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+      d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[t][2], b3[0], d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[t][0], b3[2], d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[t][1], b3[1], d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[t][1], b3[0], d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[t][0], b3[1], d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[t][0], b3[0], d, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(d[r], c1, c0));
+        rs[t][r] += e;
+        col += e;
+      }
+    }
+    // this lane's column jt * 16 + tl over the 12 rows it holds; the other three lane groups hold the other rows
+    col += __shfl_xor(col, 16);
+    col += __shfl_xor(col, 32);
+    if (g == 0) cp[jt * 16 + tl] = col;
+  }
+  float* rp = rpart + ((long long)pair * kSimColParts + zpart) * NTOK;
+#pragma unroll
+  for (int t = 0; t < kSimRT; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      float v = rs[t][r];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
+      if (tl == 0) rp[(it0 + t) * 16 + 4 * g + r] = v;
+    }
+}
+
+// column sums from the 25 partials (fixed order), the candidate bound of every row, and the range check
+__global__ __launch_bounds__(256) void k_sim_finish(const float* __restrict__ gbound, float* __restrict__ rstats,
+                                                    const float* __restrict__ rpart,
+                                                    float* __restrict__ cstats, long long stats_stride,
+                                                    const float* __restrict__ cpart, float threshold,
+                                                    float* __restrict__ lim, uint32_t* __restrict__ redo, int n_pairs,
+                                                    int force_redo) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n_pairs * NTOK) return;
+  const int pair = idx / NTOK, i = idx - pair * NTOK;
+  const float* cp = cpart + (long long)pair * kSimParts * NTOK + i;
+  float c = 0.f;
+#pragma unroll 5
+  for (int w = 0; w < kSimParts; w++) c += cp[(long long)w * NTOK];
+  const float G = gbound[pair];
+  float* cs = cstats + (long long)pair * stats_stride;
+  cs[i] = G;
+  cs[NTOK + i] = c;
+  const float* rp = rpart + (long long)pair * kSimColParts * NTOK + i;
+  const float r = (rp[0] + rp[NTOK]) + rp[2 * NTOK];
+  static_assert(kSimColParts == 3, "row partials");
+  float* rsx = rstats + (long long)pair * stats_stride;
+  rsx[i] = G;
+  rsx[NTOK + i] = r;
+  if (lim) lim[idx] = G + __logf(threshold * r) - 1e-2f;
+  const bool ok = c > 1e-30f && c < 1e30f && r > 1e-30f && r < 1e30f;     // false for NaN as well
+  if (!ok || force_redo) atomicOr(&redo[pair], 1u);
+}
+
+// The candidates of the pairs whose single-pass statistics held: entries with s_ij >= lim_i (see k_row_limits; the same
+// predicate on the same s as the emitting k_sim_stats, so the same set).  A wave owns three row tiles of S (their twelve
+// bounds per lane stay in registers) and walks the column tiles; the products are compared in d units first (a slack of
+// 1e-3 covers the rounding of the division) and only a tile with a hit takes the exact division and the append.  Appends go
+// to a wave-private LDS list (ballot + prefix, no atomics) that is flushed with ONE global atomic: the per-lane global
+// atomics of the emitting k_sim_stats -- a memory round trip per tile with a hit, in the wave's critical path -- are
+// what made its three-tiles-per-wave form slower than one tile per wave.
+constexpr int kCandBuf = 512;                         // entries per wave; a step adds at most 9 x 256
+__global__ __launch_bounds__(64 * kSimItemWaves) void k_sim_cand3(const __bf16* __restrict__ pa, const __bf16* __restrict__ pb,
+                                                              long long pair_stride, const float* __restrict__ lim,
+                                                              SimCand* __restrict__ cand, uint32_t* __restrict__ cand_cnt,
+                                                              const uint32_t* __restrict__ skip_if, int n_items) {
+  __shared__ SimCand buf_s[kSimItemWaves][kCandBuf];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tl = lane & 15, g = lane >> 4;
+  const int item = blockIdx.x * kSimItemWaves + wave;
+  if (item >= n_items) return;
+  const int pair = item / kSimItemsPerPair, rem = item - pair * kSimItemsPerPair;
+  const int zpart = rem / kSimParts, it0 = (rem - zpart * kSimParts) * kSimRT;
+  if (skip_if && skip_if[pair]) return;        // flagged: the running-maximum passes list this pair's candidates
+  const bf16x8* PA = reinterpret_cast<const bf16x8*>(pa + (long long)pair * 3 * pair_stride);
+  const bf16x8* PB = reinterpret_cast<const bf16x8*>(pb + (long long)pair * 3 * pair_stride);
+  constexpr int kPlane = NTOK * DM / 8;
+  bf16x8 a3[kSimRT][3];
+  float li[kSimRT][4], ld[kSimRT][4];
+#pragma unroll
+  for (int t = 0; t < kSimRT; t++) {
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) a3[t][pl] = PA[pl * kPlane + ((it0 + t) * 16 + tl) * (DM / 8) + g];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      li[t][r] = lim[(long long)pair * NTOK + (it0 + t) * 16 + 4 * g + r];
+      ld[t][r] = (li[t][r] - 1e-3f) * 0.1f - 1e-6f;
+    }
+  }
+  SimCand* buf = buf_s[wave];
+  SimCand* out = cand + (long long)pair * kCandCap;
+  uint32_t nb = 0;                               // wave-uniform
+  auto flush = [&]() {
+    if (nb == 0) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&cand_cnt[pair], nb);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    for (uint32_t k = lane; k < nb; k += 64)
+      if (base + k < (uint32_t)kCandCap) out[base + k] = buf[k];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    nb = 0;
+  };
+  bf16x8 bn[3];
+  const int jt_lo = zpart * kSimColTiles, jt_hi = jt_lo + kSimColTiles;            // a third of the columns (see k_sim_single)
+#pragma unroll
+  for (int pl = 0; pl < 3; pl++) bn[pl] = PB[pl * kPlane + (jt_lo * 16 + tl) * (DM / 8) + g];
+  for (int jt = jt_lo; jt < jt_hi; jt++) {
+    bf16x8 b3[3];
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) b3[pl] = bn[pl];
+    const int jn = jt + 1 < jt_hi ? jt + 1 : jt;            // one tile ahead (see k_sim_single)
+#pragma unroll
+    for (int pl = 0; pl < 3; pl++) bn[pl] = PB[pl * kPlane + (jn * 16 + tl) * (DM / 8) + g];
+#pragma unroll
+    for (int t = 0; t < kSimRT; t++) {
+      f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+      // the product order of the emitting k_sim_stats call (operands swapped there): the same s, bit for bit
+      d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[t][0], b3[2], d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[t][2], b3[0], d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[t][1], b3[1], d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[t][0], b3[1], d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[t][1], b3[0], d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[t][0], b3[0], d, 0, 0, 0);
+      const bool reach = d[0] >= ld[t][0] || d[1] >= ld[t][1] || d[2] >= ld[t][2] || d[3] >= ld[t][3];
+      if (__any(reach)) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float sv = div_temperature(d[r]);
+          const bool hit = sv >= li[t][r];
+          const unsigned long long bal = __ballot(hit);
+          if (bal) {
+            if (hit) {
+              const uint32_t k = nb + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+              buf[k] = SimCand{(uint32_t)((it0 + t) * 16 + 4 * g + r) | ((uint32_t)(jt * 16 + tl) << 16), sv};
+            }
+            nb += (uint32_t)__popcll(bal);
+          }
+        }
+        if (nb > (uint32_t)(kCandBuf - 256)) flush();
+      }
+    }
+  }
+  flush();
 }
 
 // working copies of cached per-frame tokens for the pairs (slot_a[i], slot_b[i]): z = 0 -> f0, z = 1 -> f1
@@ -3646,6 +3897,12 @@ struct LoftrPipeline::Impl {
   float* lim = nullptr;      // [max_pairs][1200] candidate bound per row of S
   SimCand* cand = nullptr;   // [max_pairs][kCandCap]
   uint32_t* cand_cnt = nullptr;
+  float* gbound = nullptr;   // [max_pairs] single-pass statistics: the pair's exponent offset
+  float* cpart = nullptr;    // [max_pairs][25][1200] column-sum partials
+  float* rpart = nullptr;    // [max_pairs][3][1200] row-sum partials (one per third of the columns)
+  uint32_t* sim_redo = nullptr;   // [max_pairs] pairs whose single-pass sums left the f32 range
+  bool sim_single = true;    // MSF_LOFTR_SIM_SINGLE=0: the two running-maximum passes always
+  bool sim_force_redo = false;    // MSF_LOFTR_SIM_FORCE_REDO=1 (tests): every pair takes the fallback
   bool dense_head = false;
   bool fuse_blocks = true;   // MSF_LOFTR_UNFUSED=1: one kernel per convolution (tests: bit-identical results)
   bool split_bf16 = true;    // MSF_LOFTR_F32=1: every convolution on the f32 MFMA (no split-bf16 kernels)
@@ -3703,6 +3960,8 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
   P.n_slots = 2 * max_pairs + (extra_slots > 0 ? extra_slots : 0);
   {
     if (const char* d = getenv("MSF_LOFTR_DENSE_HEAD")) P.dense_head = atoi(d) != 0;   // tests: force the dense head
+    if (const char* d = getenv("MSF_LOFTR_SIM_SINGLE")) P.sim_single = atoi(d) != 0;
+    if (const char* d = getenv("MSF_LOFTR_SIM_FORCE_REDO")) P.sim_force_redo = atoi(d) != 0;
     if (const char* d = getenv("MSF_LOFTR_UNFUSED")) P.fuse_blocks = atoi(d) == 0;
     P.split_bf16 = !f32_convs;
     if (const char* d = getenv("MSF_LOFTR_F32")) P.split_bf16 = atoi(d) == 0;
@@ -4036,6 +4295,14 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
     LF_TRY(hipMemset(P.mask, 0, (size_t)max_pairs * NTOK * MASK_WORDS * sizeof(uint32_t)));
   }
   LF_TRY(dalloc(&P.lim, (size_t)max_pairs * NTOK));
+  LF_TRY(dalloc(&P.gbound, (size_t)max_pairs));
+  LF_TRY(dalloc(&P.cpart, (size_t)max_pairs * kSimParts * NTOK));
+  LF_TRY(dalloc(&P.rpart, (size_t)max_pairs * kSimColParts * NTOK));
+  {
+    float* m = nullptr;
+    LF_TRY(dalloc(&m, (size_t)max_pairs));
+    P.sim_redo = reinterpret_cast<uint32_t*>(m);
+  }
   {
     float* m = nullptr;
     LF_TRY(dalloc(&m, (size_t)max_pairs * kCandCap * 2));
@@ -4437,21 +4704,42 @@ hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf
   const dim3 grid3((NTOK / 16 / kSimRT + kSimWaves - 1) / kSimWaves, n), block3(64 * kSimWaves);
   // a call of a few pairs is latency-bound: one row tile per wave (75 waves per pair) instead of three (25)
   const bool few = n < 8;
-  if (p0 && !few) hipLaunchKernelGGL(k_sim_stats3<false>, grid3, block3, 0, st, p0, p1, ts, P.rstats, 2LL * NTOK, nullptr, nullptr, nullptr);
+  const bool sparse = threshold >= kCandMinThreshold && !P.dense_head;
+  const bool single = p0 && !few && P.sim_single;
+  const uint32_t* redo = nullptr;
+  if (single) {
+    // one evaluation of S gives both statistics; a pair whose sums left the f32 range is flagged and redone below
+    hipMemsetAsync(P.sim_redo, 0, (size_t)n * sizeof(uint32_t), st);
+    hipLaunchKernelGGL(k_pair_bound, dim3(n), dim3(256), 0, st, f0s, f1s, ts, P.gbound);
+    const int n_items = n * kSimItemsPerPair;
+    const dim3 gridi((n_items + kSimItemWaves - 1) / kSimItemWaves), blocki(64 * kSimItemWaves);
+    hipLaunchKernelGGL(k_sim_single, gridi, blocki, 0, st, p0, p1, ts, P.gbound, P.rpart, P.cpart, n_items);
+    hipLaunchKernelGGL(k_sim_finish, dim3((n * NTOK + 255) / 256), dim3(256), 0, st, P.gbound, P.rstats, P.rpart, P.cstats, 2LL * NTOK,
+                       P.cpart, threshold, sparse ? P.lim : nullptr, P.sim_redo, n, P.sim_force_redo ? 1 : 0);
+    redo = P.sim_redo;
+  }
+  // row statistics by the running-maximum pass: everything without the single pass, only the flagged pairs with it
+  if (p0 && !few) hipLaunchKernelGGL(k_sim_stats3<false>, grid3, block3, 0, st, p0, p1, ts, P.rstats, 2LL * NTOK, nullptr, nullptr, nullptr, redo);
   else if (p0) hipLaunchKernelGGL((k_sim_stats<false, true>), dim3(head_blocks, n), dim3(256), 0, st, f0s, f1s, ts, P.rstats, 2LL * NTOK,
-                                  nullptr, nullptr, nullptr, p0, p1);
+                                  nullptr, nullptr, nullptr, p0, p1, nullptr);
   else hipLaunchKernelGGL((k_sim_stats<false, false>), dim3(head_blocks, n), dim3(256), 0, st, f0s, f1s, ts, P.rstats, 2LL * NTOK,
-                          nullptr, nullptr, nullptr, nullptr, nullptr);
-  if (threshold >= kCandMinThreshold && !P.dense_head) {
+                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  if (sparse) {
     // sparse path: the column pass lists the few entries per row that can pass, k_conf_cand evaluates them exactly
     hipMemsetAsync(P.cand_cnt, 0, (size_t)n * sizeof(uint32_t), st);
     hipMemsetAsync(P.mask, 0, (size_t)n * NTOK * MASK_WORDS * sizeof(uint32_t), st);
-    hipLaunchKernelGGL(k_row_limits, dim3((n * NTOK + 255) / 256), dim3(256), 0, st, P.rstats, 2LL * NTOK, threshold, P.lim, n);
+    hipLaunchKernelGGL(k_row_limits, dim3((n * NTOK + 255) / 256), dim3(256), 0, st, P.rstats, 2LL * NTOK, threshold, P.lim, n, redo);
     // (the emitting pass stays one row tile per wave: three per wave serialises the candidate appends, 330 -> 381 us)
-    if (p0) hipLaunchKernelGGL((k_sim_stats<true, true>), dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats, 2LL * NTOK,
-                               P.lim, P.cand, P.cand_cnt, p1, p0);
+    if (single) {
+      const int n_items = n * kSimItemsPerPair;
+      hipLaunchKernelGGL(k_sim_cand3, dim3((n_items + kSimItemWaves - 1) / kSimItemWaves), dim3(64 * kSimItemWaves), 0, st, p0, p1, ts,
+                         P.lim, P.cand, P.cand_cnt, redo, n_items);
+      hipLaunchKernelGGL((k_sim_stats<true, true>), dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats, 2LL * NTOK,
+                         P.lim, P.cand, P.cand_cnt, p1, p0, redo);      // flagged pairs only
+    } else if (p0) hipLaunchKernelGGL((k_sim_stats<true, true>), dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats, 2LL * NTOK,
+                                    P.lim, P.cand, P.cand_cnt, p1, p0, nullptr);
     else hipLaunchKernelGGL((k_sim_stats<true, false>), dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats, 2LL * NTOK,
-                            P.lim, P.cand, P.cand_cnt, nullptr, nullptr);
+                            P.lim, P.cand, P.cand_cnt, nullptr, nullptr, nullptr);
     // pair 0's confidence matrix (+ its mask, densely) is kept for the parity tests
     if (P.keep_debug)
       hipLaunchKernelGGL(k_conf_mask, dim3(head_blocks, 1), dim3(256), 0, st, f0s, f1s, ts, P.rstats, P.cstats, 2LL * NTOK,
@@ -4460,11 +4748,11 @@ hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf
                        P.mask);
   } else {
     if (p0 && !few) hipLaunchKernelGGL(k_sim_stats3<false>, grid3, block3, 0, st, p1, p0, ts, P.cstats, 2LL * NTOK, nullptr, nullptr,
-                                       nullptr);
+                                       nullptr, redo);
     else if (p0) hipLaunchKernelGGL((k_sim_stats<false, true>), dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats,
-                                    2LL * NTOK, nullptr, nullptr, nullptr, p1, p0);
+                                    2LL * NTOK, nullptr, nullptr, nullptr, p1, p0, nullptr);
     else hipLaunchKernelGGL((k_sim_stats<false, false>), dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats,
-                            2LL * NTOK, nullptr, nullptr, nullptr, nullptr, nullptr);
+                            2LL * NTOK, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(k_conf_mask, dim3(head_blocks, n), dim3(256), 0, st, f0s, f1s, ts, P.rstats, P.cstats, 2LL * NTOK,
                        threshold, P.mask, P.keep_debug ? P.conf_dbg : nullptr, 0);
   }

@@ -296,3 +296,45 @@ def test_split_bf16_blocks_stay_within_a_tenth_of_the_tolerance(strip, seeds):
         maybe = np.argwhere(f["conf"] > 0.15 - 1e-4)
         cell = lambda m: set(((y1 // 16) * 40 + x1 // 16, (y2 // 16) * 40 + x2 // 16) for x1, y1, x2, y2 in m)
         assert set(map(tuple, sure)) <= cell(x["m"]) <= set(map(tuple, maybe))
+
+
+def test_single_pass_statistics_equal_the_running_maximum_passes(monkeypatch):
+    """Batches of >= 8 pairs take both soft-max statistics from ONE evaluation of S with a per-pair exponent offset
+    (k_sim_single / k_sim_finish / k_sim_cand3); MSF_LOFTR_SIM_SINGLE=0 keeps the two running-maximum passes.  The
+    confidences of the debug pair must agree to 1e-5 (a hundredth of the tolerance), the lists wherever no confidence
+    is that close to the threshold -- textured pairs, the KATs, a frame against itself -- on the sparse and the dense
+    head; and a batch whose every pair is flagged for the fallback (MSF_LOFTR_SIM_FORCE_REDO=1: what a pair with
+    logits outside the offset's range takes) must give the running-maximum lists exactly."""
+    n = 12
+    A, B = synth.synth_batch(7300, n, 640, 480, mode=1)
+    A[3], B[3] = G["img0_ii"], G["img1_ii"]
+    A[5], B[5] = G["img0_i"], G["img1_i"]
+    B[7] = A[7]
+    fa, fb = list(A), list(B)
+    one = _dm(0.15, pairs=n)
+    monkeypatch.setenv("MSF_LOFTR_SIM_SINGLE", "0")
+    two = _dm(0.15, pairs=n)
+    monkeypatch.delenv("MSF_LOFTR_SIM_SINGLE")
+    monkeypatch.setenv("MSF_LOFTR_SIM_FORCE_REDO", "1")
+    redo = _dm(0.15, pairs=n)
+    monkeypatch.delenv("MSF_LOFTR_SIM_FORCE_REDO")
+    total = 0
+    for thr in (0.15, 0.05, 0.3, 0.02):
+        for m in (one, two, redo):
+            m.SetThreshold(thr)
+        l1 = one.match_batch(fa, fb, cap=8192)
+        c1 = one.conf_matrix()
+        l2 = two.match_batch(fa, fb, cap=8192)
+        c2 = two.conf_matrix()
+        l3 = redo.match_batch(fa, fb, cap=8192)
+        assert np.abs(c1 - c2).max() <= 1e-5
+        for k in range(n):
+            np.testing.assert_array_equal(l2[k], l3[k])
+            total += len(l2[k])
+        # pair 0: the lists may differ only at confidences within 1e-5 of the threshold
+        s1, s2 = set(map(tuple, l1[0])), set(map(tuple, l2[0]))
+        near = int((np.abs(c2 - thr) <= 1e-5).sum())
+        assert len(s1 ^ s2) <= near
+        differing = sum(1 for k in range(n) if len(l1[k]) != len(l2[k]) or not np.array_equal(l1[k], l2[k]))
+        assert differing <= 1, differing
+    assert total > 3000

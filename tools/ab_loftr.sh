@@ -1,0 +1,14 @@
+#!/bin/bash
+# A/B of LoFTR bench variants on the GPU box: tools/ab_loftr.sh "NAME1:ENV=VAL ENV2=VAL" "NAME2:..." ...
+R=${GRAFT_REPO_ROOT:-/root/repo}
+ARGS=${AB_ARGS:---matcher loftr --steps 10 --warmup 3 --no-secondary --no-cpu-baseline}
+for spec in "$@"; do
+  name=${spec%%:*}; envs=${spec#*:}
+  out=$R/gpurun_out/abl_$name.json
+  env $envs timeout -k 10 240 python3 $R/bench.py $ARGS > $out 2> $R/gpurun_out/abl_$name.err || { echo "$name FAILED"; tail -3 $R/gpurun_out/abl_$name.err; continue; }
+  python3 - "$name" "$out" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[2]).read())
+print("%-14s %9.0f pairs/s %7.3f ms  %s" % (sys.argv[1], d["value"], d["ms_per_step"], d["roofline"].get("stage_ms")))
+PY
+done
