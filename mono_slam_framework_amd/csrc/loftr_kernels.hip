@@ -2738,13 +2738,28 @@ __global__ __launch_bounds__(256, 2) void k_block16(const float* __restrict__ in
 }
 
 // ------------------------------------------------------------------ tokens: + positional encoding, n c h w -> n (h w) c
+// PE add + 'n c h w -> n (hw) c' as a tiled transpose: a workgroup takes 32 channels x 64 tokens of one image, reads each
+// channel's 64 tokens as one 256-byte segment, and writes the 64 tokens' 32 channels as one contiguous 8-KB run (the
+// element-per-thread form read with a 4 800-byte stride between neighbouring lanes: 42 us per 256 images at 1.9 TB/s)
+constexpr int kTokTile = 64;
 __global__ __launch_bounds__(256) void k_tokens(const float* __restrict__ bb, const float* __restrict__ pe,
                                                 float* __restrict__ tok, int n_img) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= n_img * NTOK * DM) return;
-  const int img = idx / (NTOK * DM), rem = idx % (NTOK * DM);
-  const int t = rem / DM, c = rem % DM;
-  tok[idx] = bb[((long long)img * DM + c) * NTOK + t] + pe[c * NTOK + t];
+  __shared__ float tile[DM][kTokTile + 1];
+  const int img = blockIdx.y, t0 = blockIdx.x * kTokTile, tid = threadIdx.x;
+  if (img >= n_img) return;
+  const float* src = bb + (long long)img * DM * NTOK;
+#pragma unroll
+  for (int k = 0; k < DM * kTokTile / 256; k++) {
+    const int e = k * 256 + tid, c = e / kTokTile, t = e - c * kTokTile;
+    if (t0 + t < NTOK) tile[c][t] = src[(long long)c * NTOK + t0 + t] + pe[c * NTOK + t0 + t];
+  }
+  __syncthreads();
+  float* dst = tok + ((long long)img * NTOK + t0) * DM;
+#pragma unroll
+  for (int k = 0; k < DM * kTokTile / 256; k++) {
+    const int e = k * 256 + tid, t = e / DM, c = e - t * DM;
+    if (t0 + t < NTOK) dst[e] = tile[c][t];
+  }
 }
 
 // ------------------------------------------------------------------ linear-attention encoder block (MFMA)
@@ -3083,35 +3098,49 @@ __global__ __launch_bounds__(64 * kKvWaves) void k_attn_kv_x(const float* __rest
 
 __global__ __launch_bounds__(256) void k_attn_update_x(const float* __restrict__ xsrc, long long x_stride,
                                                        const float* __restrict__ kv, BlockW w, float* __restrict__ dst,
-                                                       long long d_stride) {
+                                                       long long d_stride, int n_items, int items_per_wg,
+                                                       float* __restrict__ fs_out, __bf16* __restrict__ pl_out) {
   // fragments: [mtile][K group][hi | lo][lane]
   __shared__ bf16x8 sWq[2 * 2 * 64], sKV[2 * 2 * 64], sWm[2 * 2 * 64], sW0[4 * 2 * 2 * 64], sW1[2 * 2 * 2 * 64];
   __shared__ float sLN[4 * DM], sKs[DM];
-  const int seq = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tl = lane & 15, g = lane >> 4;
-  const float* kvp = kv + (long long)seq * (DM * DM + DM);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tl = lane & 15, g = lane >> 4;
+  // The block's weights (32 KB of fragments) are the same for every sequence: a workgroup stages them once and then walks
+  // a contiguous run of (sequence, group of 8 token tiles) items, re-staging only the sequence's KV when it changes.
+  // Runs longer than one item did not pay (see Impl::upd_wgs): the other workgroups of a CU cover a prologue better than
+  // a serial run of items amortises it.
   for (int i = tid; i < 2 * 2 * 64; i += 256) {
     sWq[i] = reinterpret_cast<const bf16x8*>(w.wq_x)[i];
     sWm[i] = reinterpret_cast<const bf16x8*>(w.wm_x)[i];
   }
   for (int i = tid; i < 4 * 2 * 2 * 64; i += 256) sW0[i] = reinterpret_cast<const bf16x8*>(w.w0_x)[i];
   for (int i = tid; i < 2 * 2 * 2 * 64; i += 256) sW1[i] = reinterpret_cast<const bf16x8*>(w.w1_x)[i];
-  if (tid < 128) {                                 // this sequence's KV (f32, [(m * 8 + slot) * 64 + lane]) -> fragments
-    const int m = tid >> 6, ln = tid & 63;
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) v[j] = kvp[(m * 8 + j) * 64 + ln];
-    bf16x8 hi, lo;
-    split8(v, hi, lo);
-    sKV[(m * 2 + 0) * 64 + ln] = hi;
-    sKV[(m * 2 + 1) * 64 + ln] = lo;
-  }
   if (tid < DM) {
     sLN[tid] = w.n1w[tid]; sLN[DM + tid] = w.n1b[tid]; sLN[2 * DM + tid] = w.n2w[tid]; sLN[3 * DM + tid] = w.n2b[tid];
-    sKs[tid] = kvp[DM * DM + tid];
   }
-  __syncthreads();
+  constexpr int kUpdBlocks = (NTOK / 16 + 4 * kUpdTilesPerWave - 1) / (4 * kUpdTilesPerWave);
+  const int item_lo = blockIdx.x * items_per_wg, item_hi = min(item_lo + items_per_wg, n_items);
+  int cur_seq = -1;
+  for (int item = item_lo; item < item_hi; item++) {
+  const int seq = item / kUpdBlocks, xblk = item - seq * kUpdBlocks;
+  if (seq != cur_seq) {                            // uniform over the workgroup
+    cur_seq = seq;
+    __syncthreads();                               // every wave is done with the previous sequence's KV
+    const float* kvp = kv + (long long)seq * (DM * DM + DM);
+    if (tid < 128) {                               // this sequence's KV (f32, [(m * 8 + slot) * 64 + lane]) -> fragments
+      const int m = tid >> 6, ln = tid & 63;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) v[j] = kvp[(m * 8 + j) * 64 + ln];
+      bf16x8 hi, lo;
+      split8(v, hi, lo);
+      sKV[(m * 2 + 0) * 64 + ln] = hi;
+      sKV[(m * 2 + 1) * 64 + ln] = lo;
+    }
+    if (tid < DM) sKs[tid] = kvp[DM * DM + tid];
+    __syncthreads();
+  }
   for (int it = 0; it < kUpdTilesPerWave; it++) {
-    const int tile = (blockIdx.x * kUpdTilesPerWave + it) * 4 + wave;
+    const int tile = (xblk * kUpdTilesPerWave + it) * 4 + wave;
     if (tile >= NTOK / 16) break;
     const float* xr = xsrc + (long long)seq * x_stride + (long long)(tile * 16 + tl) * DM;
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(xr + 8 * g), b1 = *reinterpret_cast<const f32x4*>(xr + 8 * g + 4);
@@ -3173,8 +3202,40 @@ __global__ __launch_bounds__(256) void k_attn_update_x(const float* __restrict__
     }
     layer_norm_cols(o, sLN + 2 * DM, sLN + 3 * DM, g);
     float* dr = dst + (long long)seq * d_stride + (long long)(tile * 16 + tl) * DM;
-    *reinterpret_cast<f32x4*>(dr + 4 * g) = xd0 + o[0];
-    *reinterpret_cast<f32x4*>(dr + 16 + 4 * g) = xd1 + o[1];
+    const f32x4 r0 = xd0 + o[0], r1 = xd1 + o[1];
+    *reinterpret_cast<f32x4*>(dr + 4 * g) = r0;
+    *reinterpret_cast<f32x4*>(dr + 16 + 4 * g) = r1;
+    if (fs_out) {
+      // the last block of a side: the matching head's inputs leave here as well (what k_scale_feats makes of dst: the
+      // features / sqrt(32) and their three bf16 planes, the same expressions on the same values)
+      const long long e0 = (long long)(tile * 16 + tl) * DM;
+      float* fr = fs_out + (long long)seq * d_stride + e0;
+      __bf16* pr = pl_out + (long long)seq * 3 * d_stride + e0;
+      const float rv[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+      float sv[8];
+      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+      bf16x4_t ph[2], pm[2], pl[2];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const float v = rv[q] / 5.656854f;
+        sv[q] = v;
+        const __bf16 h = (__bf16)v;
+        const float e1 = v - (float)h;
+        const __bf16 m = (__bf16)e1;
+        const __bf16 l = (__bf16)(e1 - (float)m);
+        ph[q >> 2][q & 3] = h; pm[q >> 2][q & 3] = m; pl[q >> 2][q & 3] = l;
+      }
+      *reinterpret_cast<f32x4*>(fr + 4 * g) = f32x4{sv[0], sv[1], sv[2], sv[3]};
+      *reinterpret_cast<f32x4*>(fr + 16 + 4 * g) = f32x4{sv[4], sv[5], sv[6], sv[7]};
+#pragma unroll
+      for (int hf = 0; hf < 2; hf++) {
+        const int c = hf * 16 + 4 * g;
+        *reinterpret_cast<bf16x4_t*>(pr + c) = ph[hf];
+        *reinterpret_cast<bf16x4_t*>(pr + d_stride + c) = pm[hf];
+        *reinterpret_cast<bf16x4_t*>(pr + 2 * d_stride + c) = pl[hf];
+      }
+    }
+  }
   }
 }
 
@@ -3567,8 +3628,14 @@ __global__ __launch_bounds__(64 * kSimItemWaves) void k_sim_single(const __bf16*
       }
     }
     // this lane's column jt * 16 + tl over the 12 rows it holds; the other three lane groups hold the other rows
-    col += __shfl_xor(col, 16);
-    col += __shfl_xor(col, 32);
+    // (v_permlane16/32_swap: the cross-row sums stay in the VALU; as shuffles they are two LDS round trips per column
+    // tile in the wave's critical path)
+    {
+      const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(col), __float_as_uint(col), false, false);
+      col = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);               // lanes l and l ^ 16
+      const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(col), __float_as_uint(col), false, false);
+      col = __uint_as_float(r32[0]) + __uint_as_float(r32[1]);               // ... and l ^ 32: all four lane groups
+    }
     if (g == 0) cp[jt * 16 + tl] = col;
   }
   float* rp = rpart + ((long long)pair * kSimColParts + zpart) * NTOK;
@@ -3901,6 +3968,9 @@ struct LoftrPipeline::Impl {
   float* cpart = nullptr;    // [max_pairs][25][1200] column-sum partials
   float* rpart = nullptr;    // [max_pairs][3][1200] row-sum partials (one per third of the columns)
   uint32_t* sim_redo = nullptr;   // [max_pairs] pairs whose single-pass sums left the f32 range
+  int upd_wgs = 1 << 30;     // MSF_LOFTR_UPD_WGS: at most this many workgroups of k_attn_update_x, each walking a run of items with
+                             // the block's weights staged once.  Default: one item per workgroup -- 1 024 / 2 048 workgroups (one / two
+                             // rounds of the chip, 5 / 3 items each) measured 0.54 / 0.52 ms for the 8 blocks against 0.49
   bool sim_single = true;    // MSF_LOFTR_SIM_SINGLE=0: the two running-maximum passes always
   bool sim_force_redo = false;    // MSF_LOFTR_SIM_FORCE_REDO=1 (tests): every pair takes the fallback
   bool dense_head = false;
@@ -3961,6 +4031,7 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
   {
     if (const char* d = getenv("MSF_LOFTR_DENSE_HEAD")) P.dense_head = atoi(d) != 0;   // tests: force the dense head
     if (const char* d = getenv("MSF_LOFTR_SIM_SINGLE")) P.sim_single = atoi(d) != 0;
+    if (const char* d = getenv("MSF_LOFTR_UPD_WGS")) { const int v = atoi(d); if (v >= 1) P.upd_wgs = v; }
     if (const char* d = getenv("MSF_LOFTR_SIM_FORCE_REDO")) P.sim_force_redo = atoi(d) != 0;
     if (const char* d = getenv("MSF_LOFTR_UNFUSED")) P.fuse_blocks = atoi(d) == 0;
     P.split_bf16 = !f32_convs;
@@ -4669,8 +4740,9 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
   }
   keep(3, a, 32u * 30 * 40);
   launch_conv<32, 32, 1, 1, 16, false, false, false>(c[20], a, s40, 0, nullptr, b, ni, st);      // b = 245
-  if (nA) hipLaunchKernelGGL(k_tokens, dim3((nA * NTOK * DM + 255) / 256), dim3(256), 0, st, b, P.d_pe, tokA, nA);
-  if (nB) hipLaunchKernelGGL(k_tokens, dim3((nB * NTOK * DM + 255) / 256), dim3(256), 0, st, b + (long long)nA * 32LL * 30 * 40, P.d_pe, tokB, nB);
+  const int tok_tiles = (NTOK + kTokTile - 1) / kTokTile;
+  if (nA) hipLaunchKernelGGL(k_tokens, dim3(tok_tiles, nA), dim3(256), 0, st, b, P.d_pe, tokA, nA);
+  if (nB) hipLaunchKernelGGL(k_tokens, dim3(tok_tiles, nB), dim3(256), 0, st, b + (long long)nA * 32LL * 30 * 40, P.d_pe, tokB, nB);
 }
 
 }  // namespace
@@ -4689,7 +4761,15 @@ hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf
   for (int bi = 0; bi < 8; bi++) {
     if (P.split_bf16) hipLaunchKernelGGL(k_attn_kv_x, dim3(n), dim3(64 * kKvWaves), 0, st, seq[bi].s, ts, P.blk[bi], P.kv);
     else hipLaunchKernelGGL(k_attn_kv, dim3(n), dim3(64 * kKvWaves), 0, st, seq[bi].s, ts, P.blk[bi], P.kv);
-    if (P.split_bf16) hipLaunchKernelGGL(k_attn_update_x, dim3(upd_blocks, n), dim3(256), 0, st, seq[bi].x, ts, P.kv, P.blk[bi], seq[bi].o, ts);
+    if (P.split_bf16) {
+      const int n_items = n * upd_blocks;
+      const int per_wg = (n_items + P.upd_wgs - 1) / P.upd_wgs;
+      // blocks 6 and 7 write the final f0 and f1: they also write the head's scaled features and bf16 planes
+      float* fs_o = bi == 6 ? P.fsc : bi == 7 ? P.fsc + (long long)P.max_pairs * ts : nullptr;
+      __bf16* pl_o = bi == 6 ? P.fsp : bi == 7 ? P.fsp + (long long)P.max_pairs * 3 * ts : nullptr;
+      hipLaunchKernelGGL(k_attn_update_x, dim3((n_items + per_wg - 1) / per_wg), dim3(256), 0, st, seq[bi].x, ts, P.kv, P.blk[bi],
+                         seq[bi].o, ts, n_items, per_wg, fs_o, pl_o);
+    }
     else hipLaunchKernelGGL(k_attn_update, dim3(upd_blocks, n), dim3(256), 0, st, seq[bi].x, ts, P.kv, P.blk[bi], seq[bi].o, ts);
   }
   if (ev) hipEventRecord(ev[2], st);
@@ -4698,8 +4778,10 @@ hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf
   float* f1s = P.fsc + (long long)P.max_pairs * ts;
   __bf16* p0 = P.split_bf16 ? P.fsp : nullptr;      // split path: the scaled features also as three bf16 planes
   __bf16* p1 = P.split_bf16 ? P.fsp + (long long)P.max_pairs * 3 * ts : nullptr;
-  hipLaunchKernelGGL(k_scale_feats, dim3((unsigned)((n * ts + 255) / 256)), dim3(256), 0, st, f0, f0s, n * ts, p0, ts);
-  hipLaunchKernelGGL(k_scale_feats, dim3((unsigned)((n * ts + 255) / 256)), dim3(256), 0, st, f1, f1s, n * ts, p1, ts);
+  if (!P.split_bf16) {      // (the split path's last two attention blocks wrote f0s / f1s and the planes themselves)
+    hipLaunchKernelGGL(k_scale_feats, dim3((unsigned)((n * ts + 255) / 256)), dim3(256), 0, st, f0, f0s, n * ts, p0, ts);
+    hipLaunchKernelGGL(k_scale_feats, dim3((unsigned)((n * ts + 255) / 256)), dim3(256), 0, st, f1, f1s, n * ts, p1, ts);
+  }
   const int head_blocks = (NTOK / 16 + 3) / 4;
   const dim3 grid3((NTOK / 16 / kSimRT + kSimWaves - 1) / kSimWaves, n), block3(64 * kSimWaves);
   // a call of a few pairs is latency-bound: one row tile per wave (75 waves per pair) instead of three (25)

@@ -520,6 +520,9 @@ constexpr int RK = 16;                   // ring rows (power of two)
 #ifndef MSF_ABL_DESCRIBE
 #define MSF_ABL_DESCRIBE 0       // timing-only ablations of k_describe (1: patches from the L2, 2: no descriptor tests)
 #endif
+#ifndef MSF_WALK_REPS
+#define MSF_WALK_REPS 1          // strips per walker workgroup
+#endif
 #ifndef MSF_WALK_NOBRANCH
 #define MSF_WALK_NOBRANCH 0
 #endif
@@ -581,17 +584,17 @@ __device__ __forceinline__ int stream_score(const uint8_t* ring, uint32_t r0, ui
 // strips, then the rest, so the lines neighbouring strips share stay in one L2 and a frame's quarter is long done when
 // its other strips start.  dyn = 0: no refinement (forced threshold, MSF_ORB_FAST_ONE_PART).  part = -1: all strips;
 // 0 / 1: only the sampled quarter / only the rest (small launches, whose strips would all start together, run as two).
+// one strip: unit u of XCD xcd in the launch's order
 template <bool RESIZE>
-__global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_t* pyr, const uint32_t* __restrict__ tab,
-                                             uint32_t* tau, uint32_t* qstat, uint32_t* cand_cnt, uint32_t* cand_key,
-                                             uint8_t* cand_sc, float* cand_resp, int l_lo, int l_hi, int n_frames,
-                                             int margin_pct, int dyn, int part, int harris) {
-  __shared__ StreamSmem sm;
+__device__ __forceinline__ void walk_unit(StreamSmem& sm, const OrbGeometry& g, const FrameSrc& src, uint8_t* pyr,
+                                          const uint32_t* __restrict__ tab, uint32_t* tau, uint32_t* qstat,
+                                          uint32_t* cand_cnt, uint32_t* cand_key, uint8_t* cand_sc, float* cand_resp,
+                                          int l_lo, int l_hi, int n_frames, int margin_pct, int dyn, int part, int harris,
+                                          const int xcd, const int u) {
   const int lane = threadIdx.x;
   int fi, t;
   bool quarter;
   {
-    const int xcd = (int)(blockIdx.x & 7u), u = (int)(blockIdx.x >> 3);
     const int nf8 = n_frames >> 3, nrem = n_frames & 7;
     const int nfx = nf8 + (xcd < nrem ? 1 : 0), f0 = xcd * nf8 + (xcd < nrem ? xcd : nrem);
     const int S = g.lv[l_hi].wk_base + g.lv[l_hi].wk_nx * g.lv[l_hi].wk_ny - g.lv[l_lo].wk_base;
@@ -1159,6 +1162,22 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
     // every histogram add of this strip is complete before the strip counts as done (agent-scope atomics both sides)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) atomicAdd(&qs[kTauBins], 1u);
+  }
+}
+
+// A workgroup (one wave) walks MSF_WALK_REPS consecutive units of its XCD.
+template <bool RESIZE>
+__global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_t* pyr, const uint32_t* __restrict__ tab,
+                                             uint32_t* tau, uint32_t* qstat, uint32_t* cand_cnt, uint32_t* cand_key,
+                                             uint8_t* cand_sc, float* cand_resp, int l_lo, int l_hi, int n_frames,
+                                             int margin_pct, int dyn, int part, int harris) {
+  __shared__ StreamSmem sm;
+  const int xcd = (int)(blockIdx.x & 7u), v = (int)(blockIdx.x >> 3);
+#pragma unroll 1
+  for (int rep = 0; rep < MSF_WALK_REPS; rep++) {
+    walk_unit<RESIZE>(sm, g, src, pyr, tab, tau, qstat, cand_cnt, cand_key, cand_sc, cand_resp, l_lo, l_hi, n_frames, margin_pct,
+                      dyn, part, harris, xcd, v * MSF_WALK_REPS + rep);
+    MSF_WAVE_SYNC();
   }
 }
 
@@ -2603,11 +2622,12 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
     const bool two = dyn && Sr > 0 && (long long)nf * Sq < walk_round_;
     for (int part = two ? 0 : -1; part <= (two ? 1 : -1); part++) {
       const unsigned units = part < 0 ? (unsigned)S : part == 0 ? (unsigned)Sq : (unsigned)Sr;
+      const unsigned wgs = 8u * (((f8 / 8u) * units + MSF_WALK_REPS - 1) / MSF_WALK_REPS);
       if (resize)
-        hipLaunchKernelGGL(k_walk<true>, dim3(f8 * units), dim3(64), 0, s_, g, fs, d_pyr_, d_tab_, tau, d_qstat_, d_cand_cnt_,
+        hipLaunchKernelGGL(k_walk<true>, dim3(wgs), dim3(64), 0, s_, g, fs, d_pyr_, d_tab_, tau, d_qstat_, d_cand_cnt_,
                            d_cand_, d_cand_sc_, d_cand_resp_, l_lo, l_hi, nf, tau2_margin_pct_, dyn, part, walker_harris_);
       else
-        hipLaunchKernelGGL(k_walk<false>, dim3(f8 * units), dim3(64), 0, s_, g, fs, d_pyr_, d_tab_, tau, d_qstat_, d_cand_cnt_,
+        hipLaunchKernelGGL(k_walk<false>, dim3(wgs), dim3(64), 0, s_, g, fs, d_pyr_, d_tab_, tau, d_qstat_, d_cand_cnt_,
                            d_cand_, d_cand_sc_, d_cand_resp_, l_lo, l_hi, nf, tau2_margin_pct_, dyn, part, walker_harris_);
     }
   };
