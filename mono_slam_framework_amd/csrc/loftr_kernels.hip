@@ -1200,7 +1200,16 @@ struct DownW {
   const float *b1, *bsc, *b2;
 };
 
-__global__ __launch_bounds__(64 * down16::WAVES) void k_down16x(const float* __restrict__ in, DownW dw, float* __restrict__ out,
+#ifndef MSF_LOFTR_DOWN16_WPE
+#define MSF_LOFTR_DOWN16_WPE 4     // k_down16x capped at 128 registers (10 spilled, 44 B of scratch): two workgroups fit a CU
+                                   // (66 KB of LDS each) instead of one at 164 registers; 584 -> 541 us per 512 images.  0 = uncapped
+#endif
+#if MSF_LOFTR_DOWN16_WPE
+#define MSF_DOWN16_ATTR __attribute__((amdgpu_waves_per_eu(MSF_LOFTR_DOWN16_WPE, MSF_LOFTR_DOWN16_WPE)))
+#else
+#define MSF_DOWN16_ATTR
+#endif
+__global__ __launch_bounds__(64 * down16::WAVES) MSF_DOWN16_ATTR void k_down16x(const float* __restrict__ in, DownW dw, float* __restrict__ out,
                                                                 int H, int W, int n_strips) {
   using namespace down16;
   extern __shared__ __attribute__((aligned(16))) float lds[];

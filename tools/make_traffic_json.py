@@ -22,7 +22,9 @@ STAGE = {"k_resize": "pyramid", "k_fast": "fast_nms", "k_fast_tau": "pyramid_fas
          "k_strip8x": "backbone_convs", "k_stem_strip8x": "backbone_convs", "k_convx2": "backbone_convs", "k_strip16x": "backbone_convs", "k_strip32x": "backbone_convs",
          "k_down32x": "backbone_convs",
          "k_attn_kv": "transformer", "k_attn_update": "transformer", "k_attn_kv_x": "transformer",
-         "k_attn_update_x": "transformer", "k_scale_feats": "match_head",
+         "k_attn_update_x": "transformer", "k_scale_feats": "match_head", "k_harris_flat": "select_harris",
+         "k_pair_bound": "match_head", "k_sim_single": "match_head", "k_sim_finish": "match_head",
+         "k_sim_cand3": "match_head", "k_conf_cand": "match_head", "k_row_limits": "match_head",
          "k_sim_stats": "match_head", "k_sim_stats3": "match_head", "k_conf_mask": "match_head", "k_decode": "match_head"}
 
 
