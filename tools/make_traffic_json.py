@@ -34,6 +34,13 @@ def load(d, steps):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0].split("<")[0].replace("msf::", "").replace("void ", "")
+            if k.startswith("_ZN3msf"):          # a name rocprofv3 left mangled: _ZN3msf<len><identifier>...
+                digits = ""
+                rest = k[len("_ZN3msf"):]
+                while rest and rest[0].isdigit():
+                    digits, rest = digits + rest[0], rest[1:]
+                if digits:
+                    k = rest[:int(digits)]
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"]) / steps
     return acc
 
