@@ -735,9 +735,9 @@ __device__ __forceinline__ void walk_unit(StreamSmem& sm, const OrbGeometry& g, 
     const uint4* xsel = reinterpret_cast<const uint4*>(tab + Ld.tab_off);
     const uint4* xwxp = xsel + groups;
     const uint4* xoff = xwxp + groups;
-    const uint32_t* xstrip = tab + Ld.tab_xstrip;
     const uint32_t* yemit = tab + Ld.tab_yemit;
-    const int g_first = (int)xstrip[sx], g_end = (int)xstrip[sx + 1];
+    // straight from the kernel arguments (indexing the local copy Ld would put it in scratch memory)
+    const int g_first = g.lv[l + 1].wk_xg[sx], g_end = g.lv[l + 1].wk_xg[sx + 1];   // (host-checked: wk_nx <= kWkMaxNx if fused)
     const int gq = min(g_first + lane, groups - 1);
     rz_lane = g_first + lane < g_end;
     const uint4 qsv = xsel[gq], qwv = xwxp[gq], qov = xoff[gq];
@@ -2272,6 +2272,7 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   // k_thr_harris only ranks (default 0: k_thr_harris computes the responses of the kept candidates from the pyramid)
   if (const char* e = getenv("MSF_ORB_WALKER_HARRIS")) walker_harris_ = atoi(e);
   if (const char* e = getenv("MSF_ORB_HARRIS_FLAT")) harris_flat_ = atoi(e);
+  if (const char* e = getenv("MSF_ORB_DESC_BX")) { const int v = atoi(e); if (v >= 1 && v <= 128) desc_bx_min_ = v; }
   // MSF_ORB_TAU_PREDICT: percent of the needed corner density the prediction of a level's first threshold from the level
   // above keeps (0 = sample every level, the r02 behaviour)
   if (const char* e = getenv("MSF_ORB_TAU_PREDICT")) {
@@ -2459,6 +2460,8 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     for (int c = 0; c < Ls.wk_nx; c++)
       if (xstrip[c + 1] < xstrip[c] || xstrip[c + 1] - xstrip[c] > 64u) fused = false;
     if (xstrip[0] != 0u) fused = false;
+    if (Ls.wk_nx > kWkMaxNx) fused = false;
+    for (int c = 0; c <= kWkMaxNx; c++) g.lv[l].wk_xg[c] = (int)xstrip[c < Ls.wk_nx ? c : Ls.wk_nx];
     g.lv[l].wk_fused = fused ? 1 : 0;
   }
   const size_t S = (size_t)max_slots;
@@ -2752,7 +2755,7 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
     // 4 key points per workgroup pass: 8 workgroups per frame keep a big batch busy; a single pair (the drop-in call)
     // gets up to 128 so that its ~500 key points per frame are one pass instead of sixteen
     int bx = 2048 / n;
-    bx = bx < 8 ? 8 : bx > 128 ? 128 : bx;
+    bx = bx < desc_bx_min_ ? desc_bx_min_ : bx > 128 ? 128 : bx;
     auto kd = blur_sum256_ ? k_describe<true, true> : half_up_ ? k_describe<true, false> : k_describe<false, false>;
     hipLaunchKernelGGL(kd, dim3(bx, n), dim3(256), 0, st, g, src, d_pyr_, d_kp_, d_kp_cnt_, d_desc_);
   }

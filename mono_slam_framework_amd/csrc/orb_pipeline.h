@@ -20,6 +20,7 @@ constexpr int kKpCap = 2048;       // keypoints per frame (cv::ORB nfeatures = 5
 constexpr int kOrbStages = 6;
 constexpr int kS1Cap = 8192;       // per level: keypoints kept by retainBest(2N) on the FAST score (+ ties)
 
+constexpr int kWkMaxNx = 17;   // walker strips across a level (4096 px)
 struct OrbLevelInfo {
   int w, h, pitch;     // level size, row pitch in bytes (multiple of 16)
   int quota;           // nfeaturesPerLevel
@@ -34,6 +35,8 @@ struct OrbLevelInfo {
   int wk_fused;        // this level (as the DESTINATION of a resize) can be made by the walker of level l - 1
   int tab_yemit;       // offset (entries) of the per-source-row emit table of the resize INTO this level
   int tab_xstrip;      // offset (entries) of the first output group of each walker strip of level l - 1
+  int wk_xg[kWkMaxNx + 1];   // the same numbers inside the kernel arguments (a scalar load instead of a dependent memory
+                             // round trip in front of the strip's table loads); more strips than kWkMaxNx: not fused
   int tab_off;         // offset (entries) of this level's resize tables
   int samp_sx, samp_sy, samp_rows, samp_cols;   // k_fast_tau's sample lattice over [31, w-31) x [31, h-31); rows 0 = none
   long long pix_off;   // byte offset of this level inside a slot's pyramid blob (levels >= 1)
@@ -110,6 +113,7 @@ class OrbPipeline {
   uint32_t* d_cand_ = nullptr;     // [slots][cand_total] key = y << 16 | x
   uint8_t* d_cand_sc_ = nullptr;   // [slots][cand_total] FAST score
   float* d_cand_resp_ = nullptr;   // [slots][levels][kRespCap] Harris response of the walker's candidates
+  int desc_bx_min_ = 8;            // MSF_ORB_DESC_BX: k_describe workgroups per frame in a big batch (4 waves each)
   int harris_flat_ = 1;            // MSF_ORB_HARRIS_FLAT=0: Harris responses inside k_thr_harris (one wave per (frame, level))
   int walker_harris_ = 0;          // MSF_ORB_WALKER_HARRIS (opt-in: less HBM traffic, more walker time)
   uint32_t* d_s1_cnt_ = nullptr;   // [slots][8]
