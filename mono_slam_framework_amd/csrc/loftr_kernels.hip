@@ -3540,7 +3540,10 @@ __global__ __launch_bounds__(64 * kSimWaves) void k_sim_stats3(const __bf16* __r
 // owns three row tiles over a third of the column tiles, leaves its row sums in rpart[pair][third][1200] and its column
 // partials in cpart[pair][triple 0..24][1200]; k_sim_finish adds the 3 and the 25 in order.  Deterministic, no atomics.
 constexpr int kSimParts = NTOK / 16 / kSimRT;         // 25 row-tile triples per pair
-constexpr int kSimColParts = 3;                       // column thirds (blockIdx.z)
+#ifndef MSF_LOFTR_SIM_COLPARTS
+#define MSF_LOFTR_SIM_COLPARTS 3
+#endif
+constexpr int kSimColParts = MSF_LOFTR_SIM_COLPARTS;  // an item covers 1 / kSimColParts of the column tiles (1, 3, 5 measured)
 constexpr int kSimColTiles = NTOK / 16 / kSimColParts;
 static_assert(kSimColTiles * kSimColParts == NTOK / 16, "column thirds");
 // Work items (pair, column third, row-tile triple), the triple running fastest, four per workgroup: a workgroup of FIVE
@@ -3678,8 +3681,9 @@ __global__ __launch_bounds__(256) void k_sim_finish(const float* __restrict__ gb
   cs[i] = G;
   cs[NTOK + i] = c;
   const float* rp = rpart + (long long)pair * kSimColParts * NTOK + i;
-  const float r = (rp[0] + rp[NTOK]) + rp[2 * NTOK];
-  static_assert(kSimColParts == 3, "row partials");
+  float r = rp[0];
+#pragma unroll
+  for (int z = 1; z < kSimColParts; z++) r += rp[(long long)z * NTOK];
   float* rsx = rstats + (long long)pair * stats_stride;
   rsx[i] = G;
   rsx[NTOK + i] = r;
