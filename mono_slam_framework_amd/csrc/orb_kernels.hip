@@ -527,7 +527,9 @@ constexpr int RK = 16;                   // ring rows (power of two)
 #define MSF_WALK_NOBRANCH 0
 #endif
 #ifndef MSF_WALK_PREFETCH8
-#define MSF_WALK_PREFETCH8 1
+#define MSF_WALK_PREFETCH8 0     // 1: a second row queue (loads requested eight rows ahead).  Measured the same as four; with the
+                                 // ring-phase copies of the group body the compiler copies the queues at the common flush site
+                                 // behind a vmcnt wait, so the effective distance is one group either way
 #endif
 constexpr int kWkMaxPx = 244;            // strip pitch <= 244: a group of 4 output px reads two aligned 8-byte pairs <= 8 B apart
 constexpr int kWkMaxRows = 112;          // owned rows per strip at most (a strip's emit table lives in two registers per lane);
