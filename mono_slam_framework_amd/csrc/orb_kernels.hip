@@ -1613,7 +1613,15 @@ struct HarrisUnits {
   int base[kOrbLevels + 1];    // first unit of level l; base[nlevels] = units per frame
   int n[kOrbLevels];
 };
-__global__ __launch_bounds__(256) void k_harris_flat(OrbGeometry g, FrameSrc src, const uint8_t* pyr, HarrisUnits hw,
+#ifndef MSF_HARRIS_FLAT_WPE
+#define MSF_HARRIS_FLAT_WPE 0      // > 0: cap k_harris_flat's registers for this many waves per SIMD (A/B builds)
+#endif
+#if MSF_HARRIS_FLAT_WPE
+#define MSF_HARRIS_FLAT_ATTR __attribute__((amdgpu_waves_per_eu(MSF_HARRIS_FLAT_WPE, MSF_HARRIS_FLAT_WPE)))
+#else
+#define MSF_HARRIS_FLAT_ATTR
+#endif
+__global__ __launch_bounds__(256) MSF_HARRIS_FLAT_ATTR void k_harris_flat(OrbGeometry g, FrameSrc src, const uint8_t* pyr, HarrisUnits hw,
                                                      const uint32_t* __restrict__ s1_cnt, uint4* s1,
                                                      const uint32_t* __restrict__ cand_cnt,
                                                      const uint32_t* __restrict__ tau) {
