@@ -2895,7 +2895,10 @@ __device__ __forceinline__ void layer_norm_cols(f32x4* v, const float* w, const 
 }
 
 // phase B: features on MFMA rows, tokens on columns; one wave carries 16 tokens through the whole block.
-constexpr int kUpdTilesPerWave = 2;
+#ifndef MSF_LOFTR_UPD_TILES
+#define MSF_LOFTR_UPD_TILES 2
+#endif
+constexpr int kUpdTilesPerWave = MSF_LOFTR_UPD_TILES;   // token tiles per wave and workgroup item (1 / 2 / 3 / 5 measured)
 __global__ __launch_bounds__(256) void k_attn_update(const float* __restrict__ xsrc, long long x_stride,
                                                      const float* __restrict__ kv, BlockW w, float* __restrict__ dst,
                                                      long long d_stride) {
