@@ -2282,6 +2282,7 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   // k_thr_harris only ranks (default 0: k_thr_harris computes the responses of the kept candidates from the pyramid)
   if (const char* e = getenv("MSF_ORB_WALKER_HARRIS")) walker_harris_ = atoi(e);
   if (const char* e = getenv("MSF_ORB_HARRIS_FLAT")) harris_flat_ = atoi(e);
+  if (const char* e = getenv("MSF_ORB_CHAIN_MERGE")) { const int v = atoi(e); if (v >= 1) chain_merge_level_ = v; }
   if (const char* e = getenv("MSF_ORB_DESC_BX")) { const int v = atoi(e); if (v >= 1 && v <= 128) desc_bx_min_ = v; }
   // MSF_ORB_TAU_PREDICT: percent of the needed corner density the prediction of a level's first threshold from the level
   // above keeps (0 = sample every level, the r02 behaviour)
@@ -2659,33 +2660,44 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
     // a short latency-bound kernel that leaves the chip nearly idle (8 x 68 us per step when everything is one chain),
     // so a large batch runs as two chains of half the frames on two streams: one half's samplers run beside the other
     // half's walkers.  Both chains lie between the same two stage events.
-    auto chain = [&](const FrameSrc& fs, int nf, int f0, hipStream_t s_) {
+    // step l of a chain: the sampler of level l, then the walker of level l (which makes level l + 1)
+    auto chain_step = [&](int l, const FrameSrc& fs, int nf, int f0, hipStream_t s_) {
       hipLaunchKernelGGL(k_fast_tau, dim3(1, nf), dim3(256), 0, s_, g, fs, d_pyr_, force_tau, tau, tau_first, d_redo_,
-                         d_redo_ + 1, 0, d_qstat_, f0, 0);
-      for (int l = 1; l < g.nlevels; l++) {
-        launch_walk(true, l - 1, l - 1, fs, nf, s_);
-        hipLaunchKernelGGL(k_fast_tau, dim3(1, nf), dim3(256), 0, s_, g, fs, d_pyr_, force_tau, tau, tau_first, d_redo_,
-                           d_redo_ + 1, l, d_qstat_, f0, dyn ? tau_predict_pct_ : 0);
-      }
-      launch_walk(false, g.nlevels - 1, g.nlevels - 1, fs, nf, s_);
+                         d_redo_ + 1, l, d_qstat_, f0, (l > 0 && dyn) ? tau_predict_pct_ : 0);
+      if (l + 1 < g.nlevels) launch_walk(true, l, l, fs, nf, s_);
+      else launch_walk(false, l, l, fs, nf, s_);
+    };
+    auto chain = [&](const FrameSrc& fs, int nf, int f0, hipStream_t s_) {
+      for (int l = 0; l < g.nlevels; l++) chain_step(l, fs, nf, f0, s_);
     };
     // chains_ parts of the batch (default 2; MSF_ORB_CHAINS, MSF_ORB_ONE_CHAIN=1), each at least 128 frames
     int K = (allow_side && tau_stream_ != nullptr) ? chains_ : 1;
     while (K > 1 && n / K < 128) K--;
     if (K > 1) {
+      // the chains are enqueued level by level in turn, so that they start together (chain by chain, the second one's
+      // first kernel waited for the host to enqueue the first chain's sixteen)
       hipEventRecord(tau_ev_[0], st);
-      int f0 = 0;
-      for (int k = 0; k < K; k++) {
+      FrameSrc fsk[kMaxChains];
+      int f0k[kMaxChains], nfk[kMaxChains];
+      hipStream_t sk[kMaxChains];
+      for (int k = 0, f0 = 0; k < K; k++) {
         const int f1 = (int)((long long)n * (k + 1) / K);
-        hipStream_t sk = k == 0 ? st : chain_stream_[k - 1];
-        if (k > 0) hipStreamWaitEvent(sk, tau_ev_[0], 0);
-        chain(k == 0 ? src : sub_src(f0), f1 - f0, f0, sk);
-        if (k > 0) {
-          hipEventRecord(chain_ev_[k - 1], sk);
-          hipStreamWaitEvent(st, chain_ev_[k - 1], 0);
-        }
+        fsk[k] = k == 0 ? src : sub_src(f0);
+        f0k[k] = f0;
+        nfk[k] = f1 - f0;
+        sk[k] = k == 0 ? st : chain_stream_[k - 1];
+        if (k > 0) hipStreamWaitEvent(sk[k], tau_ev_[0], 0);
         f0 = f1;
       }
+      const int l_merge = chain_merge_level_ < g.nlevels ? chain_merge_level_ : g.nlevels;
+      for (int l = 0; l < l_merge; l++)
+        for (int k = 0; k < K; k++) chain_step(l, fsk[k], nfk[k], f0k[k], sk[k]);
+      for (int k = 1; k < K; k++) {
+        hipEventRecord(chain_ev_[k - 1], sk[k]);
+        hipStreamWaitEvent(st, chain_ev_[k - 1], 0);
+      }
+      // MSF_ORB_CHAIN_MERGE=l: from level l on, one chain over all frames (twice the strips per launch on the small levels)
+      for (int l = l_merge; l < g.nlevels; l++) chain_step(l, src, n, 0, st);
     } else {
       chain(src, n, 0, st);
     }

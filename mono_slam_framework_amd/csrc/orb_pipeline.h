@@ -113,6 +113,7 @@ class OrbPipeline {
   uint32_t* d_cand_ = nullptr;     // [slots][cand_total] key = y << 16 | x
   uint8_t* d_cand_sc_ = nullptr;   // [slots][cand_total] FAST score
   float* d_cand_resp_ = nullptr;   // [slots][levels][kRespCap] Harris response of the walker's candidates
+  int chain_merge_level_ = 99;     // MSF_ORB_CHAIN_MERGE: the chains of a fused extraction join before this level
   int desc_bx_min_ = 8;            // MSF_ORB_DESC_BX: k_describe workgroups per frame in a big batch (4 waves each)
   int harris_flat_ = 1;            // MSF_ORB_HARRIS_FLAT=0: Harris responses inside k_thr_harris (one wave per (frame, level))
   int walker_harris_ = 0;          // MSF_ORB_WALKER_HARRIS (opt-in: less HBM traffic, more walker time)
