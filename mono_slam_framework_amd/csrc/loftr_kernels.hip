@@ -26,6 +26,29 @@
 #include <utility>
 #include <vector>
 
+// Load-queue depth of the streaming kernels: steps a row pair's loads are requested ahead of their use.  Each step of the
+// queue is a statically named register set and the step loop is unrolled by the depth, so the depth sets the register
+// count: at 4 k_down16x / k_strip32x needed 164 registers and ran ONE workgroup of eight waves per CU (three waves per
+// SIMD allow twelve); see the defaults' comments for what each kernel measured.
+#ifndef MSF_LOFTR_STRIP8_DEPTH
+#define MSF_LOFTR_STRIP8_DEPTH 3   // k_strip8x: 4 / 3 / 2 steps measured 649 / 641 / 657 us per 512 images (120 / 108 / 96 registers)
+#endif
+#ifndef MSF_LOFTR_STEM_DEPTH
+#define MSF_LOFTR_STEM_DEPTH 4   // k_stem_strip8x: 858 / 867 / 898 us
+#endif
+#ifndef MSF_LOFTR_STRIP16_DEPTH
+#define MSF_LOFTR_STRIP16_DEPTH 2   // k_strip16x: 452 / 435 / 419 us
+#endif
+#ifndef MSF_LOFTR_STRIP32_DEPTH
+#define MSF_LOFTR_STRIP32_DEPTH 2   // k_strip32x: 484 / 492 us at one workgroup per CU (164 / 145 registers); 2 steps + the 128-register cap below: two workgroups, 368-375 us
+#endif
+#ifndef MSF_LOFTR_DOWN32_DEPTH
+#define MSF_LOFTR_DOWN32_DEPTH 4   // k_down32x: 479 / 484 / 505 us (232 / 200 / 164 registers: one workgroup per CU at any depth)
+#endif
+#ifndef MSF_LOFTR_DOWN16_DEPTH
+#define MSF_LOFTR_DOWN16_DEPTH 3   // 110 registers, two workgroups per CU, no spills (4: 164 registers, one workgroup): 584 -> 475 us
+#endif
+
 namespace msf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -921,7 +944,7 @@ __global__ __launch_bounds__(64 * WV) void k_strip8x(const float* __restrict__ i
     __syncthreads();                                                                              \
     if (kLd) {                                                                                    \
       MSF_ST_COMMIT(q_, n_)                                                                       \
-      MSF_ST_ISSUE(q_, (n_) + 4)                                                                  \
+      MSF_ST_ISSUE(q_, (n_) + MSF_LOFTR_STRIP8_DEPTH)                                                                  \
     }                                                                                             \
     const int p_ = (n_) - 2 * cst;                                                                \
     if (p_ >= 0 && p_ <= npairs) stage(p_);                                                       \
@@ -929,21 +952,38 @@ __global__ __launch_bounds__(64 * WV) void k_strip8x(const float* __restrict__ i
     rin += 2 * XP; rin = rin >= RWRAP ? rin - RWRAP : rin;                                        \
     ror += 2 * XP; ror = ror >= RWRAP ? ror - RWRAP : ror;                                        \
   }
-  const int nsteps = (npairs + 2 * NS + 3) & ~3;   // the last stage's last pair is made at step npairs - 1 + 2 NS
+  // the load queue is MSF_LOFTR_STRIP8_DEPTH steps deep (2, 3 or 4), each step's registers named statically; the loop is unrolled by the depth
+  constexpr int kQDepth = MSF_LOFTR_STRIP8_DEPTH;
+  static_assert(kQDepth >= 2 && kQDepth <= 4, "load queue depth");
+  const int nsteps = ((npairs + 2 * NS + kQDepth - 1) / kQDepth) * kQDepth;   // the last stage's last pair is made at step npairs - 1 + 2 NS
   auto run = [&](auto is_loader) {
     constexpr bool kLd = decltype(is_loader)::value;
-    float q0[8], q1[8], q2[8], q3[8];
+    float q0[8]; float q1[8];
+#if MSF_LOFTR_STRIP8_DEPTH >= 3
+    float q2[8];
+#endif
+#if MSF_LOFTR_STRIP8_DEPTH >= 4
+    float q3[8];
+#endif
     if (kLd) {
       MSF_ST_ISSUE(q0, 0)
       MSF_ST_ISSUE(q1, 1)
+#if MSF_LOFTR_STRIP8_DEPTH >= 3
       MSF_ST_ISSUE(q2, 2)
+#endif
+#if MSF_LOFTR_STRIP8_DEPTH >= 4
       MSF_ST_ISSUE(q3, 3)
+#endif
     }
-    for (int n = 0; n < nsteps; n += 4) {
+    for (int n = 0; n < nsteps; n += kQDepth) {
       MSF_ST_STEP(q0, n)
       MSF_ST_STEP(q1, n + 1)
+#if MSF_LOFTR_STRIP8_DEPTH >= 3
       MSF_ST_STEP(q2, n + 2)
+#endif
+#if MSF_LOFTR_STRIP8_DEPTH >= 4
       MSF_ST_STEP(q3, n + 3)
+#endif
     }
   };
   if (ldwave) run(std::true_type{});
@@ -1134,28 +1174,45 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8
     __syncthreads();                                                                              \
     if (kLd) {                                                                                    \
       MSF_SS_COMMIT(q_, n_)                                                                       \
-      MSF_SS_ISSUE(q_, (n_) + 4)                                                                  \
+      MSF_SS_ISSUE(q_, (n_) + MSF_LOFTR_STEM_DEPTH)                                                                  \
     }                                                                                             \
     const int p_ = (n_) - 2 - 2 * sid;                                                            \
     if (p_ >= 0 && p_ <= npairs) stage(p_);                                                       \
     rin += 2 * XP; rin = rin >= RWRAP ? rin - RWRAP : rin;                                        \
     ror += 2 * XP; ror = ror >= RWRAP ? ror - RWRAP : ror;                                        \
   }
-  const int nsteps = (npairs + 2 * NS + 2 + 3) & ~3;
+  // the load queue is MSF_LOFTR_STEM_DEPTH steps deep (2, 3 or 4), each step's registers named statically; the loop is unrolled by the depth
+  constexpr int kQDepth = MSF_LOFTR_STEM_DEPTH;
+  static_assert(kQDepth >= 2 && kQDepth <= 4, "load queue depth");
+  const int nsteps = ((npairs + 2 * NS + 2 + kQDepth - 1) / kQDepth) * kQDepth;
   auto run = [&](auto is_loader) {
     constexpr bool kLd = decltype(is_loader)::value;
-    uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    uint32_t q0 = 0; uint32_t q1 = 0;
+#if MSF_LOFTR_STEM_DEPTH >= 3
+    uint32_t q2 = 0;
+#endif
+#if MSF_LOFTR_STEM_DEPTH >= 4
+    uint32_t q3 = 0;
+#endif
     if (kLd) {
       MSF_SS_ISSUE(q0, 0)
       MSF_SS_ISSUE(q1, 1)
+#if MSF_LOFTR_STEM_DEPTH >= 3
       MSF_SS_ISSUE(q2, 2)
+#endif
+#if MSF_LOFTR_STEM_DEPTH >= 4
       MSF_SS_ISSUE(q3, 3)
+#endif
     }
-    for (int n = 0; n < nsteps; n += 4) {
+    for (int n = 0; n < nsteps; n += kQDepth) {
       MSF_SS_STEP(q0, n)
       MSF_SS_STEP(q1, n + 1)
+#if MSF_LOFTR_STEM_DEPTH >= 3
       MSF_SS_STEP(q2, n + 2)
+#endif
+#if MSF_LOFTR_STEM_DEPTH >= 4
       MSF_SS_STEP(q3, n + 3)
+#endif
     }
   };
   if (ldwave) run(std::true_type{});
@@ -1201,8 +1258,8 @@ struct DownW {
 };
 
 #ifndef MSF_LOFTR_DOWN16_WPE
-#define MSF_LOFTR_DOWN16_WPE 4     // k_down16x capped at 128 registers (10 spilled, 44 B of scratch): two workgroups fit a CU
-                                   // (66 KB of LDS each) instead of one at 164 registers; 584 -> 541 us per 512 images.  0 = uncapped
+#define MSF_LOFTR_DOWN16_WPE 0     // > 0: cap k_down16x's registers for this many waves per SIMD (with the 4-step queue the cap 4 spilled
+                                   // 10 registers and still gained 7 %: two workgroups per CU; the 3-step queue needs no cap)
 #endif
 #if MSF_LOFTR_DOWN16_WPE
 #define MSF_DOWN16_ATTR __attribute__((amdgpu_waves_per_eu(MSF_LOFTR_DOWN16_WPE, MSF_LOFTR_DOWN16_WPE)))
@@ -1373,7 +1430,7 @@ __global__ __launch_bounds__(64 * down16::WAVES) MSF_DOWN16_ATTR void k_down16x(
     __syncthreads();                                                                              \
     if (kLd) {                                                                                    \
       MSF_DN_COMMIT(q_, n_)                                                                       \
-      MSF_DN_ISSUE(q_, (n_) + 4)                                                                  \
+      MSF_DN_ISSUE(q_, (n_) + MSF_LOFTR_DOWN16_DEPTH)                                             \
     }                                                                                             \
     if (st1) {                                                                                    \
       const int p_ = (n_) - 1;                                                                    \
@@ -1384,21 +1441,31 @@ __global__ __launch_bounds__(64 * down16::WAVES) MSF_DOWN16_ATTR void k_down16x(
     }                                                                                             \
     irow += 4 * IPX; irow = irow >= IWRAP ? irow - IWRAP : irow;                                  \
   }
-  const int nsteps = (npairs + 3 + 3) & ~3;
+  // the load queue is MSF_LOFTR_DOWN16_DEPTH steps deep, each step's registers named statically (a rotating queue would
+  // make every step wait for the newest load)
+  constexpr int kDepth = MSF_LOFTR_DOWN16_DEPTH;
+  const int nsteps = ((npairs + 3 + kDepth - 1) / kDepth) * kDepth;
   auto run = [&](auto is_loader) {
     constexpr bool kLd = decltype(is_loader)::value;
-    float q0[8], q1[8], q2[8], q3[8];
+    float q0[8], q1[8], q2[8];
+#if MSF_LOFTR_DOWN16_DEPTH == 4
+    float q3[8];
+#endif
     if (kLd) {
       MSF_DN_ISSUE(q0, 0)
       MSF_DN_ISSUE(q1, 1)
       MSF_DN_ISSUE(q2, 2)
+#if MSF_LOFTR_DOWN16_DEPTH == 4
       MSF_DN_ISSUE(q3, 3)
+#endif
     }
-    for (int n = 0; n < nsteps; n += 4) {
+    for (int n = 0; n < nsteps; n += kDepth) {
       MSF_DN_STEP(q0, n)
       MSF_DN_STEP(q1, n + 1)
       MSF_DN_STEP(q2, n + 2)
+#if MSF_LOFTR_DOWN16_DEPTH == 4
       MSF_DN_STEP(q3, n + 3)
+#endif
     }
   };
   if (ldwave) run(std::true_type{});
@@ -1579,7 +1646,7 @@ __global__ __launch_bounds__(64 * strip16::WAVES) void k_strip16x(const float* _
     __syncthreads();                                                                              \
     if (kLd) {                                                                                    \
       MSF_S16_COMMIT(q_, n_)                                                                      \
-      MSF_S16_ISSUE(q_, (n_) + 4)                                                                 \
+      MSF_S16_ISSUE(q_, (n_) + MSF_LOFTR_STRIP16_DEPTH)                                                                 \
     }                                                                                             \
     if (stA) {                                                                                    \
       const int p_ = (n_) - 2;                                                                    \
@@ -1590,21 +1657,38 @@ __global__ __launch_bounds__(64 * strip16::WAVES) void k_strip16x(const float* _
     }                                                                                             \
     crow += 2 * XPX; crow = crow >= XWRAP ? crow - XWRAP : crow;                                  \
   }
-  const int nsteps = (npairs + 4 + 3) & ~3;
+  // the load queue is MSF_LOFTR_STRIP16_DEPTH steps deep (2, 3 or 4), each step's registers named statically; the loop is unrolled by the depth
+  constexpr int kQDepth = MSF_LOFTR_STRIP16_DEPTH;
+  static_assert(kQDepth >= 2 && kQDepth <= 4, "load queue depth");
+  const int nsteps = ((npairs + 4 + kQDepth - 1) / kQDepth) * kQDepth;
   auto run = [&](auto is_loader) {
     constexpr bool kLd = decltype(is_loader)::value;
-    float q0[8], q1[8], q2[8], q3[8];
+    float q0[8]; float q1[8];
+#if MSF_LOFTR_STRIP16_DEPTH >= 3
+    float q2[8];
+#endif
+#if MSF_LOFTR_STRIP16_DEPTH >= 4
+    float q3[8];
+#endif
     if (kLd) {
       MSF_S16_ISSUE(q0, 0)
       MSF_S16_ISSUE(q1, 1)
+#if MSF_LOFTR_STRIP16_DEPTH >= 3
       MSF_S16_ISSUE(q2, 2)
+#endif
+#if MSF_LOFTR_STRIP16_DEPTH >= 4
       MSF_S16_ISSUE(q3, 3)
+#endif
     }
-    for (int n = 0; n < nsteps; n += 4) {
+    for (int n = 0; n < nsteps; n += kQDepth) {
       MSF_S16_STEP(q0, n)
       MSF_S16_STEP(q1, n + 1)
+#if MSF_LOFTR_STRIP16_DEPTH >= 3
       MSF_S16_STEP(q2, n + 2)
+#endif
+#if MSF_LOFTR_STRIP16_DEPTH >= 4
       MSF_S16_STEP(q3, n + 3)
+#endif
     }
   };
   if (ldwave) run(std::true_type{});
@@ -1636,7 +1720,15 @@ constexpr int NLOAD = 4 * 2 * XW;                  // loader threads: (channel b
 constexpr int LDS_BYTES = 16 * (XRING + TRING + 16);
 }  // namespace strip32
 
-__global__ __launch_bounds__(64 * strip32::WAVES) void k_strip32x(const float* __restrict__ in, const uint16_t* __restrict__ wx1,
+#ifndef MSF_LOFTR_STRIP32_WPE
+#define MSF_LOFTR_STRIP32_WPE 4   // k_strip32x capped at 128 registers (with the 2-step queue 9 are spilled): two workgroups per CU instead of one
+#endif
+#if MSF_LOFTR_STRIP32_WPE
+#define MSF_STRIP32_ATTR __attribute__((amdgpu_waves_per_eu(MSF_LOFTR_STRIP32_WPE, MSF_LOFTR_STRIP32_WPE)))
+#else
+#define MSF_STRIP32_ATTR
+#endif
+__global__ __launch_bounds__(64 * strip32::WAVES) MSF_STRIP32_ATTR void k_strip32x(const float* __restrict__ in, const uint16_t* __restrict__ wx1,
                                                                   const float* __restrict__ b1, const uint16_t* __restrict__ wx2,
                                                                   const float* __restrict__ b2, float* __restrict__ out, int H,
                                                                   int W, int n_strips) {
@@ -1785,7 +1877,7 @@ __global__ __launch_bounds__(64 * strip32::WAVES) void k_strip32x(const float* _
     __syncthreads();                                                                              \
     if (kLd) {                                                                                    \
       MSF_S32_COMMIT(q_, n_)                                                                      \
-      MSF_S32_ISSUE(q_, (n_) + 4)                                                                 \
+      MSF_S32_ISSUE(q_, (n_) + MSF_LOFTR_STRIP32_DEPTH)                                                                 \
     }                                                                                             \
     if (stA) {                                                                                    \
       const int p_ = (n_) - 2;                                                                    \
@@ -1796,21 +1888,38 @@ __global__ __launch_bounds__(64 * strip32::WAVES) void k_strip32x(const float* _
     }                                                                                             \
     crow += 2 * XPX; crow = crow >= XWRAP ? crow - XWRAP : crow;                                  \
   }
-  const int nsteps = (npairs + 4 + 3) & ~3;
+  // the load queue is MSF_LOFTR_STRIP32_DEPTH steps deep (2, 3 or 4), each step's registers named statically; the loop is unrolled by the depth
+  constexpr int kQDepth = MSF_LOFTR_STRIP32_DEPTH;
+  static_assert(kQDepth >= 2 && kQDepth <= 4, "load queue depth");
+  const int nsteps = ((npairs + 4 + kQDepth - 1) / kQDepth) * kQDepth;
   auto run = [&](auto is_loader) {
     constexpr bool kLd = decltype(is_loader)::value;
-    float q0[8], q1[8], q2[8], q3[8];
+    float q0[8]; float q1[8];
+#if MSF_LOFTR_STRIP32_DEPTH >= 3
+    float q2[8];
+#endif
+#if MSF_LOFTR_STRIP32_DEPTH >= 4
+    float q3[8];
+#endif
     if (kLd) {
       MSF_S32_ISSUE(q0, 0)
       MSF_S32_ISSUE(q1, 1)
+#if MSF_LOFTR_STRIP32_DEPTH >= 3
       MSF_S32_ISSUE(q2, 2)
+#endif
+#if MSF_LOFTR_STRIP32_DEPTH >= 4
       MSF_S32_ISSUE(q3, 3)
+#endif
     }
-    for (int n = 0; n < nsteps; n += 4) {
+    for (int n = 0; n < nsteps; n += kQDepth) {
       MSF_S32_STEP(q0, n)
       MSF_S32_STEP(q1, n + 1)
+#if MSF_LOFTR_STRIP32_DEPTH >= 3
       MSF_S32_STEP(q2, n + 2)
+#endif
+#if MSF_LOFTR_STRIP32_DEPTH >= 4
       MSF_S32_STEP(q3, n + 3)
+#endif
     }
   };
   if (ldwave) run(std::true_type{});
@@ -1842,7 +1951,15 @@ constexpr int NLOAD = 2 * 4 * INW;                 // loader threads: (channel b
 constexpr int LDS_BYTES = 16 * (IRING + 2 * TRING + 16);
 }  // namespace down32
 
-__global__ __launch_bounds__(64 * down32::WAVES) void k_down32x(const float* __restrict__ in, DownW dw, float* __restrict__ out,
+#ifndef MSF_LOFTR_DOWN32_WPE
+#define MSF_LOFTR_DOWN32_WPE 0     // > 0: cap k_down32x's registers for this many waves per SIMD
+#endif
+#if MSF_LOFTR_DOWN32_WPE
+#define MSF_DOWN32_ATTR __attribute__((amdgpu_waves_per_eu(MSF_LOFTR_DOWN32_WPE, MSF_LOFTR_DOWN32_WPE)))
+#else
+#define MSF_DOWN32_ATTR
+#endif
+__global__ __launch_bounds__(64 * down32::WAVES) MSF_DOWN32_ATTR void k_down32x(const float* __restrict__ in, DownW dw, float* __restrict__ out,
                                                                 int H, int W, int n_strips) {
   using namespace down32;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2013,7 +2130,7 @@ __global__ __launch_bounds__(64 * down32::WAVES) void k_down32x(const float* __r
     __syncthreads();                                                                              \
     if (kLd) {                                                                                    \
       MSF_D32_COMMIT(q_, n_)                                                                      \
-      MSF_D32_ISSUE(q_, (n_) + 4)                                                                 \
+      MSF_D32_ISSUE(q_, (n_) + MSF_LOFTR_DOWN32_DEPTH)                                                                 \
     }                                                                                             \
     if (st1) {                                                                                    \
       const int p_ = (n_) - 1;                                                                    \
@@ -2024,21 +2141,38 @@ __global__ __launch_bounds__(64 * down32::WAVES) void k_down32x(const float* __r
     }                                                                                             \
     irow += 4 * IPX; irow = irow >= IWRAP ? irow - IWRAP : irow;                                  \
   }
-  const int nsteps = (npairs + 3 + 3) & ~3;
+  // the load queue is MSF_LOFTR_DOWN32_DEPTH steps deep (2, 3 or 4), each step's registers named statically; the loop is unrolled by the depth
+  constexpr int kQDepth = MSF_LOFTR_DOWN32_DEPTH;
+  static_assert(kQDepth >= 2 && kQDepth <= 4, "load queue depth");
+  const int nsteps = ((npairs + 3 + kQDepth - 1) / kQDepth) * kQDepth;
   auto run = [&](auto is_loader) {
     constexpr bool kLd = decltype(is_loader)::value;
-    float q0[8], q1[8], q2[8], q3[8];
+    float q0[8]; float q1[8];
+#if MSF_LOFTR_DOWN32_DEPTH >= 3
+    float q2[8];
+#endif
+#if MSF_LOFTR_DOWN32_DEPTH >= 4
+    float q3[8];
+#endif
     if (kLd) {
       MSF_D32_ISSUE(q0, 0)
       MSF_D32_ISSUE(q1, 1)
+#if MSF_LOFTR_DOWN32_DEPTH >= 3
       MSF_D32_ISSUE(q2, 2)
+#endif
+#if MSF_LOFTR_DOWN32_DEPTH >= 4
       MSF_D32_ISSUE(q3, 3)
+#endif
     }
-    for (int n = 0; n < nsteps; n += 4) {
+    for (int n = 0; n < nsteps; n += kQDepth) {
       MSF_D32_STEP(q0, n)
       MSF_D32_STEP(q1, n + 1)
+#if MSF_LOFTR_DOWN32_DEPTH >= 3
       MSF_D32_STEP(q2, n + 2)
+#endif
+#if MSF_LOFTR_DOWN32_DEPTH >= 4
       MSF_D32_STEP(q3, n + 3)
+#endif
     }
   };
   if (ldwave) run(std::true_type{});
