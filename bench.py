@@ -236,9 +236,7 @@ def run_workload(args, matcher, W, H, P, ratio_or_thr, loftr_f32, rank, world, l
                 res = gather(packed.to(cdev), offs.to(cdev))
                 if res is not None:
                     gathered[0] = sum(int(r[0].shape[0]) for r in res)
-        if timed:
-            for k, v in fm.stage_times().items():   # HIP events recorded on the launch stream
-                stage_acc[k] = stage_acc.get(k, 0.0) + v
+
 
     def fence():
         if world > 1:
@@ -248,11 +246,15 @@ def run_workload(args, matcher, W, H, P, ratio_or_thr, loftr_f32, rank, world, l
     for _ in range(args.warmup):
         step(False)
     fence()
+    fm.stage_times()          # drop the warm-up calls' stage times (msf_stage_times sums over the calls since the last query)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
+        step(True)            # enqueue only: nothing waits for the device inside the timed region
     fence()
     dt = time.perf_counter() - t0
+    # HIP events recorded on the launch stream by every timed call (a ring of event sets), read after the region
+    for k, v in fm.stage_times().items():
+        stage_acc[k] = stage_acc.get(k, 0.0) + v
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)   # timing only, outside the timed region

@@ -302,8 +302,11 @@ typedef enum msf_debug_what {
 int msf_debug_get(msf_handle* h, int32_t what, int32_t slot, int32_t level,
                   void* host_out, size_t cap_bytes, size_t* n_bytes);
 
-/* per-stage device time of the LAST batch call, measured with HIP events on the launch stream
- * (needs MSF_FLAG_PROFILE).  names[i] are static strings.  Returns the number of stages. */
+/* per-stage device time, measured with HIP events on the launch stream (needs MSF_FLAG_PROFILE): the SUM over the batch
+ * calls since the previous query -- queried after every call it is that call's times; a caller that enqueues many calls
+ * ahead of the device (nothing in the recording waits) queries once afterwards and divides by its call count.  The events
+ * live in a ring of 32 sets; a set needed again before it was queried is folded into the sum first.  Waits for the calls
+ * it reports.  names[i] are static strings.  Returns the number of stages. */
 int msf_stage_times(msf_handle* h, const char** names, float* ms, int32_t cap);
 
 #ifdef __cplusplus

@@ -4136,8 +4136,35 @@ struct LoftrPipeline::Impl {
   float* act_dbg[4] = {nullptr, nullptr, nullptr, nullptr};   // frame A of pair 0 after layer1..4: [8][240][320], [16][120][160], [32][60][80], [32][30][40]
   int dbg_pair = 0;
   bool have_dbg = false;
-  std::vector<hipEvent_t> ev;  // start, backbone done, transformer done, head done
-  bool ev_ok = false, ev_rec = false;
+  // Stage events (start, backbone done, transformer done, head done) as a ring of sets: a call records into the next free
+  // set and nobody waits, so a caller can enqueue batches ahead of the device; stage_times() harvests the finished sets
+  // and returns the sums since the last query (a query after every call sees that call's times, as before)
+  static constexpr int kEvRing = 32;
+  std::vector<hipEvent_t> ev;  // kEvRing x 4
+  bool ev_set_rec[kEvRing] = {};
+  int ev_cur = 0;
+  float ev_acc[3] = {0.f, 0.f, 0.f};
+  int ev_acc_calls = 0;
+  bool ev_ok = false;
+  hipEvent_t* ev_cur_set() { return ev.data() + 4 * ev_cur; }
+  void ev_harvest(int i) {
+    if (!ev_set_rec[i]) return;
+    ev_set_rec[i] = false;
+    hipEvent_t* e = ev.data() + 4 * i;
+    if (hipEventSynchronize(e[3]) != hipSuccess) return;
+    for (int k = 0; k < 3; k++) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, e[k], e[k + 1]) == hipSuccess) ev_acc[k] += t;
+    }
+    ev_acc_calls++;
+  }
+  hipEvent_t* ev_begin_call() {           // the set this call records into
+    if (ev_set_rec[ev_cur]) {
+      ev_cur = (ev_cur + 1) % kEvRing;
+      ev_harvest(ev_cur);                  // the oldest set, kEvRing calls back: long finished
+    }
+    return ev_cur_set();
+  }
 };
 
 LoftrPipeline::~LoftrPipeline() { destroy(); }
@@ -4538,7 +4565,7 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
     for (int l = 0; l < 4; l++) LF_TRY(dalloc(&P.act_dbg[l], act_elems[l]));
   }
   if (profile) {
-    P.ev.resize(4);
+    P.ev.resize(4 * Impl::kEvRing);
     for (auto& e : P.ev) LF_TRY(hipEventCreate(&e));
     P.ev_ok = true;
   }
@@ -4744,7 +4771,7 @@ hipError_t LoftrPipeline::match(int n_pairs, const uint8_t* d_a, const uint8_t* 
   Impl& P = *p_;
   if (n_pairs > P.max_pairs) return hipErrorInvalidValue;
   const long long ts = (long long)NTOK * DM;
-  hipEvent_t* ev = P.ev_ok ? P.ev.data() : nullptr;
+  hipEvent_t* ev = P.ev_ok ? P.ev_begin_call() : nullptr;
   if (ev) hipEventRecord(ev[0], st);
   // ---- backbone, in chunks of pairs (activations are the big buffers); tokens of all pairs are kept
   for (int p0 = 0; p0 < n_pairs; p0 += P.chunk) {
@@ -4777,7 +4804,7 @@ hipError_t LoftrPipeline::match_slots(int n_pairs, const int32_t* d_slot_a, cons
   Impl& P = *p_;
   if (n_pairs > P.max_pairs) return hipErrorInvalidValue;
   if (n_pairs <= 0) return hipSuccess;
-  hipEvent_t* ev = P.ev_ok ? P.ev.data() : nullptr;
+  hipEvent_t* ev = P.ev_ok ? P.ev_begin_call() : nullptr;
   if (ev) hipEventRecord(ev[0], st);
   hipLaunchKernelGGL(k_gather_tokens, dim3(NTOK * DM / 4 / 256 + 1, n_pairs, 2), dim3(256), 0, st, P.tok_cache,
                      d_slot_a, d_slot_b, P.n_slots, P.tok[0], P.tok[1]);
@@ -4901,7 +4928,7 @@ hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf
                                                int32_t* d_n_out, hipStream_t st) {
   Impl& P = *p_;
   const long long ts = (long long)NTOK * DM;
-  hipEvent_t* ev = P.ev_ok ? P.ev.data() : nullptr;
+  hipEvent_t* ev = P.ev_ok ? P.ev_cur_set() : nullptr;      // the set match() / match_slots() began
   // ---- 8 encoder blocks over all pairs: (x, source) -> dst   [self, self, cross, cross(updated feat0)] x 2
   const int n = n_pairs;
   float *f0 = P.tok[0], *f1 = P.tok[1], *t0 = P.tok[2], *t1 = P.tok[3];
@@ -4994,19 +5021,23 @@ hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf
     hipMemcpyAsync(P.feat_dbg + ts, f1, ts * sizeof(float), hipMemcpyDeviceToDevice, st);
     P.have_dbg = true;
   }
-  if (ev) { hipEventRecord(ev[3], st); P.ev_rec = true; }
+  if (ev) { hipEventRecord(ev[3], st); P.ev_set_rec[P.ev_cur] = true; }
   return hipGetLastError();
 }
 
 int LoftrPipeline::stage_times(const char** names, float* ms, int cap) {
   static const char* kNames[3] = {"backbone_convs", "transformer", "match_head"};
-  if (!p_ || !p_->ev_ok || !p_->ev_rec) return 0;
-  if (hipEventSynchronize(p_->ev[3]) != hipSuccess) return 0;
+  if (!p_ || !p_->ev_ok) return 0;
+  Impl& P = *p_;
+  for (int k = 0; k < Impl::kEvRing; k++) P.ev_harvest((P.ev_cur + 1 + k) % Impl::kEvRing);   // oldest first
+  if (P.ev_acc_calls == 0) return 0;
   int n = 0;
   for (int i = 0; i < 3 && n < cap; i++, n++) {
     names[n] = kNames[i];
-    if (hipEventElapsedTime(&ms[n], p_->ev[i], p_->ev[i + 1]) != hipSuccess) ms[n] = -1.f;
+    ms[n] = P.ev_acc[i];
+    P.ev_acc[i] = 0.f;
   }
+  P.ev_acc_calls = 0;
   return n;
 }
 

@@ -2220,8 +2220,10 @@ void OrbPipeline::destroy() {
   d_pyr_ = nullptr; d_tab_ = nullptr; d_cand_cnt_ = nullptr; d_cand_ = nullptr; d_cand_sc_ = nullptr; d_qres_ = nullptr; d_done_ = nullptr; d_s1_cnt_ = nullptr;
   d_s1_ = nullptr; d_kp_ = nullptr; d_desc_ = nullptr; d_kp_cnt_ = nullptr; d_status_ = nullptr;
   if (ev_ok_) {
-    for (auto& e : ev_) hipEventDestroy(e);
-    for (auto& e : ev2_) if (e) hipEventDestroy(e);
+    for (auto& set : evr_) {
+      for (auto& e : set.ev) if (e) hipEventDestroy(e);
+      for (auto& e : set.ev2) if (e) hipEventDestroy(e);
+    }
   }
   ev_ok_ = false;
   if (split_stream_) {
@@ -2522,8 +2524,10 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     MSF_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_disc), disc.data(), sizeof(uint32_t) * 2 * kDiscTasks));
   }
   if (profile_) {
-    for (auto& e : ev_) MSF_HIP_TRY(hipEventCreate(&e));
-    for (auto& e : ev2_) MSF_HIP_TRY(hipEventCreate(&e));
+    for (auto& set : evr_) {
+      for (auto& e : set.ev) MSF_HIP_TRY(hipEventCreate(&e));
+      for (auto& e : set.ev2) MSF_HIP_TRY(hipEventCreate(&e));
+    }
     ev_ok_ = true;
   }
   if (!getenv("MSF_ORB_NO_SIDE_STREAM")) {
@@ -2554,6 +2558,7 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
   if (src.slot0 < 0 || src.slot0 + n > max_slots_) return hipErrorInvalidValue;
   last_src_ = src;
   last_split_ = false;
+  if (ev_ok_) ev_begin_call();
   if (split_stream_ && n >= 256) {
     // K parts, alternately on the caller's stream and the second one; part k's pyramid starts when part k-1's is done
     last_split_ = true;
@@ -2791,7 +2796,10 @@ hipError_t OrbPipeline::match(int n_pairs, const int32_t* d_slot_a, const int32_
   const int limit = slot_limit > 0 && slot_limit < max_slots_ ? slot_limit : max_slots_;
   // train descriptors go through LDS in chunks of kTrainChunk; MSF_ORB_TRAIN_CHUNK shrinks the chunk so tests can
   // exercise the multi-chunk path with ordinary keypoint counts
-  if (ev_ok_ && !ev_extract_pending_) hipEventRecord(ev_[4], st);
+  if (ev_ok_ && !ev_extract_pending_) {
+    ev_begin_call();                      // a slot-pair match on its own is a call of its own
+    hipEventRecord(ev_[4], st);
+  }
   static const int chunk = [] {
     const char* e = getenv("MSF_ORB_TRAIN_CHUNK");
     const int v = e ? atoi(e) : kTrainChunk;
@@ -2805,31 +2813,59 @@ hipError_t OrbPipeline::match(int n_pairs, const int32_t* d_slot_a, const int32_
                        d_desc_, d_status_, ratio, d_out, cap, d_n_out, chunk, slot_base, limit);
   if (ev_ok_) {
     hipEventRecord(ev_[5], st);
-    ev_recorded_ = true;
-    ev_match_only_ = !ev_extract_pending_;   // a slot-pair match on its own: only the last interval is of this call
+    EvSet& set = evr_[ev_cur_];
+    set.recorded = true;
+    set.match_only = !ev_extract_pending_;   // a slot-pair match on its own: only the last interval is of this call
+    set.split = last_split_;
     ev_extract_pending_ = false;
   }
   return hipGetLastError();
 }
 
-int OrbPipeline::stage_times(const char** names, float* ms, int cap) {
-  // fused extraction: the first stage is pyramid + FAST of levels 0 .. 6 in one pass per level (samplers included), the
-  // second what is left of FAST (the last level, the check, the dense redo)
-  const char* kNames[5] = {last_fused_ ? "pyramid_fast" : "pyramid", "fast_nms", "select_harris", "orient_describe", "match"};
-  if (!ev_ok_ || !ev_recorded_) return 0;
-  if (hipEventSynchronize(ev_[5]) != hipSuccess) return 0;
-  int n = 0;
-  for (int i = ev_match_only_ ? 4 : 0; i < 5 && n < cap; i++, n++) {
-    names[n] = kNames[i];
+void OrbPipeline::ev_begin_call() {
+  if (evr_[ev_cur_].recorded) {
+    ev_cur_ = (ev_cur_ + 1) % kEvRing;
+    if (evr_[ev_cur_].recorded) ev_harvest(ev_cur_);   // the oldest set, kEvRing calls back
+  }
+  ev_ = evr_[ev_cur_].ev;
+  ev2_ = evr_[ev_cur_].ev2;
+}
+
+// adds the stage times of set i to the accumulators (waits for the set's last event)
+void OrbPipeline::ev_harvest(int i) {
+  EvSet& set = evr_[i];
+  if (!set.recorded) return;
+  set.recorded = false;
+  if (hipEventSynchronize(set.ev[5]) != hipSuccess) return;
+  for (int k = set.match_only ? 4 : 0; k < 5; k++) {
     // a split extraction (two sub-batches on two streams): a stage's time is the sum over the two parts (each measured
-    // on its own stream, i.e. with the other part's kernels beside it); part 0's descriptors end at ev_[6]
-    hipEvent_t e1 = (last_split_ && !ev_match_only_ && i == 3) ? ev_[6] : ev_[i + 1];
-    if (hipEventElapsedTime(&ms[n], ev_[i], e1) != hipSuccess) ms[n] = -1.f;
-    if (last_split_ && !ev_match_only_ && i < 4) {
+    // on its own stream, i.e. with the other part's kernels beside it); part 0's descriptors end at ev[6]
+    hipEvent_t e1 = (set.split && !set.match_only && k == 3) ? set.ev[6] : set.ev[k + 1];
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, set.ev[k], e1) == hipSuccess) acc_ms_[k] += t;
+    if (set.split && !set.match_only && k < 4) {
       float t2 = 0.f;
-      if (hipEventElapsedTime(&t2, ev2_[i], ev2_[i + 1]) == hipSuccess) ms[n] += t2;
+      if (hipEventElapsedTime(&t2, set.ev2[k], set.ev2[k + 1]) == hipSuccess) acc_ms_[k] += t2;
     }
   }
+  if (set.match_only) acc_match_only_++;
+  else acc_full_++;
+}
+
+int OrbPipeline::stage_times(const char** names, float* ms, int cap) {
+  // fused extraction: the first stage is pyramid + FAST of levels 0 .. 6 in one pass per level (samplers included), the
+  // second what is left of FAST (the last level, the check, the dense redo).  Sums over the calls since the last query.
+  const char* kNames[5] = {last_fused_ ? "pyramid_fast" : "pyramid", "fast_nms", "select_harris", "orient_describe", "match"};
+  if (!ev_ok_) return 0;
+  for (int k = 0; k < kEvRing; k++) ev_harvest((ev_cur_ + 1 + k) % kEvRing);      // oldest first
+  if (acc_full_ + acc_match_only_ == 0) return 0;
+  int n = 0;
+  for (int i = acc_full_ ? 0 : 4; i < 5 && n < cap; i++, n++) {
+    names[n] = kNames[i];
+    ms[n] = acc_ms_[i];
+  }
+  for (auto& a : acc_ms_) a = 0.f;
+  acc_full_ = acc_match_only_ = 0;
   return n;
 }
 

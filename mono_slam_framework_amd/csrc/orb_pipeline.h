@@ -125,8 +125,25 @@ class OrbPipeline {
   uint32_t* d_status_ = nullptr;   // [slots]
   uint32_t* d_qres_ = nullptr;     // [kSplitMaxPairs][kKpCap] per-query results of the small-batch matcher
   uint32_t* d_done_ = nullptr;     // [kSplitMaxPairs] ticket counters (left at 0)
-  hipEvent_t ev_[kOrbStages + 2] = {};
-  bool ev_ok_ = false, ev_recorded_ = false, ev_extract_pending_ = false, ev_match_only_ = false;
+  // Stage events (MSF_FLAG_PROFILE).  A RING of event sets: a call records into the next free set and nobody waits, so a
+  // caller can enqueue many batches ahead of the device; stage_times() harvests every finished set and returns the SUM
+  // of the stage times since the last query (a query after every call sees that call's times, as before).  A set that
+  // is needed again before it was queried is harvested first -- it is kEvRing calls old, long finished.
+  static constexpr int kEvRing = 32;
+  struct EvSet {
+    hipEvent_t ev[kOrbStages + 2] = {};
+    hipEvent_t ev2[kOrbStages + 2] = {};        // stage boundaries of the parts on split_stream_ (profiling)
+    bool recorded = false, match_only = false, split = false;
+  };
+  EvSet evr_[kEvRing];
+  int ev_cur_ = 0;
+  hipEvent_t* ev_ = evr_[0].ev;                 // the current set
+  hipEvent_t* ev2_ = evr_[0].ev2;
+  float acc_ms_[5] = {};                        // harvested, not yet returned
+  int acc_full_ = 0, acc_match_only_ = 0;       // calls behind acc_ms_: with an extraction / slot-pair matches only
+  void ev_begin_call();
+  void ev_harvest(int i);
+  bool ev_ok_ = false, ev_extract_pending_ = false;
   FrameSrc last_src_{};
   static constexpr int kMaxChains = 4;          // chains of a fused extraction: the caller's stream + up to 3 of these
   hipStream_t chain_stream_[kMaxChains - 1] = {};   // [0] = tau_stream_
@@ -143,7 +160,6 @@ class OrbPipeline {
   hipStream_t split_stream_ = nullptr;
   hipEvent_t split_ev_[3] = {};
   hipEvent_t split_pyr_[8] = {};
-  hipEvent_t ev2_[kOrbStages + 2] = {};         // stage boundaries of the parts on split_stream_ (profiling)
   int split_parts_ = 2;
   bool last_split_ = false, last_fused_ = false;
   uint32_t* d_redo2_ = nullptr;
