@@ -761,7 +761,10 @@ constexpr int WAVES = 8;
 // waves one wave of stage 1 takes two jobs.  Tried (r03): 10 waves, 5 per stage, every wave at most one job -- the kernel
 // needs 118 VGPRs (24 of weight fragments, 32 of load queue), two workgroups per CU would need <= 96: forced there it
 // spills 60 B per lane and runs 1.47 ms against 0.62 (one workgroup per CU, unforced: not faster either).  8 it stays.
-constexpr int BLK_WAVES = 8;
+#ifndef MSF_LOFTR_STRIP8_WAVES
+#define MSF_LOFTR_STRIP8_WAVES 8
+#endif
+constexpr int BLK_WAVES = MSF_LOFTR_STRIP8_WAVES;
 // Tried (r03): strips of 62 columns (MSF_LOFTR_STRIP8_S=62) -- stage 1 then writes 64 columns = 4 M tiles and stage 2
 // 62 = 4 tiles, 8 jobs for 8 waves in ONE round per step instead of 5 + 4 jobs in two; six strips instead of five, the last
 // overlapping its neighbour.  774 vs 617 us: exactly the 6 / 5 more strips, i.e. a step costs the same with one job less
