@@ -16,10 +16,11 @@ for name, make in (("orb", lambda: FeatureMatcher(0.6, 640, 480, flags=_lib.MSF_
     a, b = synth.synth_pair(5, 640, 480, mode=0 if name == "orb" else 1)
     for _ in range(20):
         fm.MatchFrames(a, b)
+    fm.stage_times()                 # msf_stage_times sums over the calls since the last query: start the sum here
     t0 = time.perf_counter()
     for _ in range(200):
         fm.MatchFrames(a, b)
     dt = (time.perf_counter() - t0) / 200
-    st = fm.stage_times()
+    st = {k: v / 200 for k, v in fm.stage_times().items()}      # mean per call
     print(name, "(stateless)" if NOCACHE else "(frames cached)", "640x480 MatchFrames latency %.3f ms; kernel stages (ms):" % (dt * 1e3),
           {k: round(v, 3) for k, v in st.items()}, "sum %.3f" % sum(st.values()))
