@@ -270,6 +270,17 @@ int msf_multi_match_batch_device(msf_multi* m, const int32_t* n_pairs, const uin
  *       in rank order (pair p of rank r starts at sum(totals[0..r)) + d_all_offsets[r][p]); other ranks pass NULL.
  *       MSF_ERR_CAPACITY if a rank holds more than cap_records records (nothing is transferred then).
  *   msf_gather_plan        the placement arithmetic on its own (host only; unit-tested without a GPU).
+ * Failure semantics of msf_gather_matches_device (a collective: every rank calls it the same number of times).
+ *   MSF_ERR_CAPACITY / MSF_ERR_INVALID_ARG from the placement step are computed by every rank from the same gathered
+ *   offsets: ALL ranks return the same code, none enters the send / recv leg, the object stays usable.  Any other error
+ *   (a failing RCCL or HIP call on this rank) is HARD: the rank aborts its communicator (ncclCommAbort, where the library
+ *   exports it) so that peers blocked in their send / recv come back with an error instead of waiting for ever, every
+ *   later call on the object returns MSF_ERR_HIP, and the only valid operation left is msf_gather_destroy -- on every
+ *   rank, followed by a new msf_gather_unique_id / msf_gather_create round if the job goes on.  EXPERIMENTAL beyond one
+ *   rank: see the next line.
+ * Missing RCCL (no librccl.so to dlopen; MSF_RCCL_LIBRARY overrides the name) gives MSF_ERR_HIP from
+ * msf_gather_unique_id / msf_gather_create with the loader's message in msf_gather_last_error(NULL); nothing else in
+ * libmsf.so needs RCCL.
  * Executed so far: on one MI355X with a one-rank communicator; the send / recv leg has not run on more than one GPU. */
 typedef struct msf_gather msf_gather;
 int msf_gather_unique_id(uint8_t* id128);

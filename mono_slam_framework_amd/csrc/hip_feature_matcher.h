@@ -170,6 +170,47 @@ class HipDNNFeatureMatcher : public HipMatcherBase {
       : HipMatcherBase(make(model_file_path, threshold, image_width, image_height, model_resolution, device,
                             max_batch_pairs), 4096),
         path_(model_file_path) {}
+  // the reference's own signature, dnnfeaturematcher.h:11-13 (a wide path because Ort::Session takes ORTCHAR_T = wchar_t on
+  // the platform the app was written on); its call, src/main.cpp:62: DNNFeatureMatcher featureMatcher(L"model/LoFTR_teacher.onnx");
+  explicit HipDNNFeatureMatcher(const std::wstring& model_file_path, float threshold = 0.15f, int64_t image_width = 640,
+                                int64_t image_height = 480, int model_resolution = 16, int device = 0,
+                                int max_batch_pairs = 1)
+      : HipDNNFeatureMatcher(narrow(model_file_path), threshold, image_width, image_height, model_resolution, device,
+                             max_batch_pairs) {}
+  // wide and narrow string LITERALS would otherwise be ambiguous between the two string classes' converting constructors
+  explicit HipDNNFeatureMatcher(const wchar_t* model_file_path, float threshold = 0.15f, int64_t image_width = 640,
+                                int64_t image_height = 480, int model_resolution = 16, int device = 0,
+                                int max_batch_pairs = 1)
+      : HipDNNFeatureMatcher(std::wstring(model_file_path ? model_file_path : L""), threshold, image_width, image_height,
+                             model_resolution, device, max_batch_pairs) {}
+  explicit HipDNNFeatureMatcher(const char* model_file_path, float threshold = 0.15f, int64_t image_width = 640,
+                                int64_t image_height = 480, int model_resolution = 16, int device = 0,
+                                int max_batch_pairs = 1)
+      : HipDNNFeatureMatcher(std::string(model_file_path ? model_file_path : ""), threshold, image_width, image_height,
+                             model_resolution, device, max_batch_pairs) {}
+
+  // wchar_t path -> UTF-8 (wchar_t is UTF-32 on Linux, UTF-16 with surrogate pairs where it is 16 bits wide)
+  static std::string narrow(const std::wstring& w) {
+    std::string out;
+    out.reserve(w.size());
+    for (size_t i = 0; i < w.size(); i++) {
+      uint32_t c = (uint32_t)w[i];
+      if (sizeof(wchar_t) == 2 && c >= 0xD800u && c < 0xDC00u && i + 1 < w.size()) {
+        const uint32_t lo = (uint32_t)w[i + 1];
+        if (lo >= 0xDC00u && lo < 0xE000u) { c = 0x10000u + ((c - 0xD800u) << 10) + (lo - 0xDC00u); i++; }
+      }
+      if (c < 0x80u) out.push_back((char)c);
+      else if (c < 0x800u) { out.push_back((char)(0xC0u | (c >> 6))); out.push_back((char)(0x80u | (c & 0x3Fu))); }
+      else if (c < 0x10000u) {
+        out.push_back((char)(0xE0u | (c >> 12))); out.push_back((char)(0x80u | ((c >> 6) & 0x3Fu)));
+        out.push_back((char)(0x80u | (c & 0x3Fu)));
+      } else {
+        out.push_back((char)(0xF0u | ((c >> 18) & 7u))); out.push_back((char)(0x80u | ((c >> 12) & 0x3Fu)));
+        out.push_back((char)(0x80u | ((c >> 6) & 0x3Fu))); out.push_back((char)(0x80u | (c & 0x3Fu)));
+      }
+    }
+    return out;
+  }
 
  private:
   static msf_config make(const std::string& path, float thr, int64_t w, int64_t h, int res, int dev, int max_pairs) {

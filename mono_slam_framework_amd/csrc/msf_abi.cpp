@@ -792,6 +792,9 @@ int msf_render_match_image(msf_handle* h, const msf_image* f1, const msf_image* 
     }
     msf_match* d_m = n_matches ? h->d_render_m : nullptr;
     uint8_t* d_flags = n_matches ? reinterpret_cast<uint8_t*>(h->d_render_m + h->render_cap) : nullptr;
+    // From here on asynchronous copies from / to the CALLER's buffers are in flight: whichever way the call leaves --
+    // an error branch included -- the stream is drained first, so the caller may free or reuse them on return.
+    struct Drain { hipStream_t s; bool armed = true; ~Drain() { if (armed) hipStreamSynchronize(s); } } drain{st};
     if (n_matches) {
       if ((e = hipMemcpyAsync(d_m, matches, (size_t)n_matches * sizeof(msf_match), hipMemcpyHostToDevice, st)) != hipSuccess) return hip_fail(h, "hipMemcpyAsync", e);
       if ((e = hipMemsetAsync(d_flags, 0, (size_t)2 * n_matches, st)) != hipSuccess) return hip_fail(h, "hipMemsetAsync", e);
@@ -803,6 +806,7 @@ int msf_render_match_image(msf_handle* h, const msf_image* f1, const msf_image* 
     if ((e = msf::render_match_image(dA, dB, W, H, h->stage_pitch, d_m, d_flags, d_flags ? d_flags + n_matches : nullptr,
                                      n_matches, h->d_render, 6ll * W, st)) != hipSuccess) return hip_fail(h, "render_match_image", e);
     if ((e = hipMemcpy2DAsync(out_rgb, out_stride, h->d_render, (size_t)6 * W, (size_t)6 * W, H, hipMemcpyDeviceToHost, st)) != hipSuccess) return hip_fail(h, "hipMemcpy2DAsync", e);
+    drain.armed = false;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(h, "hipStreamSynchronize", e);   // the one wait of the call
     return MSF_OK;
   } catch (...) {

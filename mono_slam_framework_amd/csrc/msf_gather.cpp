@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -30,6 +31,7 @@ struct Rccl {
   int (*GetUniqueId)(UniqueId*) = nullptr;
   int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommAbort)(void*) = nullptr;   // optional
   int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
@@ -44,12 +46,19 @@ Rccl* rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    const char* names[] = {"librccl.so", "librccl.so.1"};
+    // MSF_RCCL_LIBRARY names the one library to bind instead (a site's own RCCL build; tests point it at a name that
+    // does not exist to take the not-found path)
+    const char* over = getenv("MSF_RCCL_LIBRARY");
+    const char* names[] = {over && *over ? over : "librccl.so", over && *over ? over : "librccl.so.1"};
     for (const char* n : names)                       // an RCCL this process already holds (torch.distributed) first
       if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
     for (const char* n : names)
       if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (!r.lib) { r.err = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : ""); return; }
+    if (!r.lib) {
+      const char* de = dlerror();                     // ONE call: dlerror() clears the message it returns
+      r.err = std::string(names[0]) + " not found: " + (de ? de : "(no dlerror text)");
+      return;
+    }
     auto sym = [&](const char* s) { void* p = dlsym(r.lib, s); if (!p && r.err.empty()) r.err = std::string("RCCL symbol missing: ") + s; return p; };
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
@@ -60,6 +69,7 @@ Rccl* rccl() {
     r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.lib, "ncclCommAbort"));
   });
   return &r;
 }
@@ -76,6 +86,7 @@ struct msf_gather {
   std::vector<int64_t> first;
   std::mutex mu;
   std::string err;
+  bool dead = false;                  // a collective failed on this rank: the communicator was aborted, only destroy is left
 };
 
 namespace {
@@ -86,6 +97,15 @@ int gfail(msf_gather* g, int code, const std::string& msg) {
 int nccl_fail(msf_gather* g, const char* what, int rc) {
   Rccl* r = rccl();
   return gfail(g, MSF_ERR_HIP, std::string(what) + ": " + (r->GetErrorString ? r->GetErrorString(rc) : "RCCL error"));
+}
+// A failure on ONE rank between the all-gather and the end of the group call leaves its peers inside their send / recv:
+// the communicator is aborted (ncclCommAbort, where the library has it) so that they return with an error instead of
+// waiting for ever, and the object only accepts msf_gather_destroy from then on (include/msf_abi.h, "failure semantics").
+int hard_fail(msf_gather* g, int code) {
+  g->dead = true;
+  Rccl* r = rccl();
+  if (g->comm && r->CommAbort) { r->CommAbort(g->comm); g->comm = nullptr; }
+  return code;
 }
 }  // namespace
 
@@ -161,7 +181,7 @@ int msf_gather_create(int32_t device, int32_t rank, int32_t n_ranks, const uint8
 void msf_gather_destroy(msf_gather* g) {
   if (!g) return;
   hipSetDevice(g->device);
-  if (g->comm && rccl()->CommDestroy) rccl()->CommDestroy(g->comm);
+  if (g->comm && rccl()->CommDestroy) rccl()->CommDestroy(g->comm);   // (an aborted communicator is already gone)
   if (g->h_offs) hipHostFree(g->h_offs);
   delete g;
 }
@@ -175,23 +195,26 @@ int msf_gather_matches_device(msf_gather* g, const msf_match* d_packed, const in
     std::lock_guard<std::mutex> lk(g->mu);
     if (!d_packed || !d_offsets || !d_all_offsets || !totals || (g->rank == 0 && !d_recv))
       return gfail(g, MSF_ERR_INVALID_ARG, "msf_gather_matches_device: null argument");
+    if (g->dead) return gfail(g, MSF_ERR_HIP, "msf_gather_matches_device: an earlier call failed; destroy this gather object");
     Rccl* r = rccl();
     hipError_t e = hipSetDevice(g->device);
     if (e != hipSuccess) return gfail(g, MSF_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
     hipStream_t st = (hipStream_t)stream;
     const size_t n_off = (size_t)g->pairs + 1;
     int rc = r->AllGather(d_offsets, d_all_offsets, n_off, kNcclInt32, g->comm, st);
-    if (rc != 0) return nccl_fail(g, "ncclAllGather(offsets)", rc);
+    if (rc != 0) return hard_fail(g, nccl_fail(g, "ncclAllGather(offsets)", rc));
     // exact-size send / recv need the totals on the host: one small copy + wait per step (a padded all-gather of
     // capacity-sized lists would move ~10x the bytes over xGMI instead)
     if ((e = hipMemcpyAsync(g->h_offs, d_all_offsets, (size_t)g->n_ranks * n_off * sizeof(int32_t), hipMemcpyDeviceToHost, st)) != hipSuccess ||
         (e = hipStreamSynchronize(st)) != hipSuccess)
-      return gfail(g, MSF_ERR_HIP, std::string("offsets to host: ") + hipGetErrorString(e));
+      return hard_fail(g, gfail(g, MSF_ERR_HIP, std::string("offsets to host: ") + hipGetErrorString(e)));
     const int plan = msf_gather_plan(g->n_ranks, g->pairs, g->h_offs, g->cap, totals, g->first.data());
+    // every rank plans from the same gathered offsets: a capacity / format error is returned by ALL ranks, none enters
+    // the send / recv leg, and the object stays usable
     if (plan != MSF_OK)
       return gfail(g, plan, plan == MSF_ERR_CAPACITY ? "msf_gather_matches_device: a rank holds more records than cap_records"
                                                      : "msf_gather_matches_device: malformed offsets");
-    if ((rc = r->GroupStart()) != 0) return nccl_fail(g, "ncclGroupStart", rc);
+    if ((rc = r->GroupStart()) != 0) return hard_fail(g, nccl_fail(g, "ncclGroupStart", rc));
     if (g->rank == 0) {
       for (int q = 1; q < g->n_ranks && rc == 0; q++)
         if (totals[q] > 0) rc = r->Recv(d_recv + g->first[q], (size_t)totals[q] * 4, kNcclInt32, q, g->comm, st);
@@ -199,11 +222,11 @@ int msf_gather_matches_device(msf_gather* g, const msf_match* d_packed, const in
       rc = r->Send(d_packed, (size_t)totals[g->rank] * 4, kNcclInt32, 0, g->comm, st);
     }
     const int rc_end = r->GroupEnd();
-    if (rc != 0) return nccl_fail(g, "ncclSend/ncclRecv", rc);
-    if (rc_end != 0) return nccl_fail(g, "ncclGroupEnd", rc_end);
+    if (rc != 0) return hard_fail(g, nccl_fail(g, "ncclSend/ncclRecv", rc));
+    if (rc_end != 0) return hard_fail(g, nccl_fail(g, "ncclGroupEnd", rc_end));
     if (g->rank == 0 && totals[0] > 0 &&
         (e = hipMemcpyAsync(d_recv + g->first[0], d_packed, (size_t)totals[0] * sizeof(msf_match), hipMemcpyDeviceToDevice, st)) != hipSuccess)
-      return gfail(g, MSF_ERR_HIP, std::string("own records: ") + hipGetErrorString(e));
+      return gfail(g, MSF_ERR_HIP, std::string("own records: ") + hipGetErrorString(e));   // local copy: peers are not waiting on it
     return MSF_OK;
   } catch (...) {
     return gfail(g, MSF_ERR_HIP, "msf_gather_matches_device: host exception");

@@ -18,6 +18,13 @@ SLAM_PIPELINE::MatchFramesResult through_the_interface(SLAM_PIPELINE::FrameBase&
   msf::HipOrbMatcher featureMatcher(0.6f);
   msf::HipLoftrMatcher dnnMatcher("../model/LoFTR_teacher.onnx", 0.1f);
   dnnMatcher.SetThreshold(0.15f);
+  // the reference's own constructor call, src/main.cpp:62 (a wide literal: dnnfeaturematcher.h:11 takes std::wstring)
+  msf::HipLoftrMatcher featureMatcherW(L"model/LoFTR_teacher.onnx");
+  featureMatcherW.SetThreshold(0.1f);
+  const std::wstring wide_path = L"model/LoFTR_teacher.onnx";
+  msf::HipLoftrMatcher fromWString(wide_path, 0.15f, 640, 480, 16);
+  const std::string narrow_path = "model/LoFTR_teacher.onnx";
+  msf::HipLoftrMatcher fromString(narrow_path);
   SLAM_PIPELINE::FeatureMatcher* plugins[2] = {&featureMatcher, &dnnMatcher};
   SLAM_PIPELINE::MatchFramesResult r = plugins[0]->MatchFrames(cur, kf);
   SLAM_PIPELINE::MatchFramesResult r2 = plugins[1]->MatchFrames(cur, kf);

@@ -12,6 +12,13 @@ extern "C" int msf_synth_pair(uint64_t seed, int w, int h, int dx, int dy, int m
                               int64_t stride_a, uint8_t* b, int64_t stride_b);
 
 int main() {
+  // host only: the wide model path of the reference's constructor (dnnfeaturematcher.h:11, src/main.cpp:62) as UTF-8
+  if (msf::HipDNNFeatureMatcher::narrow(L"model/LoFTR_teacher.onnx") != "model/LoFTR_teacher.onnx" ||
+      msf::HipDNNFeatureMatcher::narrow(L"mod\u00e8le/\u20ac.onnx") != "mod\xc3\xa8le/\xe2\x82\xac.onnx" ||
+      msf::HipDNNFeatureMatcher::narrow(L"\U0001F600") != "\xf0\x9f\x98\x80" || !msf::HipDNNFeatureMatcher::narrow(L"").empty()) {
+    std::printf("wide path conversion\n");
+    return 3;
+  }
   const int W = 640, H = 480, STEP = 704;  // cv::Mat with a row step larger than the width
   std::vector<uint8_t> a((size_t)STEP * H), b((size_t)STEP * H);
   if (msf_synth_pair(0x5EED0000ull + 77, W, H, 9, -5, 0, 8, a.data(), STEP, b.data(), STEP)) return 1;

@@ -11,8 +11,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-pytestmark = pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") and shutil.which("hipcc") is None,
-                                reason="needs hipcc (cross-compiles without a GPU)")
+import asm_audit  # noqa: E402
+
+pytestmark = pytest.mark.skipif(asm_audit.hipcc() is None, reason="needs hipcc (cross-compiles without a GPU)")
 
 
 def _audit(which):

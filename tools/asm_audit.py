@@ -10,6 +10,7 @@ kernel that prefetches is the first thing to look at; so is a workgroup whose wa
 usage: tools/asm_audit.py [orb|loftr|pack|ransac ...]"""
 import os
 import re
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -20,10 +21,21 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fh
          "-fno-fast-math", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "--cuda-device-only", "-S"]
 
 
+def hipcc():
+    """the compiler build.py uses: $HIPCC, else hipcc on PATH, else /opt/rocm/bin/hipcc (None if there is none)"""
+    cand = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    return cand if (os.path.isabs(cand) and os.path.exists(cand)) or shutil.which(cand) else None
+
+
 def audit(src):
+    cc = hipcc()
+    if cc is None:
+        raise FileNotFoundError("no hipcc ($HIPCC, PATH, /opt/rocm/bin)")
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
-        subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + ["-o", out, src], check=True, stderr=subprocess.DEVNULL)
+        r = subprocess.run([cc] + FLAGS + ["-o", out, src], stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("%s failed on %s:\n%s" % (cc, src, r.stderr[-4000:]))
         lines = open(out).read().split("\n")
     stats, cur, inloop = {}, None, False
     for ln in lines:
