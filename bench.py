@@ -294,10 +294,9 @@ def run_workload(args, matcher, W, H, P, ratio_or_thr, loftr_f32, rank, world, l
                 roofline["f32_equiv_frac"] = round(achieved / MFMA_F32_PEAK_TFLOPS, 5)
             roofline["mfma_busy"] = mfma_busy_record(dom, P, loftr_f32)
         elif dom:
-            # a batch of >= 256 frames is extracted as two pipelined sub-batches: every batch kernel is launched once per
-            # part, stage times are sums over the parts, and "per launch" below is per part
-            # ... and the fused pyramid + FAST walker runs once per source level (7 launches per extraction)
-            launches = fm.extract_parts(2 * P) * fm.walker_launches(dom)
+            # the dominant kernel k_walk (pyramid + FAST of all levels) is ONE launch per step: the stage time between
+            # its two HIP events is that launch's duration (rocprofv3's average for k_walk must agree)
+            launches = fm.walker_launches(dom)
             achieved = P * bpp / (stages[dom] * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom,
                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

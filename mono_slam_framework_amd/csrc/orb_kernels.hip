@@ -514,28 +514,25 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
 // it finds every maximum >= its own tau, so every maximum >= the final tau[idx] (the maximum over the strips) is in the
 // list; k_fast_check counts those and a level that falls short is redone densely: the result is the dense one bit for
 // bit in every interleaving.
-constexpr int kTauBins = 64;             // score histogram bins of width 4 (k_fast_tau's sample, the emitted corners)
-constexpr int kQStat = kTauBins + 2;     // per (slot, level): the quarter's histogram, its strips done, spare
+constexpr int kTauBins = 64;             // score histogram bins of width 4 (the threshold sample, the emitted corners)
+// State of a (slot, level) while the walker launch runs: kQStat words, zeroed (hipMemsetAsync) before the launch, every
+// access an agent-scope atomic.  It is both the statistics the thresholds come from and the dependency tracking of the
+// one-launch form (see k_walk):
+//   [0, 64)   histogram of the FAST scores of the corners the level's sampled quarter emitted
+//   kQDone    strips of the quarter that are done (their histogram adds included)
+//   kQTau     the threshold in force: the largest refined threshold any strip published (atomicMax; 0 = none yet)
+//   kQFirst   kQReady | the first estimate, stored by the (frame, level)'s threshold unit once the level exists
+//   kQAll     strips of the level that are done: at wk_nx * wk_ny every pixel of level l + 1 has been written
+constexpr int kQDone = kTauBins, kQTau = kTauBins + 1, kQFirst = kTauBins + 2, kQAll = kTauBins + 3;
+constexpr int kQStat = kTauBins + 4;
+constexpr uint32_t kQReady = 0x80000000u;
 constexpr int RK = 16;                   // ring rows (power of two)
-#ifndef MSF_ABL_DESCRIBE
-#define MSF_ABL_DESCRIBE 0       // timing-only ablations of k_describe (1: patches from the L2, 2: no descriptor tests)
-#endif
-#ifndef MSF_WALK_REPS
-#define MSF_WALK_REPS 1          // strips per walker workgroup
-#endif
-#ifndef MSF_WALK_NOBRANCH
-#define MSF_WALK_NOBRANCH 0
-#endif
-#ifndef MSF_WALK_PREFETCH8
-#define MSF_WALK_PREFETCH8 0     // 1: a second row queue (loads requested eight rows ahead).  Measured the same as four; with the
-                                 // ring-phase copies of the group body the compiler copies the queues at the common flush site
-                                 // behind a vmcnt wait, so the effective distance is one group either way
-#endif
 constexpr int kWkMaxPx = 244;            // strip pitch <= 244: a group of 4 output px reads two aligned 8-byte pairs <= 8 B apart
-constexpr int kWkMaxRows = 112;          // owned rows per strip at most (a strip's emit table lives in two registers per lane);
-                                         // 80 measured best at 720p (48 / 64 / 80 / 96 / 112 rows: 8.19 / 7.97 / 7.83 / 7.88 / 7.96 ms per step)
-constexpr int kSGCap = 288, kSPCap = 256, kSHCap = 64, kSOCap = 32;   // 10 240 B of LDS per wave: exactly 16 waves per CU
-constexpr int kRespCap = 8192;           // per (slot, level): Harris responses of the walker's first kRespCap candidates
+constexpr int kWkMaxRows = 112;          // owned rows per strip at most (a strip's emit table lives in two registers per lane)
+constexpr int kWkRowsTarget = 80;        // owned rows per strip aimed at: 48 / 64 / 80 / 96 / 112 rows measured 8.19 / 7.97 / 7.83 /
+                                         // 7.88 / 7.96 ms per 720p step (r03), flat at 640 x 480
+constexpr int kTauSites = 1024;          // sampled runs of 4 px per (frame, level) of the threshold sampler (512 / 2048 / 4096: slower)
+constexpr int kSGCap = 288, kSPCap = 256, kSHCap = 64, kSOCap = 64;   // 10 240 B of LDS per wave: exactly 16 waves per CU
 constexpr uint32_t kSGFlush = 32;        // records that trigger a flush at the end of a four-step group (<= 4 x 64 more arrive)
 static_assert(kSGCap >= (int)kSGFlush + 256, "record list capacity");
 // A row put at step s overwrites rel row s - 13; pending records read pixel rows >= last_flush - 2 and pending NMS
@@ -553,7 +550,6 @@ struct StreamSmem {
   uint16_t p[kSPCap];        // pixel entries: byte in row | ring row << 8 | darker-type << 12
   uint16_t h[kSHCap];        // scored corners: byte in row | ring row << 8 (the rel row follows from the ring row)
   uint32_t opk[kSOCap];      // kept corners waiting for the next flush to global memory: byte in row | rel row << 8 | score << 16
-  float oresp[kSOCap];       // ... and their Harris responses
 };
 static_assert(sizeof(StreamSmem) == 10240, "16 waves per CU need 10 240 B per wave");
 
@@ -581,53 +577,51 @@ __device__ __forceinline__ int stream_score(const uint8_t* ring, uint32_t r0, ui
   return A > tau ? A - 1 : 0;
 }
 
-// Launch over the strips of levels [l_lo, l_hi] of n_frames frames.  Workgroups b, b + 8, ... share an XCD (observed
-// placement, speed only): XCD x takes the frames [x n / 8, (x + 1) n / 8) and runs first the sampled quarter of all their
-// strips, then the rest, so the lines neighbouring strips share stay in one L2 and a frame's quarter is long done when
-// its other strips start.  dyn = 0: no refinement (forced threshold, MSF_ORB_FAST_ONE_PART).  part = -1: all strips;
-// 0 / 1: only the sampled quarter / only the rest (small launches, whose strips would all start together, run as two).
-// one strip: unit u of XCD xcd in the launch's order
-template <bool RESIZE>
-__device__ __forceinline__ void walk_unit(StreamSmem& sm, const OrbGeometry& g, const FrameSrc& src, uint8_t* pyr,
-                                          const uint32_t* __restrict__ tab, uint32_t* tau, uint32_t* qstat,
-                                          uint32_t* cand_cnt, uint32_t* cand_key, uint8_t* cand_sc, float* cand_resp,
-                                          int l_lo, int l_hi, int n_frames, int margin_pct, int dyn, int part, int harris,
-                                          const int xcd, const int u) {
-  const int lane = threadIdx.x;
-  int fi, t;
-  bool quarter;
-  {
-    const int nf8 = n_frames >> 3, nrem = n_frames & 7;
-    const int nfx = nf8 + (xcd < nrem ? 1 : 0), f0 = xcd * nf8 + (xcd < nrem ? xcd : nrem);
-    const int S = g.lv[l_hi].wk_base + g.lv[l_hi].wk_nx * g.lv[l_hi].wk_ny - g.lv[l_lo].wk_base;
-    const int Sq = (S + 3) >> 2, Sr = S - Sq;
-    const int nq = part == 1 ? 0 : nfx * Sq;     // quarter units of this XCD in this launch
-    if (u < nq) {
-      fi = f0 + u / Sq;
-      t = 4 * (u % Sq);
-      quarter = true;
-    } else {
-      const int u2 = u - nq;
-      if (part == 0 || u2 >= nfx * Sr) return;
-      fi = f0 + u2 / Sr;
-      const int ip = u2 % Sr;
-      t = 4 * (ip / 3) + ip % 3 + 1;
-      quarter = false;
-    }
+// ---- the one-launch form: units, their order, and what a unit may wait for
+// A walker launch covers levels [l_lo, l_hi] of n_frames frames.  Per (frame, level) it holds one THRESHOLD unit (the
+// first estimate of the level's FAST threshold: predicted from the level above or sampled, tau_unit) and one unit per
+// strip; a unit is a workgroup of one wave.  Workgroups b, b + 8, ... share an XCD (observed placement, speed only): XCD
+// x takes the frames [x n / 8, (x + 1) n / 8) and walks, level by level, first the threshold units of its frames, then
+// the sampled quarter of all their strips (strip index a multiple of 4), then the rest -- so the lines neighbouring
+// strips share stay in one L2, and whatever a unit needs was started long before it.
+// Dependencies (chain = 1: the walker of level l - 1 makes level l):
+//   threshold unit (f, l), l > 0 : all strips of (f, l - 1) done            (kQAll of level l - 1: level l exists)
+//   strip of (f, l)              : the threshold of (f, l) published         (kQFirst; implies the line above)
+//   non-quarter strip, dyn       : the quarter of (f, l) done                (kQDone: the refined threshold)
+// Every wait is for units with a LOWER flat workgroup index, so with workgroups started in index order the lowest
+// unfinished one never waits and the launch drains; the waits are bounded all the same (kSpinMax polls of ~2 us): a unit
+// that gives up flags its frame (status, surfaced as n_out = -1), raises the launch's abort word -- every other waiter
+// then leaves at its next poll -- and the grid always terminates.  Results never depend on placement or timing: pixels
+// are handed over with write-through stores, a drained store queue, an agent-scope counter, and an agent-scope acquire
+// on the reading side; thresholds may differ from run to run in principle, the candidate lists they lead to contain
+// every corner retainBest(2N) can keep either way (k_fast_check).
+constexpr uint32_t kSpinMax = 1u << 19;
+
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// a unit gives up: its frame has no valid result, every waiter of the launch leaves
+__device__ __forceinline__ void unit_stall(uint32_t* status, int slot, uint32_t* abort_word, int lane) {
+  if (lane == 0) {
+    atomicOr(&status[slot], kStatusOverflow);
+    __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  const int tb = t + g.lv[l_lo].wk_base;        // flat strip index over all levels
-  int l = l_lo;
-#pragma unroll
-  for (int i = 1; i < kOrbLevels; i++)
-    if (i > l_lo && i <= l_hi && tb >= g.lv[i].wk_base) l = i;
+}
+
+// one strip: strip ts of level l of frame fi
+template <bool RESIZE>
+__device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g, const FrameSrc& src, uint8_t* pyr,
+                                           const uint32_t* __restrict__ tab, uint32_t* qstat, uint32_t* cand_cnt,
+                                           uint32_t* cand_key, uint8_t* cand_sc, uint32_t* status, uint32_t* abort_word,
+                                           int margin_pct, int dyn, int chain, const int l, const int fi, const int ts) {
+  const int lane = threadIdx.x;
+  const bool quarter = (ts & 3) == 0;
   const OrbLevelInfo L = g.lv[l];
   const int slot = src.slot0 + fi, idx = slot * kOrbLevels + l;
-  const int ts = tb - L.wk_base;
   const int sy = ts / L.wk_nx, sx = ts - sy * L.wk_nx;
   uint32_t* const qs = qstat + (size_t)idx * kQStat;
-  // strips of this level in the sampled quarter of this launch
-  const int rel0 = L.wk_base - g.lv[l_lo].wk_base, n_strips = L.wk_nx * L.wk_ny;
-  const int qa = (rel0 + n_strips + 3) / 4 - (rel0 + 3) / 4;
+  const int n_strips = L.wk_nx * L.wk_ny;
+  const int qa = (n_strips + 3) >> 2;            // strips of this level in the sampled quarter
   const bool count_me = dyn && quarter;          // single exit below: a quarter strip always reports itself done
 
   // ---- geometry of the strip
@@ -655,43 +649,64 @@ __device__ __forceinline__ void walk_unit(StreamSmem& sm, const OrbGeometry& g, 
   const uint32_t pitch_u = uniform_u32((uint32_t)pitch);       // a level is far below 4 GB: 32-bit row offsets
   const __amdgpu_buffer_rsrc_t img_rs = uniform_rsrc(img, (uint32_t)L.h * (uint32_t)pitch);
 #define LOAD_ROW(y_) ((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(img_rs, xoff, (uint32_t)max(min((y_), ylim), 0) * pitch_u, 0))
-  // the first ten pixel rows are requested before anything else: the state of the (frame, level) below is one more
-  // memory latency, and the two overlap (they were serial: +10 us on a 40-us strip)
-  uint32_t w0_ = LOAD_ROW(y0 - 3), w1_ = LOAD_ROW(y0 - 2), w2_ = LOAD_ROW(y0 - 1), w3_ = LOAD_ROW(y0), w4_ = LOAD_ROW(y0 + 1),
-           w5_ = LOAD_ROW(y0 + 2);
-  uint32_t q0 = LOAD_ROW(y0 + 3), q1 = LOAD_ROW(y0 + 4), q2 = LOAD_ROW(y0 + 5), q3 = LOAD_ROW(y0 + 6);
-#if MSF_WALK_PREFETCH8
-  // second queue: the rows of the group after (a group consumes and refills ONE of the two queues, so a load is requested
-  // two groups = eight rows before its use: one group's time is about the loaded memory latency)
-  uint32_t p0 = LOAD_ROW(y0 + 7), p1 = LOAD_ROW(y0 + 8), p2 = LOAD_ROW(y0 + 9), p3 = LOAD_ROW(y0 + 10);
-#endif
+  // Level 0 is the caller's frame: its first ten pixel rows are requested before anything else, together with the state
+  // of the (frame, level) -- one memory latency for both.  A level the walker made is only read once that state says it
+  // is complete (the threshold unit of this (frame, level) waited for it) and behind an acquire.
+  const bool early = !(chain && l > 0);          // uniform
+  uint32_t w0_ = 0, w1_ = 0, w2_ = 0, w3_ = 0, w4_ = 0, w5_ = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+  if (early) {
+    w0_ = LOAD_ROW(y0 - 3); w1_ = LOAD_ROW(y0 - 2); w2_ = LOAD_ROW(y0 - 1); w3_ = LOAD_ROW(y0); w4_ = LOAD_ROW(y0 + 1);
+    w5_ = LOAD_ROW(y0 + 2);
+    q0 = LOAD_ROW(y0 + 3); q1 = LOAD_ROW(y0 + 4); q2 = LOAD_ROW(y0 + 5); q3 = LOAD_ROW(y0 + 6);
+  }
 
-  // ---- threshold: the sampler's, raised from the quarter's exact corners when they are all in.  The whole state of the
-  // (frame, level) -- 64 bins, strips done, threshold in force -- comes in with two independent loads (one latency).
-  const uint32_t qv = __hip_atomic_load(&qs[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const uint32_t qx = __hip_atomic_load(&qs[kTauBins + (lane & 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  int tv = (int)__builtin_amdgcn_readlane((int)qx, 1);
-  if (dyn && !quarter && tv > kFastT && qa >= kTau2MinStrips) {
-    const uint32_t done = (uint32_t)__builtin_amdgcn_readlane((int)qx, 0);
-    if (done >= (uint32_t)qa) {     // uniform
-      uint32_t c = qv;
+  // ---- threshold: the first estimate, raised from the quarter's exact corners.  The whole state of the (frame, level)
+  // -- 64 bins and the four words behind them -- comes in with two independent loads (one latency).
+  const bool need_q = dyn && !quarter && qa >= kTau2MinStrips;
+  uint32_t qv = ld_agent(&qs[lane]);
+  uint32_t qx = ld_agent(&qs[kTauBins + (lane & 3)]);
+  {
+    bool ready = false;
+    for (uint32_t it = 0; it < kSpinMax; it++) {
+      const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)qx, kQFirst - kTauBins);
+      const uint32_t done = (uint32_t)__builtin_amdgcn_readlane((int)qx, kQDone - kTauBins);
+      ready = (first & kQReady) != 0u && (!need_q || done >= (uint32_t)qa);
+      if (ready || ld_agent(abort_word) != 0u) break;     // uniform
+      __builtin_amdgcn_s_sleep(20);
+      qv = ld_agent(&qs[lane]);
+      qx = ld_agent(&qs[kTauBins + (lane & 3)]);
+    }
+    if (!ready) {
+      unit_stall(status, slot, abort_word, lane);
+      return;
+    }
+  }
+  if (!early) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    w0_ = LOAD_ROW(y0 - 3); w1_ = LOAD_ROW(y0 - 2); w2_ = LOAD_ROW(y0 - 1); w3_ = LOAD_ROW(y0); w4_ = LOAD_ROW(y0 + 1);
+    w5_ = LOAD_ROW(y0 + 2);
+    q0 = LOAD_ROW(y0 + 3); q1 = LOAD_ROW(y0 + 4); q2 = LOAD_ROW(y0 + 5); q3 = LOAD_ROW(y0 + 6);
+  }
+  int tv = (int)((uint32_t)__builtin_amdgcn_readlane((int)qx, kQFirst - kTauBins) & ~kQReady);
+  tv = max(tv, (int)__builtin_amdgcn_readlane((int)qx, kQTau - kTauBins));
+  if (need_q && tv > kFastT) {
+    uint32_t c = qv;
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {   // suffix sums: c = corners of the quarter with score >= 4 * lane
-        const uint32_t up = __shfl_down(c, o);
-        if (lane + o < 64) c += up;
-      }
-      // a level with many sampled strips gives a steadier estimate and takes the smaller margin; an explicit
-      // MSF_ORB_TAU2_MARGIN_PCT applies to every level
-      const uint32_t mp = (qa >= kTau2ManyStrips && margin_pct == kTau2MarginPct) ? (uint32_t)kTau2MarginPctMany : (uint32_t)margin_pct;
-      const uint32_t den = 100u * (uint32_t)n_strips;
-      const uint32_t need = (mp * 2u * (uint32_t)L.quota * (uint32_t)qa + den - 1u) / den;
-      const unsigned long long ok = __ballot(c >= need && 4 * lane >= tv);
-      if (ok) {
-        const int t2 = 4 * (63 - __builtin_clzll(ok));
-        if (t2 > tv) {
-          tv = t2;
-          if (lane == 0) atomicMax(&qs[kTauBins + 1], (uint32_t)t2);
-        }
+    for (int o = 1; o < 64; o <<= 1) {   // suffix sums: c = corners of the quarter with score >= 4 * lane
+      const uint32_t up = __shfl_down(c, o);
+      if (lane + o < 64) c += up;
+    }
+    // a level with many sampled strips gives a steadier estimate and takes the smaller margin; an explicit
+    // MSF_ORB_TAU2_MARGIN_PCT applies to every level
+    const uint32_t mp = (qa >= kTau2ManyStrips && margin_pct == kTau2MarginPct) ? (uint32_t)kTau2MarginPctMany : (uint32_t)margin_pct;
+    const uint32_t den = 100u * (uint32_t)n_strips;
+    const uint32_t need = (mp * 2u * (uint32_t)L.quota * (uint32_t)qa + den - 1u) / den;
+    const unsigned long long ok = __ballot(c >= need && 4 * lane >= tv);
+    if (ok) {
+      const int t2 = 4 * (63 - __builtin_clzll(ok));
+      if (t2 > tv) {
+        tv = t2;
+        if (lane == 0) atomicMax(&qs[kQTau], (uint32_t)t2);
       }
     }
   }
@@ -718,7 +733,6 @@ __device__ __forceinline__ void walk_unit(StreamSmem& sm, const OrbGeometry& g, 
   uint32_t* const out_cnt = cand_cnt + idx;
   uint32_t* const outk = cand_key + (long long)slot * g.cand_total + L.cand_off;
   uint8_t* const outs = cand_sc + (long long)slot * g.cand_total + L.cand_off;
-  float* const outr = cand_resp + ((long long)slot * kOrbLevels + l) * kRespCap;
   const uint32_t out_cap = (uint32_t)L.cand_cap;
   uint32_t* pxw = reinterpret_cast<uint32_t*>(sm.px);
   uint32_t* scw = reinterpret_cast<uint32_t*>(sm.sc);
@@ -750,7 +764,7 @@ __device__ __forceinline__ void walk_unit(StreamSmem& sm, const OrbGeometry& g, 
     roff3 = rz_lane ? qov.w - (uint32_t)xs : 0u;
     dpitch = uniform_u32((uint32_t)Ld.pitch);
     dst_rs = uniform_rsrc(pyr + (long long)slot * g.pyr_bytes + Ld.pix_off, (uint32_t)Ld.h * (uint32_t)Ld.pitch);
-    dxoff = (MSF_WALK_NOBRANCH && !rz_lane) ? 0xFFFFFFF0u : 4u * (uint32_t)gq;
+    dxoff = 4u * (uint32_t)gq;
     // emit entries of the source rows R0 - 4 + j, j = lane (em_lo) and 64 + lane (em_hi): output row | w1 << 16 | 1 << 31
     // if an output row has source rows (y, y + 1) as its taps and y is owned by this strip
     const int ra = R0 - 4 + lane, rb = ra + 64;
@@ -782,23 +796,6 @@ __device__ __forceinline__ void walk_unit(StreamSmem& sm, const OrbGeometry& g, 
     h_[3] = udot2_u16(__builtin_amdgcn_perm(b1_, b0_, rsel[3]), rwxp[3], 0u);                                          \
   } while (0)
   // j_ = index of the UPPER source row in the strip's emit table (row R0 - 4 + j_); hu_ / hl_ = sums of the upper / lower row
-#if MSF_WALK_NOBRANCH
-  // straight-line form: the blend is computed whether or not an output row sits between the two source rows (5 of 6 do) and
-  // the store of a lane / row that has nothing to write is given an offset beyond the descriptor's range, which the
-  // hardware drops -- no branch, so the four rows' sums, blends and prefilters are one scheduling region
-#define RZ_EMIT(j_, hu_, hl_)                                                                                          \
-  do {                                                                                                                 \
-    const int jj_ = (j_);                                                                                              \
-    const uint32_t em_ = (uint32_t)__builtin_amdgcn_readlane((int)(jj_ < 64 ? em_lo : em_hi), jj_ & 63);               \
-    const uint32_t wy1_ = (em_ >> 16) & 0x1FFu, wy0_ = 256u - wy1_, rnd_ = 32768u;                                     \
-    const uint32_t v0_ = mad_u24_s(hu_[0], wy0_, mad_u24_s(hl_[0], wy1_, rnd_));                                       \
-    const uint32_t v1_ = mad_u24_s(hu_[1], wy0_, mad_u24_s(hl_[1], wy1_, rnd_));                                       \
-    const uint32_t v2_ = mad_u24_s(hu_[2], wy0_, mad_u24_s(hl_[2], wy1_, rnd_));                                       \
-    const uint32_t v3_ = mad_u24_s(hu_[3], wy0_, mad_u24_s(hl_[3], wy1_, rnd_));                                       \
-    const uint32_t pk_ = __builtin_amdgcn_perm(v1_, v0_, 0x0c0c0602u) | __builtin_amdgcn_perm(v3_, v2_, 0x06020c0cu);  \
-    __builtin_amdgcn_raw_buffer_store_b32(pk_, dst_rs, (int)em_ < 0 ? dxoff : 0xFFFFFFF0u, (em_ & 0xFFFFu) * dpitch, 0); \
-  } while (0)
-#else
 #define RZ_EMIT(j_, hu_, hl_)                                                                                          \
   do {                                                                                                                 \
     const int jj_ = (j_);                                                                                              \
@@ -811,14 +808,14 @@ __device__ __forceinline__ void walk_unit(StreamSmem& sm, const OrbGeometry& g, 
       const uint32_t v2_ = mad_u24_s(hu_[2], wy0_, mad_u24_s(hl_[2], wy1_, rnd_));                                     \
       const uint32_t v3_ = mad_u24_s(hu_[3], wy0_, mad_u24_s(hl_[3], wy1_, rnd_));                                     \
       const uint32_t pk_ = __builtin_amdgcn_perm(v1_, v0_, 0x0c0c0602u) | __builtin_amdgcn_perm(v3_, v2_, 0x06020c0cu); \
-      if (rz_lane) __builtin_amdgcn_raw_buffer_store_b32(pk_, dst_rs, dxoff, (em_ & 0xFFFFu) * dpitch, 0);              \
+      /* aux 16 = sc1: write-through, so that the level is in memory when this strip counts itself done (k_walk) */     \
+      if (rz_lane) __builtin_amdgcn_raw_buffer_store_b32(pk_, dst_rs, dxoff, (em_ & 0xFFFFu) * dpitch, 16);             \
     }                                                                                                                  \
   } while (0)
-#endif
 
   auto flush_out = [&]() {
     if (nO == 0) return;
-    MSF_WAVE_SYNC();                       // the responses lane 0 wrote are read by every lane below
+    MSF_WAVE_SYNC();
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(out_cnt, nO);
     base = __builtin_amdgcn_readfirstlane(base);
@@ -828,42 +825,10 @@ __device__ __forceinline__ void walk_unit(StreamSmem& sm, const OrbGeometry& g, 
         outk[base + i] = ((uint32_t)(y0 + (int)((pk >> 8) & 255u)) << 16) | (uint32_t)(xs + (int)(pk & 255u));
         outs[base + i] = (uint8_t)sc_;
       }
-      if (harris && base + i < (uint32_t)kRespCap) outr[base + i] = sm.oresp[i];
       if (count_me) atomicAdd(&qs[sc_ >> 2], 1u);     // the quarter's exact scores: what the other strips refine tau from
     }
     MSF_WAVE_SYNC();
     nO = 0;
-  };
-
-  // HarrisResponses (orb.cpp; blockSize 7) of buffered corner e, by the whole wave while the corner's 9 x 9 pixels are in
-  // the ring (a corner is kept in the flush that follows its row by at most 8 rows: rows rr - 4 .. rr + 4 are still there,
-  // and an owned column has 4 px of window either side).  Lane t < 49 takes block position (t / 7 - 3, t % 7 - 3): its
-  // Sobel pair from 8 ring bytes, Ix^2, Iy^2, Ix Iy, three wave sums (exact integers, any order), then the reference's
-  // f32 expression on one lane -- bit for bit harris_at's result (the stage-1 parity tests compare the bits).
-  // OPT-IN (MSF_ORB_WALKER_HARRIS=1): it removes k_thr_harris' 9-row patch fetches (HBM traffic of the step 22.3 -> 20.4 GB,
-  // select_harris 0.56 -> 0.17 ms) but costs the walker 0.70 ms -- a strip emits ~15 corners, each ~80 dependent
-  // instructions on a latency-bound wave, and half of them never survive retainBest(2N): 7.52 -> 7.89 ms per step.
-  auto harris_entry = [&](uint32_t e) {
-    const uint32_t pk = sm.opk[e];
-    const int t = lane < 49 ? lane : 48;
-    const int ty = (t * 37) >> 8;                                   // t / 7 for t < 49
-    const int xc = (int)(pk & 255u) + (t - 7 * ty) - 3, rc = (int)((pk >> 8) & 255u) + ty;   // ring index of the row = rel row + 3
-    const uint8_t* r0 = pxb + (((rc - 1) & (RK - 1)) << 8) + xc;
-    const uint8_t* r1 = pxb + ((rc & (RK - 1)) << 8) + xc;
-    const uint8_t* r2 = pxb + (((rc + 1) & (RK - 1)) << 8) + xc;
-    const int p00 = r0[-1], p01 = r0[0], p02 = r0[1], p10 = r1[-1], p12 = r1[1], p20 = r2[-1], p21 = r2[0], p22 = r2[1];
-    int ix = 2 * (p12 - p10) + (p02 - p00) + (p22 - p20);
-    int iy = 2 * (p21 - p01) + (p20 - p00) + (p22 - p02);
-    if (lane >= 49) ix = iy = 0;
-    const uint32_t a = __builtin_amdgcn_readlane(wave_incl_scan((uint32_t)(ix * ix)), 63);
-    const uint32_t b = __builtin_amdgcn_readlane(wave_incl_scan((uint32_t)(iy * iy)), 63);
-    const int c = (int)__builtin_amdgcn_readlane(wave_incl_scan((uint32_t)(ix * iy)), 63);
-    if (lane == 0) {
-      const float scale = 1.f / ((1 << 2) * 7 * 255.f);
-      const float scale_sq_sq = scale * scale * scale * scale;
-      const float fa = (float)(int)a, fb = (float)(int)b, fc = (float)c;
-      sm.oresp[e] = (fa * fb - fc * fc - 0.04f * (fa + fb) * (fa + fb)) * scale_sq_sq;
-    }
   };
 
   // append (keep ? one output : nothing) of every lane, in lane order; the two half-waves one after the other, so
@@ -881,8 +846,6 @@ __device__ __forceinline__ void walk_unit(StreamSmem& sm, const OrbGeometry& g, 
       if (nO + cnt > (uint32_t)kSOCap) flush_out();
       if (kh) sm.opk[nO + mbcnt64(bal)] = xl | (rr << 8) | (score << 16);
       MSF_WAVE_SYNC();
-      if (harris)
-        for (uint32_t e = nO; e < nO + cnt; e++) harris_entry(e);
       nO += cnt;
     }
   };
@@ -1046,31 +1009,16 @@ __device__ __forceinline__ void walk_unit(StreamSmem& sm, const OrbGeometry& g, 
     cb_ = ((b0_ | b8_) & (b4_ | b12_)) & (vmr_);                                                                       \
     cd_ = ~((n0_ & n8_) | (n4_ & n12_)) & (vmr_);                                                                      \
   } while (0)
-#if MSF_WALK_NOBRANCH
-  // every lane writes: a lane without a survivor to its own dword of the pixel-entry list, which only lives inside a flush
 #define STREAM_APPEND(s_, cb_, cd_)                                                                                    \
   do {                                                                                                                 \
     const bool has_ = ((cb_) | (cd_)) != 0u;                                                                           \
     const unsigned long long bal_ = __ballot(has_);                                                                    \
-    uint32_t* const dst_ = has_ ? &sm.g[nG + mbcnt64(bal_)] : &dump[lane];                                             \
-    *dst_ = (cb_) | ((cd_) >> 1) | lane_rec | ((((uint32_t)(s_) & 63u) << 8) | (((uint32_t)(s_) >> 6) << 16));         \
-    nG += (uint32_t)__popcll(bal_);                                                                                    \
-  } while (0)
-#else
-#define STREAM_APPEND(s_, cb_, cd_)                                                                                    \
-  do {                                                                                                                 \
-    const bool has_ = ((cb_) | (cd_)) != 0u;                                                                           \
-    const unsigned long long bal_ = __ballot(has_);                                                                    \
-    if (MSF_WALK_NOBRANCH || bal_) {   /* nearly every row of 256 px has a survivor: no wave-level skip */               \
+    if (bal_) {                                                                                                        \
       /* cb_ / cd_ hold bit 7 of each byte only: the flags stay where they are, lane and row go into the free low bits */ \
       if (has_) sm.g[nG + mbcnt64(bal_)] = (cb_) | ((cd_) >> 1) | lane_rec | ((((uint32_t)(s_) & 63u) << 8) | (((uint32_t)(s_) >> 6) << 16)); \
       nG += (uint32_t)__popcll(bal_);                                                                                  \
     }                                                                                                                  \
   } while (0)
-#endif
-  uint32_t* const dump = reinterpret_cast<uint32_t*>(sm.p);
-  (void)dump;
-  static_assert(sizeof(sm.p) >= 64 * 4, "dump dwords of the branch-free append");
   const uint32_t lane_rec = (uint32_t)lane;
   static_assert(kWkMaxRows + 8 < 128, "a record holds 7 bits of rel row");
   static_assert(RK == 16, "the group body below exists in four copies, one per position of the group in the 16-row ring");
@@ -1079,24 +1027,11 @@ __device__ __forceinline__ void walk_unit(StreamSmem& sm, const OrbGeometry& g, 
   // lane base + immediate offset (18 vector instructions per group went into ring addresses).  P_ = s mod 16.
   auto group = [&](auto ph_, const int s) {
     constexpr int P_ = decltype(ph_)::value * 4;
-#if MSF_WALK_PREFETCH8
-    constexpr bool kOdd = (decltype(ph_)::value & 1) != 0;
-    uint32_t& r0 = kOdd ? p0 : q0;
-    uint32_t& r1 = kOdd ? p1 : q1;
-    uint32_t& r2 = kOdd ? p2 : q2;
-    uint32_t& r3 = kOdd ? p3 : q3;
-    const uint32_t d0 = r0, d1 = r1, d2 = r2, d3 = r3;
-    PUT_ROW(P_ + 6, d0); r0 = LOAD_ROW(y0 + s + 11);
-    PUT_ROW(P_ + 7, d1); r1 = LOAD_ROW(y0 + s + 12);
-    PUT_ROW(P_ + 8, d2); r2 = LOAD_ROW(y0 + s + 13);
-    PUT_ROW(P_ + 9, d3); r3 = LOAD_ROW(y0 + s + 14);
-#else
     const uint32_t d0 = q0, d1 = q1, d2 = q2, d3 = q3;
     PUT_ROW(P_ + 6, d0); q0 = LOAD_ROW(y0 + s + 7);
     PUT_ROW(P_ + 7, d1); q1 = LOAD_ROW(y0 + s + 8);
     PUT_ROW(P_ + 8, d2); q2 = LOAD_ROW(y0 + s + 9);
     PUT_ROW(P_ + 9, d3); q3 = LOAD_ROW(y0 + s + 10);
-#endif
     const uint32_t u0 = pxw[((P_) & (RK - 1)) * 64 + lane], u1 = pxw[((P_ + 1) & (RK - 1)) * 64 + lane];
     const uint32_t u2 = pxw[((P_ + 2) & (RK - 1)) * 64 + lane], u3 = pxw[((P_ + 3) & (RK - 1)) * 64 + lane];   // = c0
     const uint32_t c1 = pxw[((P_ + 4) & (RK - 1)) * 64 + lane], c2 = pxw[((P_ + 5) & (RK - 1)) * 64 + lane];
@@ -1118,12 +1053,7 @@ __device__ __forceinline__ void walk_unit(StreamSmem& sm, const OrbGeometry& g, 
     uint32_t cb0, cd0, cb1, cd1, cb2, cd2, cb3, cd3;
     // rows outside the strip's scored rows [s_lo, s_hi] only occur in its first and last groups: one test per group
     uint32_t vm0 = vm, vm1 = vm, vm2 = vm, vm3 = vm;
-    if (MSF_WALK_NOBRANCH) {
-      vm0 = (s >= s_lo && s <= s_hi) ? vm : 0u;
-      vm1 = (s + 1 >= s_lo && s + 1 <= s_hi) ? vm : 0u;
-      vm2 = (s + 2 >= s_lo && s + 2 <= s_hi) ? vm : 0u;
-      vm3 = (s + 3 >= s_lo && s + 3 <= s_hi) ? vm : 0u;
-    } else if (s < s_lo || s + 3 > s_hi) {
+    if (s < s_lo || s + 3 > s_hi) {
       vm0 = (s >= s_lo && s <= s_hi) ? vm : 0u;
       vm1 = (s + 1 >= s_lo && s + 1 <= s_hi) ? vm : 0u;
       vm2 = (s + 2 >= s_lo && s + 2 <= s_hi) ? vm : 0u;
@@ -1160,26 +1090,15 @@ __device__ __forceinline__ void walk_unit(StreamSmem& sm, const OrbGeometry& g, 
 #undef RZ_HSUM
 #undef RZ_EMIT
   }
-  if (count_me) {
-    // every histogram add of this strip is complete before the strip counts as done (agent-scope atomics both sides)
+  if (count_me || RESIZE) {
+    // Every store of this strip has left the wave's queue before the strip counts as done: the write-through stores of
+    // level l + 1's pixels are then in memory (what the next level's units wait for) and the histogram adds have been
+    // performed (agent-scope atomics both sides).  Inline asm: the compiler may not drop or move this wait.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) atomicAdd(&qs[kTauBins], 1u);
-  }
-}
-
-// A workgroup (one wave) walks MSF_WALK_REPS consecutive units of its XCD.
-template <bool RESIZE>
-__global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_t* pyr, const uint32_t* __restrict__ tab,
-                                             uint32_t* tau, uint32_t* qstat, uint32_t* cand_cnt, uint32_t* cand_key,
-                                             uint8_t* cand_sc, float* cand_resp, int l_lo, int l_hi, int n_frames,
-                                             int margin_pct, int dyn, int part, int harris) {
-  __shared__ StreamSmem sm;
-  const int xcd = (int)(blockIdx.x & 7u), v = (int)(blockIdx.x >> 3);
-#pragma unroll 1
-  for (int rep = 0; rep < MSF_WALK_REPS; rep++) {
-    walk_unit<RESIZE>(sm, g, src, pyr, tab, tau, qstat, cand_cnt, cand_key, cand_sc, cand_resp, l_lo, l_hi, n_frames, margin_pct,
-                      dyn, part, harris, xcd, v * MSF_WALK_REPS + rep);
-    MSF_WAVE_SYNC();
+    if (lane == 0) {
+      if (count_me) atomicAdd(&qs[kQDone], 1u);
+      if (RESIZE) atomicAdd(&qs[kQAll], 1u);
+    }
   }
 }
 
@@ -1222,65 +1141,82 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
   return x;
 }
 
-// One workgroup per (level, frame).  Sampled pixels: rows samp_sy apart with a hashed jitter, columns samp_sx apart --
-// odd, hashed phase per row, so a periodic texture is not aliased.  Only the upper tail of the score distribution
-// matters, so a sample first takes the cardinal test at kTauPre (5 byte loads; every pixel with score >= kTauPre passes
-// it) and only the survivors, compacted in LDS, get the exact score: the histogram is exact from kTauPre upwards.
-// tau = the largest multiple of 4 with enough sample hits at or above it, fastThreshold (dense) if there is none.
+// The threshold unit of (frame fi, level l): one wave.  Sampled pixels: rows samp_sy apart with a hashed jitter, columns
+// samp_sx apart -- odd, hashed phase per row, so a periodic texture is not aliased.  Only the upper tail of the score
+// distribution matters, so a sample first takes the cardinal test at kTauPre (5 byte loads; every pixel with score >=
+// kTauPre passes it) and only the survivors, compacted in LDS, get the exact score: the histogram is exact from kTauPre
+// upwards.  tau = the largest multiple of 4 with enough sample hits at or above it, fastThreshold (dense) if there is none.
 constexpr int kTauPre = 40, kTauPreHigh = 64;
 constexpr int kTauListCap = 2048;     // prefilter survivors kept per (frame, level); the rest are dropped (fewer hits: a
                                       // lower, still valid, tau)
-__global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, const uint8_t* pyr, int force_tau,
-                                                  uint32_t* tau, uint32_t* tau_first, uint32_t* redo_cnt,
-                                                  uint32_t* redo_list, int level0, uint32_t* qstat, int fi_base,
-                                                  int predict_pct) {
-  __shared__ uint32_t hist[kTauBins];
-  __shared__ uint32_t list[kTauListCap];
-  __shared__ uint32_t nlist;
-  __shared__ int predicted;
-  const int l = level0 + blockIdx.x, fi = blockIdx.y, slot = src.slot0 + fi, tid = threadIdx.x;
+struct TauSmem {
+  uint32_t hist[kTauBins];
+  uint32_t nlist, pad[3];
+  uint32_t list[kTauListCap];
+};
+static_assert(sizeof(TauSmem) <= sizeof(StreamSmem), "the threshold unit works in the walker's LDS block");
+
+__device__ __forceinline__ void tau_unit(TauSmem& T, const OrbGeometry& g, const FrameSrc& src, const uint8_t* pyr,
+                                         uint32_t* tau, uint32_t* tau_first, uint32_t* redo_cnt, uint32_t* redo_list,
+                                         uint32_t* qstat, uint32_t* status, uint32_t* abort_word, int force_tau,
+                                         int predict_pct, int chain, const int l, const int fi) {
+  const int lane = threadIdx.x, slot = src.slot0 + fi, idx = slot * kOrbLevels + l;
   const OrbLevelInfo L = g.lv[l];
-  // the walker's refinement state of this (frame, level): histogram and done count start at 0, word kTauBins + 1 is the
-  // threshold in force (written below; the walker raises it with atomicMax, k_fast_check copies it to tau[])
-  if (tid <= kTauBins) qstat[(size_t)(slot * kOrbLevels + l) * kQStat + tid] = 0;
-  int tv = kFastT, pre_used = kTauPre;
-  // Prediction from the level above (predict_pct > 0; fused chain only: the walker of level l - 1 has finished).  The
-  // sampled quarter of level l - 1 left the histogram of its exact corners; level l shows the same scene 1.2 x smaller,
-  // so the first threshold of level l is the largest multiple of 4 at which level l - 1 -- scaled from the quarter to
-  // the level -- still holds predict_pct % of the corner DENSITY level l needs for its 2N.  It only steers the quarter of
-  // level l (the rest refines from that quarter's own corners) and k_fast_check + the dense redo catch an overshoot, so
-  // whatever comes out here the result is the dense one.  No usable histogram (a dense level above, fewer than two
-  // sampled strips, too few corners): the sampler below runs as before.
-  if (tid == 0) predicted = 0;
-  __syncthreads();
-  if (predict_pct > 0 && force_tau == 0 && l > 0 && L.tiles_x > 0 && tid < 64) {
+  uint32_t* const qs = qstat + (size_t)idx * kQStat;
+  int tv = kFastT, pre_used = kTauPre, predicted = 0;
+  if (chain && l > 0) {
+    // level l exists once every strip of level l - 1 has counted itself done (walk_strip's last lines)
     const OrbLevelInfo Lp = g.lv[l - 1];
-    const uint32_t* pq = qstat + (size_t)(slot * kOrbLevels + l - 1) * kQStat;
-    const int n_strips = Lp.wk_nx * Lp.wk_ny, qa = (n_strips + 3) / 4;    // a fused launch covers one level: its quarter
-    const uint32_t done = pq[kTauBins], t_q = tau_first[slot * kOrbLevels + l - 1];
-    uint32_t c = pq[tid];
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t up = __shfl_down(c, o);
-      if (tid + o < 64) c += up;
+    const uint32_t* pq = qstat + (size_t)(idx - 1) * kQStat;
+    const int n_prev = Lp.wk_nx * Lp.wk_ny, qa = (n_prev + 3) >> 2;
+    uint32_t pv = ld_agent(&pq[lane]);
+    uint32_t px = ld_agent(&pq[kTauBins + (lane & 3)]);
+    bool ready = false;
+    for (uint32_t it = 0; it < kSpinMax; it++) {
+      ready = (uint32_t)__builtin_amdgcn_readlane((int)px, kQAll - kTauBins) >= (uint32_t)n_prev;
+      if (ready || ld_agent(abort_word) != 0u) break;     // uniform
+      __builtin_amdgcn_s_sleep(20);
+      pv = ld_agent(&pq[lane]);
+      px = ld_agent(&pq[kTauBins + (lane & 3)]);
     }
-    if (qa >= kTau2MinStrips && done >= (uint32_t)qa && t_q > (uint32_t)kFastT) {
-      const long long a_prev = (long long)(Lp.w - 2 * kEdge) * (Lp.h - 2 * kEdge), a_cur = (long long)(L.w - 2 * kEdge) * (L.h - 2 * kEdge);
-      // corners the QUARTER must hold at or above t: predict_pct % x 2N_l x (area above / area here) x (quarter / level)
-      const long long need = ((long long)predict_pct * 2 * L.quota * a_prev * qa + 100ll * a_cur * n_strips - 1) / (100ll * a_cur * n_strips);
-      const unsigned long long ok = __ballot((long long)c >= need && 4u * tid >= t_q);
-      if (ok && tid == 0) predicted = 4 * (63 - __builtin_clzll(ok));
+    if (!ready) {
+      unit_stall(status, slot, abort_word, lane);
+      return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // the sampler below reads level l's pixels
+    // Prediction from the level above (predict_pct > 0).  The sampled quarter of level l - 1 left the histogram of its
+    // exact corners; level l shows the same scene 1.2 x smaller, so the first threshold of level l is the largest
+    // multiple of 4 at which level l - 1 -- scaled from the quarter to the level -- still holds predict_pct % of the
+    // corner DENSITY level l needs for its 2N.  It only steers the quarter of level l (the rest refines from that
+    // quarter's own corners) and k_fast_check + the dense redo catch an overshoot, so whatever comes out here the result
+    // is the dense one.  No usable histogram (a dense level above, fewer than two sampled strips, too few corners): the
+    // sampler below runs.
+    if (predict_pct > 0 && force_tau == 0 && L.tiles_x > 0) {
+      const uint32_t done = (uint32_t)__builtin_amdgcn_readlane((int)px, kQDone - kTauBins);
+      const uint32_t t_q = (uint32_t)__builtin_amdgcn_readlane((int)px, kQFirst - kTauBins) & ~kQReady;
+      uint32_t c = pv;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_down(c, o);
+        if (lane + o < 64) c += up;
+      }
+      if (qa >= kTau2MinStrips && done >= (uint32_t)qa && t_q > (uint32_t)kFastT) {
+        const long long a_prev = (long long)(Lp.w - 2 * kEdge) * (Lp.h - 2 * kEdge), a_cur = (long long)(L.w - 2 * kEdge) * (L.h - 2 * kEdge);
+        // corners the QUARTER must hold at or above t: predict_pct % x 2N_l x (area above / area here) x (quarter / level)
+        const long long need = ((long long)predict_pct * 2 * L.quota * a_prev * qa + 100ll * a_cur * n_prev - 1) / (100ll * a_cur * n_prev);
+        const unsigned long long ok = __ballot((long long)c >= need && 4u * (uint32_t)lane >= t_q);
+        if (ok) predicted = 4 * (63 - __builtin_clzll(ok));
+      }
     }
   }
-  __syncthreads();
   if (predicted > kFastT) {
     tv = predicted;
   } else if (force_tau > 0) {
     tv = force_tau;
   } else if (L.samp_rows > 0) {
-    if (tid < kTauBins) hist[tid] = 0;
-    if (tid == 0) nlist = 0;
-    __syncthreads();
+    if (lane < kTauBins) T.hist[lane] = 0;
+    if (lane == 0) T.nlist = 0;
+    MSF_WAVE_SYNC();
     int pitch;
     const uint8_t* img = level_ptr(g, src, pyr, fi, l, &pitch);
     const int rh = L.h - 2 * kEdge;
@@ -1294,95 +1230,136 @@ __global__ __launch_bounds__(256) void k_fast_tau(OrbGeometry g, FrameSrc src, c
     need_hits = need_hits < (uint32_t)kTauMinHits ? (uint32_t)kTauMinHits : need_hits;
     int pre = kTauPreHigh;
     for (int attempt = 0; attempt < 2; attempt++) {
-    const uint32_t lb = 0x01010101u * (uint32_t)(128 - pre / 2), lnd = 0x01010101u * (uint32_t)(255 - (254 - pre) / 2);
-    const int x_first = (kEdge + 3) & ~3;                                  // first dword fully inside [31, w - 31)
-    const int n_dw = (L.w - kEdge - x_first) >> 2;                         // dwords fully inside
-    for (int j0 = 0; j0 < L.samp_rows; j0 += 4) {
-      for (int k = tid; k < L.samp_cols; k += 256) {
-        uint32_t Cv[4], Lv[4], Rv[4], Uv[4], Dv[4], pos[4];
+      const uint32_t lb = 0x01010101u * (uint32_t)(128 - pre / 2), lnd = 0x01010101u * (uint32_t)(255 - (254 - pre) / 2);
+      const int x_first = (kEdge + 3) & ~3;                                  // first dword fully inside [31, w - 31)
+      const int n_dw = (L.w - kEdge - x_first) >> 2;                         // dwords fully inside
+      for (int j0 = 0; j0 < L.samp_rows; j0 += 4) {
+        for (int k = lane; k < L.samp_cols; k += 64) {
+          uint32_t Cv[4], Lv[4], Rv[4], Uv[4], Dv[4], pos[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int j = min(j0 + u, L.samp_rows - 1);
-          const uint32_t hj = hash_u32((uint32_t)(l * 4099 + j) * 2654435761u + 12345u);
-          int y = j * L.samp_sy + (int)(hj % (uint32_t)L.samp_sy);
-          y = kEdge + (y < rh ? y : rh - 1);
-          int d = k * L.samp_sx + (int)((hj >> 16) % (uint32_t)L.samp_sx);   // dword index of the run
-          d = d < n_dw ? d : n_dw - 1;
-          const int x = x_first + 4 * d;
-          const uint8_t* p = img + (long long)y * pitch + x;
-          Cv[u] = *reinterpret_cast<const uint32_t*>(p);
-          Lv[u] = *reinterpret_cast<const uint32_t*>(p - 4);
-          Rv[u] = *reinterpret_cast<const uint32_t*>(p + 4);
-          Uv[u] = *reinterpret_cast<const uint32_t*>(p - 3 * pitch);
-          Dv[u] = *reinterpret_cast<const uint32_t*>(p + 3 * pitch);
-          pos[u] = ((uint32_t)y << 16) | (uint32_t)x;
-        }
+          for (int u = 0; u < 4; u++) {
+            const int j = min(j0 + u, L.samp_rows - 1);
+            const uint32_t hj = hash_u32((uint32_t)(l * 4099 + j) * 2654435761u + 12345u);
+            int y = j * L.samp_sy + (int)(hj % (uint32_t)L.samp_sy);
+            y = kEdge + (y < rh ? y : rh - 1);
+            int d = k * L.samp_sx + (int)((hj >> 16) % (uint32_t)L.samp_sx);   // dword index of the run
+            d = d < n_dw ? d : n_dw - 1;
+            const int x = x_first + 4 * d;
+            const uint8_t* p = img + (long long)y * pitch + x;
+            Cv[u] = *reinterpret_cast<const uint32_t*>(p);
+            Lv[u] = *reinterpret_cast<const uint32_t*>(p - 4);
+            Rv[u] = *reinterpret_cast<const uint32_t*>(p + 4);
+            Uv[u] = *reinterpret_cast<const uint32_t*>(p - 3 * pitch);
+            Dv[u] = *reinterpret_cast<const uint32_t*>(p + 3 * pitch);
+            pos[u] = ((uint32_t)y << 16) | (uint32_t)x;
+          }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const uint32_t W3 = __builtin_amdgcn_alignbyte(Cv[u], Lv[u], 1), E3 = __builtin_amdgcn_alignbyte(Rv[u], Cv[u], 3);
-          const uint32_t nC = ~Cv[u];
-          const uint32_t l0 = __builtin_amdgcn_lerp(Dv[u], nC, 0), l4 = __builtin_amdgcn_lerp(E3, nC, 0);
-          const uint32_t l8 = __builtin_amdgcn_lerp(Uv[u], nC, 0), l12 = __builtin_amdgcn_lerp(W3, nC, 0);
-          const uint32_t cb = (__builtin_amdgcn_lerp(l0, lb, 0) | __builtin_amdgcn_lerp(l8, lb, 0)) &
-                              (__builtin_amdgcn_lerp(l4, lb, 0) | __builtin_amdgcn_lerp(l12, lb, 0));
-          const uint32_t cd = ~((__builtin_amdgcn_lerp(l0, lnd, 0) & __builtin_amdgcn_lerp(l8, lnd, 0)) |
-                                (__builtin_amdgcn_lerp(l4, lnd, 0) & __builtin_amdgcn_lerp(l12, lnd, 0)));
-          uint32_t m = (cb | cd) & 0x80808080u;
-          if (j0 + u >= L.samp_rows) m = 0u;
-          if (m) {
-            const uint32_t idx = atomicAdd(&nlist, (uint32_t)__popc(m));
-            uint32_t q = idx;
+          for (int u = 0; u < 4; u++) {
+            const uint32_t W3 = __builtin_amdgcn_alignbyte(Cv[u], Lv[u], 1), E3 = __builtin_amdgcn_alignbyte(Rv[u], Cv[u], 3);
+            const uint32_t nC = ~Cv[u];
+            const uint32_t l0 = __builtin_amdgcn_lerp(Dv[u], nC, 0), l4 = __builtin_amdgcn_lerp(E3, nC, 0);
+            const uint32_t l8 = __builtin_amdgcn_lerp(Uv[u], nC, 0), l12 = __builtin_amdgcn_lerp(W3, nC, 0);
+            const uint32_t cb = (__builtin_amdgcn_lerp(l0, lb, 0) | __builtin_amdgcn_lerp(l8, lb, 0)) &
+                                (__builtin_amdgcn_lerp(l4, lb, 0) | __builtin_amdgcn_lerp(l12, lb, 0));
+            const uint32_t cd = ~((__builtin_amdgcn_lerp(l0, lnd, 0) & __builtin_amdgcn_lerp(l8, lnd, 0)) |
+                                  (__builtin_amdgcn_lerp(l4, lnd, 0) & __builtin_amdgcn_lerp(l12, lnd, 0)));
+            uint32_t m = (cb | cd) & 0x80808080u;
+            if (j0 + u >= L.samp_rows) m = 0u;
+            if (m) {
+              const uint32_t idx0 = atomicAdd(&T.nlist, (uint32_t)__popc(m));
+              uint32_t q = idx0;
 #pragma unroll
-            for (int b4 = 0; b4 < 4; b4++)
-              if ((m >> (8 * b4 + 7)) & 1u) {
-                if (q < (uint32_t)kTauListCap) list[q] = pos[u] + (uint32_t)b4;
-                q++;
-              }
+              for (int b4 = 0; b4 < 4; b4++)
+                if ((m >> (8 * b4 + 7)) & 1u) {
+                  if (q < (uint32_t)kTauListCap) T.list[q] = pos[u] + (uint32_t)b4;
+                  q++;
+                }
+            }
           }
         }
       }
-    }
-    __syncthreads();
-    // about one survivor of the cardinal test in four or five scores above the test's threshold
-    if (attempt == 1 || nlist >= 6u * need_hits) break;   // uniform
-    __syncthreads();
-    if (tid == 0) nlist = 0;
-    pre = kTauPre;
-    __syncthreads();
+      MSF_WAVE_SYNC();
+      // about one survivor of the cardinal test in four or five scores above the test's threshold
+      if (attempt == 1 || T.nlist >= 6u * need_hits) break;   // uniform
+      MSF_WAVE_SYNC();
+      if (lane == 0) T.nlist = 0;
+      pre = kTauPre;
+      MSF_WAVE_SYNC();
     }
     pre_used = pre;
-    __syncthreads();
-    const uint32_t n = min(nlist, (uint32_t)kTauListCap);
-    for (uint32_t i = tid; i < n; i += 256) {
-      const uint32_t e = list[i];
+    const uint32_t n = min(T.nlist, (uint32_t)kTauListCap);
+    for (uint32_t i = lane; i < n; i += 64) {
+      const uint32_t e = T.list[i];
       const int sc = fast_score_px(img + (long long)(e >> 16) * pitch + (e & 0xFFFFu), pitch);
-      if (sc >= pre_used) atomicAdd(&hist[sc >> 2], 1u);
+      if (sc >= pre_used) atomicAdd(&T.hist[sc >> 2], 1u);
     }
-    __syncthreads();
-    if (tid < 64) {
-      // suffix sums over the 64 bins: c = hits with score >= 4 * tid
-      uint32_t c = hist[tid];
+    MSF_WAVE_SYNC();
+    {
+      // suffix sums over the 64 bins: c = hits with score >= 4 * lane
+      uint32_t c = T.hist[lane];
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         const uint32_t up = __shfl_down(c, o);
-        if (tid + o < 64) c += up;
+        if (lane + o < 64) c += up;
       }
-      const uint32_t factor = (uint32_t)(L.samp_sx * L.samp_sy);
-      uint32_t need = ((uint32_t)kTauOversample * 2u * (uint32_t)L.quota + factor - 1u) / factor;
-      need = need < (uint32_t)kTauMinHits ? (uint32_t)kTauMinHits : need;
-      const unsigned long long ok = __ballot(c >= need && 4 * tid >= pre_used);
+      const unsigned long long ok = __ballot(c >= need_hits && 4 * lane >= pre_used);
       const int top = ok ? 63 - __builtin_clzll(ok) : 0;     // largest qualifying bin
       tv = ok ? 4 * top : kFastT;                            // too few strong corners: dense
     }
+    MSF_WAVE_SYNC();                                         // the LDS block is the next unit's
   }
-  if (tid == 0) {
-    tau[slot * kOrbLevels + l] = (uint32_t)tv;
-    tau_first[slot * kOrbLevels + l] = (uint32_t)tv;
-    qstat[(size_t)(slot * kOrbLevels + l) * kQStat + kTauBins + 1] = (uint32_t)tv;
+  if (lane == 0) {
+    tau[idx] = (uint32_t)tv;
+    tau_first[idx] = (uint32_t)tv;
     // nothing to gain from a threshold: straight to the dense pass
-    // (fi_base: this launch covers the frames from fi_base on of the batch the redo queue belongs to)
-    if (tv <= kFastT && L.tiles_x > 0) redo_list[atomicAdd(redo_cnt, 1u)] = (uint32_t)((fi_base + fi) * kOrbLevels + l);
+    if (tv <= kFastT && L.tiles_x > 0) redo_list[atomicAdd(redo_cnt, 1u)] = (uint32_t)(fi * kOrbLevels + l);
+    // the strips of this (frame, level) start from here
+    __hip_atomic_store(&qs[kQFirst], kQReady | (uint32_t)tv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+// The walker launch: see "the one-launch form" above walk_strip.  resize_mask bit l: the strips of level l also make
+// level l + 1.  One wave per workgroup, one unit per workgroup.
+__global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_t* pyr, const uint32_t* __restrict__ tab,
+                                             uint32_t* tau, uint32_t* tau_first, uint32_t* qstat, uint32_t* cand_cnt,
+                                             uint32_t* cand_key, uint8_t* cand_sc, uint32_t* redo_cnt, uint32_t* redo_list,
+                                             uint32_t* status, uint32_t* abort_word, int l_lo, int l_hi, int n_frames,
+                                             int margin_pct, int dyn, int force_tau, int predict_pct, int chain,
+                                             int resize_mask) {
+  __shared__ StreamSmem sm;
+  const int xcd = (int)(blockIdx.x & 7u);
+  int r = (int)(blockIdx.x >> 3);                // unit of this XCD
+  const int nf8 = n_frames >> 3, nrem = n_frames & 7;
+  const int nfx = nf8 + (xcd < nrem ? 1 : 0), f0 = xcd * nf8 + (xcd < nrem ? xcd : nrem);
+  int l = l_lo, S = 0;
+  for (;; l++) {
+    if (l > l_hi) return;                        // surplus workgroups of an XCD with one frame fewer
+    S = g.lv[l].wk_nx * g.lv[l].wk_ny;
+    const int units = nfx * (1 + S);
+    if (r < units) break;
+    r -= units;
+  }
+  if (r < nfx) {
+    tau_unit(*reinterpret_cast<TauSmem*>(&sm), g, src, pyr, tau, tau_first, redo_cnt, redo_list, qstat, status, abort_word,
+             force_tau, predict_pct, chain, l, f0 + r);
+    return;
+  }
+  r -= nfx;
+  const int Sq = (S + 3) >> 2, Sr = S - Sq;
+  int fi, ts;
+  if (r < nfx * Sq) {
+    fi = f0 + r / Sq;
+    ts = 4 * (r % Sq);
+  } else {
+    r -= nfx * Sq;
+    fi = f0 + r / Sr;
+    const int ip = r % Sr;
+    ts = 4 * (ip / 3) + ip % 3 + 1;
+  }
+  if ((resize_mask >> l) & 1)
+    walk_strip<true>(sm, g, src, pyr, tab, qstat, cand_cnt, cand_key, cand_sc, status, abort_word, margin_pct, dyn, chain, l, fi, ts);
+  else
+    walk_strip<false>(sm, g, src, pyr, tab, qstat, cand_cnt, cand_key, cand_sc, status, abort_word, margin_pct, dyn, chain, l, fi, ts);
 }
 
 // After the walker: tau[idx] is the largest threshold any strip of the (frame, level) ran at, and every strict maximum
@@ -1396,7 +1373,7 @@ __global__ __launch_bounds__(64) void k_fast_check(OrbGeometry g, int slot0, int
   if (fi >= n_frames || l >= g.nlevels) return;
   const int idx = (slot0 + fi) * kOrbLevels + l;
   if (tau[idx] <= (uint32_t)kFastT) return;
-  const uint32_t T = max(tau[idx], qstat[(size_t)idx * kQStat + kTauBins + 1]);   // the largest threshold any strip ran at
+  const uint32_t T = max(tau[idx], qstat[(size_t)idx * kQStat + kQTau]);   // the largest threshold any strip ran at
   const OrbLevelInfo L = g.lv[l];
   const uint32_t n = min(cand_cnt[idx], (uint32_t)L.cand_cap);   // an overflowed list is flagged by k_thr_harris
   const uint8_t* scs = cand_sc + (long long)(slot0 + fi) * g.cand_total + L.cand_off;
@@ -1499,9 +1476,7 @@ __device__ __forceinline__ float harris_at(const uint8_t* img, int step, int x0,
 __global__ __launch_bounds__(256) void k_thr_harris(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
                                                     const uint32_t* cand_cnt, const uint32_t* cand_key,
                                                     const uint8_t* cand_sc,
-                                                    uint32_t* s1_cnt, uint4* s1, uint32_t* status,
-                                                    const uint32_t* __restrict__ tau, const float* __restrict__ cand_resp,
-                                                    int do_harris) {
+                                                    uint32_t* s1_cnt, uint4* s1, uint32_t* status, int do_harris) {
   __shared__ uint32_t hist[256];
   __shared__ uint32_t thr_s, lcount;
   // Launched with 256 threads when the candidate lists are the dense ones (tens of thousands per level) and with one
@@ -1518,11 +1493,6 @@ __global__ __launch_bounds__(256) void k_thr_harris(OrbGeometry g, FrameSrc src,
   }
   const uint32_t* keys = cand_key + (long long)slot * g.cand_total + L.cand_off;
   const uint8_t* scs = cand_sc + (long long)slot * g.cand_total + L.cand_off;   // 16-byte aligned (cand_off % 16 == 0)
-  // A list the streaming walker made (threshold above fastThreshold, not redone densely) carries the Harris response of
-  // every candidate: the walker computed it while the pixels were in its ring (k_walk, harris_entry).  Lists of the dense
-  // tile kernel (and a walker list longer than kRespCap) get theirs here, from the pyramid.
-  const bool have_resp = tau != nullptr && tau[slot * kOrbLevels + l] > (uint32_t)kFastT && n <= (uint32_t)kRespCap;
-  const float* resp = cand_resp + ((long long)slot * kOrbLevels + l) * kRespCap;
   uint4* out = s1 + (long long)slot * g.s1_total + L.s1_off;
   for (uint32_t b = tid; b < 256u; b += nt) hist[b] = 0;
   if (tid == 0) lcount = 0;
@@ -1582,15 +1552,15 @@ __global__ __launch_bounds__(256) void k_thr_harris(OrbGeometry g, FrameSrc src,
       const int b = __ffs(mask) - 1;
       mask &= mask - 1;
       if (k < (uint32_t)kS1Cap)
-        out[k] = make_uint4(keys[i + b], have_resp ? __float_as_uint(resp[i + b]) : 0u, (w[b >> 2] >> (8 * (b & 3))) & 255u, 0u);
+        out[k] = make_uint4(keys[i + b], 0u, (w[b >> 2] >> (8 * (b & 3))) & 255u, 0u);
       k++;
     }
   }
   __syncthreads();
-  // pass 2: Harris response on dense lanes (lists without stored responses)
+  // pass 2: Harris response on dense lanes
   // (batches leave this pass to k_harris_flat: there the kept candidates of ALL (frame, level)s are spread evenly over
   // waves of one round each, instead of one wave per (frame, level) walking up to four dependent rounds)
-  const uint32_t kept = (have_resp || !do_harris) ? 0u : min(lcount, (uint32_t)kS1Cap);
+  const uint32_t kept = !do_harris ? 0u : min(lcount, (uint32_t)kS1Cap);
   for (uint32_t i = tid; i < kept; i += nt) {
     const uint32_t key = out[i].x;
     const float r = harris_at(img, pitch, key & 0xFFFF, key >> 16);
@@ -1613,18 +1583,8 @@ struct HarrisUnits {
   int base[kOrbLevels + 1];    // first unit of level l; base[nlevels] = units per frame
   int n[kOrbLevels];
 };
-#ifndef MSF_HARRIS_FLAT_WPE
-#define MSF_HARRIS_FLAT_WPE 0      // > 0: cap k_harris_flat's registers for this many waves per SIMD (A/B builds)
-#endif
-#if MSF_HARRIS_FLAT_WPE
-#define MSF_HARRIS_FLAT_ATTR __attribute__((amdgpu_waves_per_eu(MSF_HARRIS_FLAT_WPE, MSF_HARRIS_FLAT_WPE)))
-#else
-#define MSF_HARRIS_FLAT_ATTR
-#endif
-__global__ __launch_bounds__(256) MSF_HARRIS_FLAT_ATTR void k_harris_flat(OrbGeometry g, FrameSrc src, const uint8_t* pyr, HarrisUnits hw,
-                                                     const uint32_t* __restrict__ s1_cnt, uint4* s1,
-                                                     const uint32_t* __restrict__ cand_cnt,
-                                                     const uint32_t* __restrict__ tau) {
+__global__ __launch_bounds__(256) void k_harris_flat(OrbGeometry g, FrameSrc src, const uint8_t* pyr, HarrisUnits hw,
+                                                     const uint32_t* __restrict__ s1_cnt, uint4* s1) {
   const int fi = blockIdx.y, slot = src.slot0 + fi, lane = threadIdx.x & 63;
   const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (u >= hw.base[g.nlevels]) return;
@@ -1634,10 +1594,6 @@ __global__ __launch_bounds__(256) MSF_HARRIS_FLAT_ATTR void k_harris_flat(OrbGeo
     if (i < g.nlevels && u >= hw.base[i]) l = i;
   const OrbLevelInfo L = g.lv[l];
   const uint32_t kept = min(s1_cnt[slot * kOrbLevels + l], (uint32_t)kS1Cap);
-  // lists whose responses the walker made (MSF_ORB_WALKER_HARRIS=1): the condition k_thr_harris applies
-  if (tau != nullptr && tau[slot * kOrbLevels + l] > (uint32_t)kFastT &&
-      min(cand_cnt[slot * kOrbLevels + l], (uint32_t)L.cand_cap) <= (uint32_t)kRespCap)
-    return;
   uint4* out = s1 + (long long)slot * g.s1_total + L.s1_off;
   int pitch;
   const uint8_t* img = level_ptr(g, src, pyr, fi, l, &pitch);
@@ -1854,11 +1810,7 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
     // offset xo (keypoints sit >= 31 px inside the level, so this never leaves the row)
     const int ax = ((int)m.y - PR) & ~3;
     xo_pre = ((int)m.y - PR) - ax;
-#if MSF_ABL_DESCRIBE == 1
-    gptr_t base = img_ + (long long)(40 + (k & 7)) * pitch_ + (ax & 63);     // timing only: every patch from the L2
-#else
     gptr_t base = img_ + (long long)((int)m.z - PR) * pitch_ + ax;
-#endif
 #pragma unroll
     for (int u = 0; u < NPL; u++) {
       const int i = lane + 64 * u;
@@ -1969,7 +1921,7 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
       constexpr uint32_t K2 = SUM256 ? 48 : 49, K3 = SUM256 ? 56 : 55;
       constexpr uint32_t P0 = 18u | 34u << 16, P1 = K2 | K3 << 16, P2 = K2 | 34u << 16, P3 = 18u;
 #pragma unroll
-      for (int t = 0; t < (MSF_ABL_DESCRIBE == 2 ? 0 : 4); t++) {
+      for (int t = 0; t < 4; t++) {
         uint32_t val[2];
 #pragma unroll
         for (int e = 0; e < 2; e++) {
@@ -2214,37 +2166,17 @@ static void make_table(int src, int dst, uint32_t* tab) {
 OrbPipeline::~OrbPipeline() { destroy(); }
 
 void OrbPipeline::destroy() {
-  hipFree(d_tau_); hipFree(d_redo_); hipFree(d_qstat_); d_tau_ = nullptr; d_redo_ = nullptr; d_qstat_ = nullptr;
-  hipFree(d_pyr_); hipFree(d_tab_); hipFree(d_cand_cnt_); hipFree(d_cand_); hipFree(d_cand_sc_); hipFree(d_cand_resp_); d_cand_resp_ = nullptr; hipFree(d_qres_); hipFree(d_done_); hipFree(d_s1_cnt_); hipFree(d_s1_);
+  hipFree(d_tau_); hipFree(d_redo_); hipFree(d_qstat_); hipFree(d_walk_abort_);
+  d_tau_ = nullptr; d_redo_ = nullptr; d_qstat_ = nullptr; d_walk_abort_ = nullptr;
+  hipFree(d_pyr_); hipFree(d_tab_); hipFree(d_cand_cnt_); hipFree(d_cand_); hipFree(d_cand_sc_); hipFree(d_qres_); hipFree(d_done_); hipFree(d_s1_cnt_); hipFree(d_s1_);
   hipFree(d_kp_); hipFree(d_desc_); hipFree(d_kp_cnt_); hipFree(d_status_);
   d_pyr_ = nullptr; d_tab_ = nullptr; d_cand_cnt_ = nullptr; d_cand_ = nullptr; d_cand_sc_ = nullptr; d_qres_ = nullptr; d_done_ = nullptr; d_s1_cnt_ = nullptr;
   d_s1_ = nullptr; d_kp_ = nullptr; d_desc_ = nullptr; d_kp_cnt_ = nullptr; d_status_ = nullptr;
   if (ev_ok_) {
-    for (auto& set : evr_) {
+    for (auto& set : evr_)
       for (auto& e : set.ev) if (e) hipEventDestroy(e);
-      for (auto& e : set.ev2) if (e) hipEventDestroy(e);
-    }
   }
   ev_ok_ = false;
-  if (split_stream_) {
-    hipStreamSynchronize(split_stream_);
-    for (auto& ev : split_ev_) if (ev) hipEventDestroy(ev);
-    for (auto& ev : split_pyr_) if (ev) hipEventDestroy(ev);
-    hipStreamDestroy(split_stream_);
-    split_stream_ = nullptr;
-    hipFree(d_redo2_);
-    d_redo2_ = nullptr;
-  }
-  for (int k = 1; k < kMaxChains - 1; k++)
-    if (chain_stream_[k]) { hipStreamSynchronize(chain_stream_[k]); hipStreamDestroy(chain_stream_[k]); chain_stream_[k] = nullptr; }
-  for (auto& e : chain_ev_) if (e) { hipEventDestroy(e); e = nullptr; }
-  chain_stream_[0] = nullptr;
-  if (tau_stream_) {
-    hipStreamSynchronize(tau_stream_);
-    for (auto& e : tau_ev_) hipEventDestroy(e);
-    hipStreamDestroy(tau_stream_);
-    tau_stream_ = nullptr;
-  }
 }
 
 #define MSF_HIP_TRY(expr)                                                                 \
@@ -2272,35 +2204,20 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   // MSF_ORB_RESIZE_GENERIC=1: k_resize reads every pixel's taps from its own dword pair (the fallback for level
   // geometries whose column table fails the shared-pair check; tests compare the two)
   if (const char* e = getenv("MSF_ORB_RESIZE_GENERIC")) resize_generic_ = atoi(e) != 0;
-  // MSF_ORB_FAST_ONE_PART=1: the streaming FAST pass over all strips at the sampler's threshold (no second estimate)
+  // MSF_ORB_FAST_ONE_PART=1: the streaming FAST pass over all strips at the first threshold (no prediction, no refinement)
   if (const char* e = getenv("MSF_ORB_FAST_ONE_PART")) fast_two_part_ = atoi(e) == 0;
-  // MSF_ORB_UNFUSED=1: the pyramid by k_resize and one FAST-only walker launch over all levels (the r02 structure; tests
-  // compare it with the fused default, in which the walker of level l - 1 also makes level l)
+  // MSF_ORB_UNFUSED=1: the pyramid by k_resize and one FAST-only walker launch over all levels (the fallback for level
+  // geometries whose tables fail the host checks below; tests compare it with the fused default, in which the walker of
+  // level l - 1 also makes level l)
   if (const char* e = getenv("MSF_ORB_UNFUSED")) fused_ = atoi(e) == 0;
-  // MSF_ORB_WALK_ROUND: a walker launch whose sampled quarter has fewer strips than this runs as two launches (tests: 0
-  // = always one launch, refinement depending on dispatch timing; a huge value = always two)
-  if (const char* e = getenv("MSF_ORB_WALK_ROUND")) walk_round_ = atoll(e);
-  // MSF_ORB_WALKER_HARRIS=1: the walker computes the Harris response of every corner it emits from its pixel ring and
-  // k_thr_harris only ranks (default 0: k_thr_harris computes the responses of the kept candidates from the pyramid)
-  if (const char* e = getenv("MSF_ORB_WALKER_HARRIS")) walker_harris_ = atoi(e);
-  if (const char* e = getenv("MSF_ORB_HARRIS_FLAT")) harris_flat_ = atoi(e);
-  if (const char* e = getenv("MSF_ORB_CHAIN_MERGE")) { const int v = atoi(e); if (v >= 1) chain_merge_level_ = v; }
-  if (const char* e = getenv("MSF_ORB_DESC_BX")) { const int v = atoi(e); if (v >= 1 && v <= 128) desc_bx_min_ = v; }
+  // MSF_ORB_WALK_PER_LEVEL=1: the fused walker as one launch per level instead of one launch over all levels (tests
+  // compare the two: the in-launch dependency waits are then met the moment a unit starts)
+  if (const char* e = getenv("MSF_ORB_WALK_PER_LEVEL")) walk_per_level_ = atoi(e) != 0;
   // MSF_ORB_TAU_PREDICT: percent of the needed corner density the prediction of a level's first threshold from the level
-  // above keeps (0 = sample every level, the r02 behaviour)
+  // above keeps (0 = sample every level)
   if (const char* e = getenv("MSF_ORB_TAU_PREDICT")) {
     const int v = atoi(e);
     if (v >= 0 && v <= 2000) tau_predict_pct_ = v;
-  }
-  // MSF_ORB_TAU_SITES: sampled runs of 4 px per (frame, level) of the threshold sampler (tuning; default 1024)
-  if (const char* e = getenv("MSF_ORB_TAU_SITES")) {
-    const int v = atoi(e);
-    if (v >= 128 && v <= 65536) tau_sites_ = v;
-  }
-  // MSF_ORB_WALK_ROWS: rows a walker strip owns (tuning; 32 .. 112)
-  if (const char* e = getenv("MSF_ORB_WALK_ROWS")) {
-    const int v = atoi(e);
-    if (v >= 32 && v <= kWkMaxRows) wk_rows_target_ = v;
   }
   // MSF_ORB_TAU2_MARGIN_PCT: the second estimate's safety margin in percent of 2N (tests: a few percent makes it overshoot,
   // so that levels fail the check and take the dense second pass)
@@ -2376,7 +2293,7 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     // walker strips over the whole level: 256-px windows wk_px apart ((nx - 1) * wk_px + 256 >= w), wk_rows owned rows
     L.wk_nx = L.w > 256 ? (L.w - 256 + kWkMaxPx - 1) / kWkMaxPx + 1 : 1;
     L.wk_px = L.wk_nx > 1 ? (((L.w - 256 + L.wk_nx - 2) / (L.wk_nx - 1)) + 3) & ~3 : kWkMaxPx;
-    L.wk_ny = (L.h + wk_rows_target_ - 1) / wk_rows_target_;
+    L.wk_ny = (L.h + kWkRowsTarget - 1) / kWkRowsTarget;
     L.wk_rows = (((L.h + L.wk_ny - 1) / L.wk_ny) + 3) & ~3;
     L.wk_ny = (L.h + L.wk_rows - 1) / L.wk_rows;
     L.wk_base = strips;
@@ -2392,7 +2309,7 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     if (L.tiles_x > 0) {
       const int rh = L.h - 2 * kEdge;
       const int n_dw = (L.w - kEdge - ((kEdge + 3) & ~3)) >> 2;          // aligned dwords fully inside [31, w - 31)
-      const double s2 = (double)n_dw * rh / (double)tau_sites_;         // (dword, row) sites per sampled run
+      const double s2 = (double)n_dw * rh / (double)kTauSites;          // (dword, row) sites per sampled run
       int sx = (int)(sqrt(s2 > 1.0 ? s2 : 1.0) / 4.0);
       sx = (sx < 1 ? 1 : sx) | 1;
       int sy = (int)(s2 / sx + 0.5);
@@ -2489,7 +2406,8 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   MSF_HIP_TRY(hipMemset(d_qstat_, 0, S * kOrbLevels * kQStat * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMalloc(&d_cand_, S * g.cand_total * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMalloc(&d_cand_sc_, S * g.cand_total));
-  MSF_HIP_TRY(hipMalloc(&d_cand_resp_, S * kOrbLevels * kRespCap * sizeof(float)));
+  MSF_HIP_TRY(hipMalloc(&d_walk_abort_, 16));
+  MSF_HIP_TRY(hipMemset(d_walk_abort_, 0, 16));
   MSF_HIP_TRY(hipMalloc(&d_s1_cnt_, S * kOrbLevels * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMalloc(&d_s1_, S * g.s1_total * sizeof(uint4)));
   MSF_HIP_TRY(hipMalloc(&d_kp_, S * kKpCap * sizeof(msf_keypoint)));
@@ -2524,79 +2442,31 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     MSF_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_disc), disc.data(), sizeof(uint32_t) * 2 * kDiscTasks));
   }
   if (profile_) {
-    for (auto& set : evr_) {
+    for (auto& set : evr_)
       for (auto& e : set.ev) MSF_HIP_TRY(hipEventCreate(&e));
-      for (auto& e : set.ev2) MSF_HIP_TRY(hipEventCreate(&e));
-    }
     ev_ok_ = true;
   }
-  if (!getenv("MSF_ORB_NO_SIDE_STREAM")) {
-    MSF_HIP_TRY(hipStreamCreateWithFlags(&tau_stream_, hipStreamNonBlocking));
-    chain_stream_[0] = tau_stream_;
-    for (int k = 1; k < kMaxChains - 1; k++) MSF_HIP_TRY(hipStreamCreateWithFlags(&chain_stream_[k], hipStreamNonBlocking));
-    for (auto& e : chain_ev_) MSF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    if (getenv("MSF_ORB_ONE_CHAIN")) chains_ = 1;
-    if (const char* e = getenv("MSF_ORB_CHAINS")) {
-      const int v = atoi(e);
-      if (v >= 1 && v <= kMaxChains) chains_ = v;
-    }
-    const int parts = getenv("MSF_ORB_SPLIT2") ? atoi(getenv("MSF_ORB_SPLIT2")) : 0;   // opt-in: see orb_pipeline.h
-    if (parts >= 2) {
-      MSF_HIP_TRY(hipStreamCreateWithFlags(&split_stream_, hipStreamNonBlocking));
-      for (auto& ev : split_ev_) MSF_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-      for (auto& ev : split_pyr_) MSF_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-      split_parts_ = parts < 2 ? 2 : parts > 8 ? 8 : parts;
-      MSF_HIP_TRY(hipMalloc(&d_redo2_, (1 + (size_t)S * kOrbLevels) * sizeof(uint32_t)));
-    }
-    for (auto& e : tau_ev_) MSF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  }
   return "";
+}
+
+__global__ __launch_bounds__(256) void k_fill_u32(uint32_t* a, uint32_t* b, uint32_t v, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { a[i] = v; b[i] = v; }
 }
 
 hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
   if (n <= 0) return hipSuccess;
   if (src.slot0 < 0 || src.slot0 + n > max_slots_) return hipErrorInvalidValue;
   last_src_ = src;
-  last_split_ = false;
   if (ev_ok_) ev_begin_call();
-  if (split_stream_ && n >= 256) {
-    // K parts, alternately on the caller's stream and the second one; part k's pyramid starts when part k-1's is done
-    last_split_ = true;
-    const int K = ev_ok_ ? 2 : split_parts_;                // stage events exist for two parts
-    hipEvent_t evs0[5] = {ev_[0], ev_[1], ev_[2], ev_[3], ev_[6]};   // ev_[4] = start of the match stage: after the join
-    hipEventRecord(split_ev_[0], st);                       // everything queued on st so far precedes all parts
-    hipStreamWaitEvent(split_stream_, split_ev_[0], 0);
-    int f0 = 0;
-    for (int k = 0; k < K; k++) {
-      const int f1 = (int)((long long)n * (k + 1) / K), cnt = f1 - f0;
-      FrameSrc sk = src;
-      sk.slot0 = src.slot0 + f0;
-      if (f0 <= src.n_a) { sk.a = src.a + (long long)f0 * src.frame_stride; sk.n_a = src.n_a - f0; }
-      else { sk.n_a = 0; sk.b = src.b + (long long)(f0 - src.n_a) * src.frame_stride; }
-      hipStream_t sk_st = (k & 1) ? split_stream_ : st;
-      if (k > 0) hipStreamWaitEvent(sk_st, split_pyr_[(k - 1) & 7], 0);
-      hipEvent_t* evs = !ev_ok_ ? nullptr : k == 0 ? evs0 : k == 1 ? ev2_ : nullptr;
-      hipError_t e = extract_range(sk, cnt, sk_st, (k & 1) ? d_redo2_ : d_redo_, k == 0, evs, split_pyr_[k & 7]);
-      if (e != hipSuccess) return e;
-      f0 = f1;
-    }
-    hipEventRecord(split_ev_[2], split_stream_);
-    hipStreamWaitEvent(st, split_ev_[2], 0);
-    if (ev_ok_) {
-      hipEventRecord(ev_[4], st);
-      ev_extract_pending_ = true;
-    }
-    return hipGetLastError();
-  }
-  const hipError_t e = extract_range(src, n, st, d_redo_, true, ev_ok_ ? ev_ : nullptr, nullptr);
+  const hipError_t e = extract_range(src, n, st, ev_ok_ ? ev_ : nullptr);
   if (ev_ok_) ev_extract_pending_ = true;
   return e;
 }
 
-// one sub-batch: pyramid, FAST, selection, descriptors of frames src[0 .. n) on stream st; evs (or null): five events
-// recorded at the stage boundaries (start, pyramid, FAST, selection, descriptors done)
-hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st, uint32_t* d_redo_, bool allow_side,
-                                      hipEvent_t* evs, hipEvent_t pyramid_done) {
+// pyramid, FAST, selection, descriptors of frames src[0 .. n) on stream st; evs (or null): five events recorded at the
+// stage boundaries (start, pyramid + FAST, check + redo, selection, descriptors done)
+hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st, hipEvent_t* evs) {
   const OrbGeometry& g = g_;
   hipError_t e;
   if ((e = hipMemsetAsync(d_cand_cnt_ + (size_t)src.slot0 * kOrbLevels, 0, (size_t)n * kOrbLevels * 4, st))) return e;
@@ -2631,117 +2501,46 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
                        (size_t)lds_rows * sw16 + 8 * kResizeMaxRows, st, g, src, d_pyr_, d_tab_, l, rth, lds_rows, magic_n16,
                        magic_groups);
   };
-  // strips of levels [l_lo, l_hi] of the frames of `fs`: 8 x ceil(nf / 8) frames x strips workgroups of one wave (see
-  // k_walk for the order).  A launch whose sampled quarter is less than one round of the chip (16 waves x 256 CUs)
-  // would start all its strips together and refine nothing: it runs as two launches, the quarter and then the rest.
-  auto launch_walk = [&](bool resize, int l_lo, int l_hi, const FrameSrc& fs, int nf, hipStream_t s_) {
-    const int S = g.lv[l_hi].wk_base + g.lv[l_hi].wk_nx * g.lv[l_hi].wk_ny - g.lv[l_lo].wk_base;
-    const int Sq = (S + 3) / 4, Sr = S - Sq;
-    const unsigned f8 = 8u * (unsigned)((nf + 7) / 8);
-    const bool two = dyn && Sr > 0 && (long long)nf * Sq < walk_round_;
-    for (int part = two ? 0 : -1; part <= (two ? 1 : -1); part++) {
-      const unsigned units = part < 0 ? (unsigned)S : part == 0 ? (unsigned)Sq : (unsigned)Sr;
-      const unsigned wgs = 8u * (((f8 / 8u) * units + MSF_WALK_REPS - 1) / MSF_WALK_REPS);
-      if (resize)
-        hipLaunchKernelGGL(k_walk<true>, dim3(wgs), dim3(64), 0, s_, g, fs, d_pyr_, d_tab_, tau, d_qstat_, d_cand_cnt_,
-                           d_cand_, d_cand_sc_, d_cand_resp_, l_lo, l_hi, nf, tau2_margin_pct_, dyn, part, walker_harris_);
-      else
-        hipLaunchKernelGGL(k_walk<false>, dim3(wgs), dim3(64), 0, s_, g, fs, d_pyr_, d_tab_, tau, d_qstat_, d_cand_cnt_,
-                           d_cand_, d_cand_sc_, d_cand_resp_, l_lo, l_hi, nf, tau2_margin_pct_, dyn, part, walker_harris_);
-    }
-  };
-  // frames [f0, f0 + cnt) of src as a source of their own
-  auto sub_src = [&](int f0) {
-    FrameSrc sk = src;
-    sk.slot0 = src.slot0 + f0;
-    if (f0 <= src.n_a) { sk.a = src.a + (long long)f0 * src.frame_stride; sk.n_a = src.n_a - f0; }
-    else { sk.n_a = 0; sk.b = src.b + (long long)(f0 - src.n_a) * src.frame_stride; }
-    return sk;
+  // the units of levels [l_lo, l_hi]: per XCD ceil(n / 8) frames x (1 threshold unit + the level's strips), see k_walk
+  auto launch_walk = [&](int l_lo, int l_hi, int chain, int resize_mask, int predict_pct) {
+    long long per_frame = 0;
+    for (int l = l_lo; l <= l_hi; l++) per_frame += 1 + g.lv[l].wk_nx * g.lv[l].wk_ny;
+    const long long wgs = 8ll * ((n + 7) / 8) * per_frame;
+    hipLaunchKernelGGL(k_walk, dim3((unsigned)wgs), dim3(64), 0, st, g, src, d_pyr_, d_tab_, tau, tau_first, d_qstat_,
+                       d_cand_cnt_, d_cand_, d_cand_sc_, d_redo_, d_redo_ + 1, d_status_, d_walk_abort_, l_lo, l_hi, n,
+                       tau2_margin_pct_, dyn, force_tau, predict_pct, chain, resize_mask);
   };
   last_fused_ = fused;
+  if (!dense && g.total_tiles > 0) {
+    // the walker's per-(frame, level) state starts from zero: histograms, counters, "threshold published" words
+    if ((e = hipMemsetAsync(d_qstat_ + (size_t)src.slot0 * kOrbLevels * kQStat, 0, (size_t)n * kOrbLevels * kQStat * 4, st))) return e;
+    if ((e = hipMemsetAsync(d_walk_abort_, 0, 16, st))) return e;
+  }
   if (fused) {
-    // The walker of level l - 1 makes level l and finds level l - 1's corners in one pass over its pixels.  Its
-    // threshold comes from the sampler, which needs level l - 1 to exist: sampler and walker alternate.  The sampler is
-    // a short latency-bound kernel that leaves the chip nearly idle (8 x 68 us per step when everything is one chain),
-    // so a large batch runs as two chains of half the frames on two streams: one half's samplers run beside the other
-    // half's walkers.  Both chains lie between the same two stage events.
-    // step l of a chain: the sampler of level l, then the walker of level l (which makes level l + 1)
-    auto chain_step = [&](int l, const FrameSrc& fs, int nf, int f0, hipStream_t s_) {
-      hipLaunchKernelGGL(k_fast_tau, dim3(1, nf), dim3(256), 0, s_, g, fs, d_pyr_, force_tau, tau, tau_first, d_redo_,
-                         d_redo_ + 1, l, d_qstat_, f0, (l > 0 && dyn) ? tau_predict_pct_ : 0);
-      if (l + 1 < g.nlevels) launch_walk(true, l, l, fs, nf, s_);
-      else launch_walk(false, l, l, fs, nf, s_);
-    };
-    auto chain = [&](const FrameSrc& fs, int nf, int f0, hipStream_t s_) {
-      for (int l = 0; l < g.nlevels; l++) chain_step(l, fs, nf, f0, s_);
-    };
-    // chains_ parts of the batch (default 2; MSF_ORB_CHAINS, MSF_ORB_ONE_CHAIN=1), each at least 128 frames
-    int K = (allow_side && tau_stream_ != nullptr) ? chains_ : 1;
-    while (K > 1 && n / K < 128) K--;
-    if (K > 1) {
-      // the chains are enqueued level by level in turn, so that they start together (chain by chain, the second one's
-      // first kernel waited for the host to enqueue the first chain's sixteen)
-      hipEventRecord(tau_ev_[0], st);
-      FrameSrc fsk[kMaxChains];
-      int f0k[kMaxChains], nfk[kMaxChains];
-      hipStream_t sk[kMaxChains];
-      for (int k = 0, f0 = 0; k < K; k++) {
-        const int f1 = (int)((long long)n * (k + 1) / K);
-        fsk[k] = k == 0 ? src : sub_src(f0);
-        f0k[k] = f0;
-        nfk[k] = f1 - f0;
-        sk[k] = k == 0 ? st : chain_stream_[k - 1];
-        if (k > 0) hipStreamWaitEvent(sk[k], tau_ev_[0], 0);
-        f0 = f1;
-      }
-      const int l_merge = chain_merge_level_ < g.nlevels ? chain_merge_level_ : g.nlevels;
-      for (int l = 0; l < l_merge; l++)
-        for (int k = 0; k < K; k++) chain_step(l, fsk[k], nfk[k], f0k[k], sk[k]);
-      for (int k = 1; k < K; k++) {
-        hipEventRecord(chain_ev_[k - 1], sk[k]);
-        hipStreamWaitEvent(st, chain_ev_[k - 1], 0);
-      }
-      // MSF_ORB_CHAIN_MERGE=l: from level l on, one chain over all frames (twice the strips per launch on the small levels)
-      for (int l = l_merge; l < g.nlevels; l++) chain_step(l, src, n, 0, st);
+    // ONE launch: the walker of level l - 1 makes level l and finds level l - 1's corners in one pass over its pixels;
+    // the thresholds, the order of the levels and the refinement are dependencies between the launch's units (k_walk).
+    // r03 ran this stage as 2 chains x 8 levels x (sampler launch + walker launch): a fifth of its wave-slot time was
+    // the tails of those 32 launches.
+    const int mask = (1 << (g.nlevels - 1)) - 1;          // every level but the last also makes the next one
+    const int predict = dyn ? tau_predict_pct_ : 0;
+    if (walk_per_level_) {
+      for (int l = 0; l < g.nlevels; l++) launch_walk(l, l, 1, mask, predict);
     } else {
-      chain(src, n, 0, st);
+      launch_walk(0, g.nlevels - 1, 1, mask, predict);
     }
     if (evs) hipEventRecord(evs[1], st);
-    if (pyramid_done) hipEventRecord(pyramid_done, st);
   } else {
-    // k_fast_tau is a light, latency-bound kernel (one workgroup per (frame, level), scattered loads): for a batch it
-    // runs level by level on a side stream underneath the pyramid kernels, each level as soon as it exists
-    const bool side = allow_side && tau_stream_ != nullptr && n >= 64 && g.total_tiles > 0 && !dense;
-    if (side) {
-      hipEventRecord(tau_ev_[0], st);
-      hipStreamWaitEvent(tau_stream_, tau_ev_[0], 0);
-      hipLaunchKernelGGL(k_fast_tau, dim3(1, n), dim3(256), 0, tau_stream_, g, src, d_pyr_, force_tau, tau, tau_first, d_redo_,
-                         d_redo_ + 1, 0, d_qstat_, 0, 0);
-    }
-    for (int l = 1; l < g.nlevels; l++) {
-      launch_resize(l);
-      if (side) {
-        hipEventRecord(tau_ev_[l], st);
-        hipStreamWaitEvent(tau_stream_, tau_ev_[l], 0);
-        hipLaunchKernelGGL(k_fast_tau, dim3(1, n), dim3(256), 0, tau_stream_, g, src, d_pyr_, force_tau, tau, tau_first,
-                           d_redo_, d_redo_ + 1, l, d_qstat_, 0, 0);
-      }
-    }
+    for (int l = 1; l < g.nlevels; l++) launch_resize(l);
     if (evs) hipEventRecord(evs[1], st);
-    if (pyramid_done) hipEventRecord(pyramid_done, st);   // the next part may start (after FAST / selection instead: 9.26 / 9.29 vs 9.07 ms)
     if (g.total_tiles > 0) {
-      if (side) {
-        hipEventRecord(tau_ev_[kOrbLevels], tau_stream_);
-        hipStreamWaitEvent(st, tau_ev_[kOrbLevels], 0);
-      } else {
-        hipLaunchKernelGGL(k_fast_tau, dim3(g.nlevels, n), dim3(256), 0, st, g, src, d_pyr_, force_tau, tau, tau_first, d_redo_,
-                           d_redo_ + 1, 0, d_qstat_, 0, 0);
-      }
       if (dense) {   // MSF_FLAG_FAST_DENSE / a call of a few frames: the plain detector over every tile, nothing to verify
+        hipLaunchKernelGGL(k_fill_u32, dim3((n * kOrbLevels + 255) / 256), dim3(256), 0, st, tau + (size_t)src.slot0 * kOrbLevels,
+                           tau_first + (size_t)src.slot0 * kOrbLevels, (uint32_t)kFastT, n * kOrbLevels);
         hipLaunchKernelGGL(k_fast, dim3((unsigned)g.total_tiles * (unsigned)n), dim3(kFastThreads), 0, st, g, src, d_pyr_,
                            d_cand_cnt_, d_cand_, d_cand_sc_);
       } else {
-        launch_walk(false, 0, g.nlevels - 1, src, n, st);
+        // every level exists: FAST-only strips, every level's first threshold from its own sample
+        launch_walk(0, g.nlevels - 1, 0, 0, 0);
       }
     }
   }
@@ -2757,10 +2556,8 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
   }
   if (evs) hipEventRecord(evs[2], st);
   hipLaunchKernelGGL(k_thr_harris, dim3(g.nlevels, n), dim3(dense ? 256 : 64), 0, st, g, src, d_pyr_,
-                     d_cand_cnt_, d_cand_, d_cand_sc_, d_s1_cnt_, d_s1_, d_status_,
-                     (const uint32_t*)(dense || walker_harris_ == 0 ? nullptr : d_tau_), (const float*)d_cand_resp_,
-                     harris_flat_ && !dense ? 0 : 1);
-  if (harris_flat_ && !dense) {
+                     d_cand_cnt_, d_cand_, d_cand_sc_, d_s1_cnt_, d_s1_, d_status_, dense ? 1 : 0);
+  if (!dense) {
     HarrisUnits hw;
     int nu = 0;
     for (int l = 0; l < kOrbLevels; l++) {
@@ -2772,8 +2569,7 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
     hw.base[kOrbLevels] = nu;
     for (int l = g.nlevels; l < kOrbLevels; l++) hw.base[l] = nu;
     hw.base[g.nlevels] = nu;
-    hipLaunchKernelGGL(k_harris_flat, dim3((nu + 3) / 4, n), dim3(256), 0, st, g, src, d_pyr_, hw, d_s1_cnt_, d_s1_, d_cand_cnt_,
-                       (const uint32_t*)(walker_harris_ == 0 ? nullptr : d_tau_));
+    hipLaunchKernelGGL(k_harris_flat, dim3((nu + 3) / 4, n), dim3(256), 0, st, g, src, d_pyr_, hw, d_s1_cnt_, d_s1_);
   }
   hipLaunchKernelGGL(k_select, dim3(n), dim3(256), 0, st, g, src.slot0, d_s1_cnt_, d_s1_, d_kp_, d_kp_cnt_,
                      d_status_);
@@ -2782,7 +2578,7 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
     // 4 key points per workgroup pass: 8 workgroups per frame keep a big batch busy; a single pair (the drop-in call)
     // gets up to 128 so that its ~500 key points per frame are one pass instead of sixteen
     int bx = 2048 / n;
-    bx = bx < desc_bx_min_ ? desc_bx_min_ : bx > 128 ? 128 : bx;
+    bx = bx < 8 ? 8 : bx > 128 ? 128 : bx;
     auto kd = blur_sum256_ ? k_describe<true, true> : half_up_ ? k_describe<true, false> : k_describe<false, false>;
     hipLaunchKernelGGL(kd, dim3(bx, n), dim3(256), 0, st, g, src, d_pyr_, d_kp_, d_kp_cnt_, d_desc_);
   }
@@ -2816,7 +2612,6 @@ hipError_t OrbPipeline::match(int n_pairs, const int32_t* d_slot_a, const int32_
     EvSet& set = evr_[ev_cur_];
     set.recorded = true;
     set.match_only = !ev_extract_pending_;   // a slot-pair match on its own: only the last interval is of this call
-    set.split = last_split_;
     ev_extract_pending_ = false;
   }
   return hipGetLastError();
@@ -2828,7 +2623,6 @@ void OrbPipeline::ev_begin_call() {
     if (evr_[ev_cur_].recorded) ev_harvest(ev_cur_);   // the oldest set, kEvRing calls back
   }
   ev_ = evr_[ev_cur_].ev;
-  ev2_ = evr_[ev_cur_].ev2;
 }
 
 // adds the stage times of set i to the accumulators (waits for the set's last event)
@@ -2838,23 +2632,16 @@ void OrbPipeline::ev_harvest(int i) {
   set.recorded = false;
   if (hipEventSynchronize(set.ev[5]) != hipSuccess) return;
   for (int k = set.match_only ? 4 : 0; k < 5; k++) {
-    // a split extraction (two sub-batches on two streams): a stage's time is the sum over the two parts (each measured
-    // on its own stream, i.e. with the other part's kernels beside it); part 0's descriptors end at ev[6]
-    hipEvent_t e1 = (set.split && !set.match_only && k == 3) ? set.ev[6] : set.ev[k + 1];
     float t = 0.f;
-    if (hipEventElapsedTime(&t, set.ev[k], e1) == hipSuccess) acc_ms_[k] += t;
-    if (set.split && !set.match_only && k < 4) {
-      float t2 = 0.f;
-      if (hipEventElapsedTime(&t2, set.ev2[k], set.ev2[k + 1]) == hipSuccess) acc_ms_[k] += t2;
-    }
+    if (hipEventElapsedTime(&t, set.ev[k], set.ev[k + 1]) == hipSuccess) acc_ms_[k] += t;
   }
   if (set.match_only) acc_match_only_++;
   else acc_full_++;
 }
 
 int OrbPipeline::stage_times(const char** names, float* ms, int cap) {
-  // fused extraction: the first stage is pyramid + FAST of levels 0 .. 6 in one pass per level (samplers included), the
-  // second what is left of FAST (the last level, the check, the dense redo).  Sums over the calls since the last query.
+  // fused extraction: the first stage is pyramid + FAST of all levels (the one walker launch, thresholds included), the
+  // second the check and the dense redo.  Sums over the calls since the last query.
   const char* kNames[5] = {last_fused_ ? "pyramid_fast" : "pyramid", "fast_nms", "select_harris", "orient_describe", "match"};
   if (!ev_ok_) return 0;
   for (int k = 0; k < kEvRing; k++) ev_harvest((ev_cur_ + 1 + k) % kEvRing);      // oldest first

@@ -97,14 +97,14 @@ class OrbPipeline {
   uint8_t* d_pyr_ = nullptr;
   uint32_t* d_tab_ = nullptr;      // resize tables per level: per group of 4 columns selectors / weights / pair offsets, per row source row | w1 << 16
   bool resize_shared_[kOrbLevels] = {};   // per level: k_resize may read three pixels' taps from one dword pair
-  uint32_t* d_qstat_ = nullptr;           // [slots][levels][kTauBins + 2]: score histogram of the sampled quarter's corners,
-                                          // its strips done (in-launch threshold refinement, see k_walk)
-  bool fast_two_part_ = true;             // MSF_ORB_FAST_ONE_PART=1 clears it: no refinement of the sampler's threshold
+  uint32_t* d_qstat_ = nullptr;           // [slots][levels][kQStat]: per (slot, level) the score histogram of the sampled quarter's
+                                          // corners, the thresholds and the done counters of the walker launch (see k_walk)
+  uint32_t* d_walk_abort_ = nullptr;      // [4] the walker launch's abort word (a unit gave up waiting); zeroed per call
+  bool fast_two_part_ = true;             // MSF_ORB_FAST_ONE_PART=1 clears it: no refinement of the first threshold
   int tau_predict_pct_ = 300;             // MSF_ORB_TAU_PREDICT (0 = sample every level)
-  int tau_sites_ = 1024;                  // sample sites of k_fast_tau per (frame, level) (MSF_ORB_TAU_SITES)
-  int wk_rows_target_ = 80;               // owned rows per walker strip (MSF_ORB_WALK_ROWS)
-  long long walk_round_ = 4096;           // strips the chip runs at once (16 waves x 256 CUs): see launch_walk
   bool fused_ = true;                     // MSF_ORB_UNFUSED=1 clears it: k_resize x 7, then one FAST-only walker launch
+  bool walk_per_level_ = false;           // MSF_ORB_WALK_PER_LEVEL=1: the fused walker as one launch per level (the
+                                          // in-launch waits are then met at once); tests compare it with the one-launch default
   int tau2_margin_pct_ = 200;             // MSF_ORB_TAU2_MARGIN_PCT
   bool resize_generic_ = false;           // MSF_ORB_RESIZE_GENERIC: never
   uint32_t* d_cand_cnt_ = nullptr; // [slots][8]
@@ -112,11 +112,6 @@ class OrbPipeline {
   uint32_t* d_redo_ = nullptr;     // [1 + slots * 8] dense-pass queue: count, entries (frame * 8 + level)
   uint32_t* d_cand_ = nullptr;     // [slots][cand_total] key = y << 16 | x
   uint8_t* d_cand_sc_ = nullptr;   // [slots][cand_total] FAST score
-  float* d_cand_resp_ = nullptr;   // [slots][levels][kRespCap] Harris response of the walker's candidates
-  int chain_merge_level_ = 99;     // MSF_ORB_CHAIN_MERGE: the chains of a fused extraction join before this level
-  int desc_bx_min_ = 8;            // MSF_ORB_DESC_BX: k_describe workgroups per frame in a big batch (4 waves each)
-  int harris_flat_ = 1;            // MSF_ORB_HARRIS_FLAT=0: Harris responses inside k_thr_harris (one wave per (frame, level))
-  int walker_harris_ = 0;          // MSF_ORB_WALKER_HARRIS (opt-in: less HBM traffic, more walker time)
   uint32_t* d_s1_cnt_ = nullptr;   // [slots][8]
   uint4* d_s1_ = nullptr;          // [slots][s1_total] (key, response bits, score, 0)
   msf_keypoint* d_kp_ = nullptr;   // [slots][kKpCap]
@@ -131,40 +126,20 @@ class OrbPipeline {
   // is needed again before it was queried is harvested first -- it is kEvRing calls old, long finished.
   static constexpr int kEvRing = 32;
   struct EvSet {
-    hipEvent_t ev[kOrbStages + 2] = {};
-    hipEvent_t ev2[kOrbStages + 2] = {};        // stage boundaries of the parts on split_stream_ (profiling)
-    bool recorded = false, match_only = false, split = false;
+    hipEvent_t ev[kOrbStages + 1] = {};
+    bool recorded = false, match_only = false;
   };
   EvSet evr_[kEvRing];
   int ev_cur_ = 0;
   hipEvent_t* ev_ = evr_[0].ev;                 // the current set
-  hipEvent_t* ev2_ = evr_[0].ev2;
   float acc_ms_[5] = {};                        // harvested, not yet returned
   int acc_full_ = 0, acc_match_only_ = 0;       // calls behind acc_ms_: with an extraction / slot-pair matches only
   void ev_begin_call();
   void ev_harvest(int i);
   bool ev_ok_ = false, ev_extract_pending_ = false;
   FrameSrc last_src_{};
-  static constexpr int kMaxChains = 4;          // chains of a fused extraction: the caller's stream + up to 3 of these
-  hipStream_t chain_stream_[kMaxChains - 1] = {};   // [0] = tau_stream_
-  hipEvent_t chain_ev_[kMaxChains - 1] = {};
-  int chains_ = 2;
-  hipStream_t tau_stream_ = nullptr;            // k_fast_tau of a batch runs here, underneath the pyramid kernels
-  hipEvent_t tau_ev_[kOrbLevels + 1] = {};      // level l exists (fork points), all thresholds written (join)
-  // Opt-in (MSF_ORB_SPLIT2=K, K = 2 .. 8): a batch of >= 256 frames is extracted as K sub-batches, alternately on the
-  // caller's stream and split_stream_, part k's pyramid starting when part k-1's is done: the latency-bound streaming
-  // FAST of one part then runs beside the Harris / descriptor kernels of the other (9.44 -> 9.05 ms per 1024 720p pairs,
-  // K = 2 .. 6 alike).  Not the default: with two parts in flight the stage boundaries that msf_stage_times (and the
-  // bench's roofline entry) rest on are no longer well defined -- each part's stages are timed on its own stream with
-  // the other part's kernels beside them, and the sums exceed the step time (13.1 ms of stages in a 9.1 ms step).
-  hipStream_t split_stream_ = nullptr;
-  hipEvent_t split_ev_[3] = {};
-  hipEvent_t split_pyr_[8] = {};
-  int split_parts_ = 2;
-  bool last_split_ = false, last_fused_ = false;
-  uint32_t* d_redo2_ = nullptr;
-  hipError_t extract_range(const FrameSrc& src, int n, hipStream_t st, uint32_t* redo, bool allow_side, hipEvent_t* evs,
-                           hipEvent_t pyramid_done);
+  bool last_fused_ = false;
+  hipError_t extract_range(const FrameSrc& src, int n, hipStream_t st, hipEvent_t* evs);
 };
 
 }  // namespace msf

@@ -214,22 +214,12 @@ class FeatureMatcher(_Matcher):
         return self._debug(_lib.DBG_LEVEL_SIZES, 0, 0, np.int32, 8 * 4 * 4).reshape(8, 4)
 
     @staticmethod
-    def extract_parts(n_frames):
-        """Sub-batches one extraction of n_frames frames runs as: 1, or 2 with the opt-in MSF_ORB_SPLIT2=K >= 2 for batches
-        of >= 256 frames (OrbPipeline::extract pipelines the parts on two streams; msf_stage_times then reports each
-        stage summed over the first two parts)."""
-        import os
-        parts = int(os.environ.get("MSF_ORB_SPLIT2", "0"))
-        if n_frames < 256 or parts < 2 or os.environ.get("MSF_ORB_NO_SIDE_STREAM"):
-            return 1
-        return 2
-
-    @staticmethod
     def walker_launches(stage):
-        """Launches of the dominant kernel (the streaming walker k_walk) in one extraction of a large batch: one per
-        source level for the fused stage "pyramid_fast" (levels 0..6, each also making the next level), one otherwise
-        (the unfused "fast_nms" stage walks all levels in one launch; so does the last level of the fused form)."""
-        return 7 if stage == "pyramid_fast" else 1
+        """Launches of the dominant kernel (the streaming walker k_walk) in one extraction of a batch: ONE -- all levels,
+        their thresholds and the pyramid in one launch (r03: 2 chains x 8 levels of sampler + walker launches); eight with
+        MSF_ORB_WALK_PER_LEVEL=1."""
+        import os
+        return 8 if (stage == "pyramid_fast" and os.environ.get("MSF_ORB_WALK_PER_LEVEL", "0") not in ("", "0")) else 1
 
     # Introspection of the feature slots.  `slot` counts from the scratch slots of the last MatchFrames / match_batch
     # call (frame A of pair i = i, frame B = n_pairs + i); cache=True addresses the per-frame cache slots of

@@ -447,12 +447,13 @@ def test_resize_fallback_equals_shared_pair_kernel(monkeypatch, w, h):
 
 @pytest.mark.gpu
 def test_refined_fast_threshold_equals_unrefined_and_survives_an_overshooting_estimate(monkeypatch):
-    """The streaming walker runs a sampled quarter of the strips at the sampler's threshold; the other strips raise it from
-    the quarter's exact corners (k_walk).  Same match lists as without the refinement (MSF_ORB_FAST_ONE_PART=1); the
-    refined threshold really is higher on the large levels; with the margin cut to 3 % of 2N it overshoots, levels fail
-    k_fast_check, take the dense second pass -- and the lists are still the same.  Also the same: everything in ONE launch
-    per level (MSF_ORB_WALK_ROUND=0: whether a strip sees the quarter complete then depends on dispatch timing), and the
-    unfused form (MSF_ORB_UNFUSED=1: k_resize x 7 + one FAST-only walker launch)."""
+    """The streaming walker runs a sampled quarter of the strips at the first threshold; the other strips wait for that
+    quarter and raise the threshold from its exact corners (k_walk).  Same match lists as without the refinement
+    (MSF_ORB_FAST_ONE_PART=1); the refined threshold really is higher on the large levels; with the margin cut to 3 % of 2N
+    it overshoots, levels fail k_fast_check, take the dense second pass -- and the lists are still the same.  Also the
+    same: the walker as one launch per level instead of ONE launch over all levels (MSF_ORB_WALK_PER_LEVEL=1: every
+    in-launch dependency wait is then met at once), and the unfused form (MSF_ORB_UNFUSED=1: k_resize x 7 + one FAST-only
+    walker launch)."""
     from mono_slam_framework_amd import _lib
     from mono_slam_framework_amd.matcher import FeatureMatcher
     n, w, h = 12, 1280, 720
@@ -504,9 +505,8 @@ def test_refined_fast_threshold_equals_unrefined_and_survives_an_overshooting_es
     for r, g in zip(ref, got2):
         np.testing.assert_array_equal(r, g)
     monkeypatch.delenv("MSF_ORB_TAU2_MARGIN_PCT")
-    # ... and with the Harris responses computed by the walker from its pixel ring (opt-in) instead of by k_thr_harris
-    for env in ({"MSF_ORB_WALK_ROUND": "0"}, {"MSF_ORB_UNFUSED": "1"}, {"MSF_ORB_UNFUSED": "1", "MSF_ORB_WALK_ROUND": "0"},
-                {"MSF_ORB_WALKER_HARRIS": "1"}, {"MSF_ORB_WALKER_HARRIS": "1", "MSF_ORB_UNFUSED": "1"}):
+    for env in ({"MSF_ORB_WALK_PER_LEVEL": "1"}, {"MSF_ORB_UNFUSED": "1"},
+                {"MSF_ORB_WALK_PER_LEVEL": "1", "MSF_ORB_TAU_PREDICT": "0"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         alt = FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=fl)
@@ -526,23 +526,25 @@ def test_refined_fast_threshold_equals_unrefined_and_survives_an_overshooting_es
 
 
 @pytest.mark.gpu
-def test_two_half_batch_chains_equal_one_chain_and_the_unfused_form(monkeypatch):
-    """A batch of >= 256 frames runs its fused pyramid + FAST stage as two chains of half the frames on two streams (one
-    half's threshold samplers beside the other half's walkers).  Same lists, key points and pyramids as one chain
-    (MSF_ORB_ONE_CHAIN=1) and as the unfused form; a frame of the second half is checked against the oracle."""
+def test_one_launch_walker_equals_per_level_launches_and_the_unfused_form(monkeypatch):
+    """A batch runs pyramid + FAST of all eight levels as ONE launch whose units wait for each other (threshold unit of
+    level l for the strips of level l - 1, strips for their threshold, non-quarter strips for the quarter).  Same lists,
+    key points and pyramids as one launch per level (MSF_ORB_WALK_PER_LEVEL=1) and as the unfused form, on a frame count
+    that is no multiple of 8 (XCDs with different numbers of frames) and on odd level sizes; three frames are checked
+    against the oracle; no frame is flagged as stalled."""
     from mono_slam_framework_amd import _lib
     from mono_slam_framework_amd.matcher import FeatureMatcher
-    n, w, h = 144, 333, 251                                  # 288 frames, odd sizes
+    n, w, h = 147, 333, 251                                  # 294 frames
     A, B = synth.synth_batch(9500, n, w, h, mode=0)
     fl = _lib.MSF_FLAG_NO_FRAME_CACHE
-    two = FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=fl)
-    ref = two.match_batch(list(A), list(B), cap=1024)
+    one = FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=fl)
+    ref = one.match_batch(list(A), list(B), cap=1024)
     assert sum(len(m) for m in ref) > 5 * n
     orc = oracle_orb.FeatureMatcherOracle(0.7)
     for i in (0, n // 2 + 3, n - 1):
         np.testing.assert_array_equal(ref[i], orc.MatchFrames(A[i], B[i]))
-    kp_ref = [two.keypoints(s) for s in (0, n - 1, n, 2 * n - 1)]
-    for env in ("MSF_ORB_ONE_CHAIN", "MSF_ORB_UNFUSED"):
+    kp_ref = [one.keypoints(s) for s in (0, n - 1, n, 2 * n - 1)]
+    for env in ("MSF_ORB_WALK_PER_LEVEL", "MSF_ORB_UNFUSED"):
         monkeypatch.setenv(env, "1")
         alt = FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=fl)
         got = alt.match_batch(list(A), list(B), cap=1024)
@@ -551,32 +553,26 @@ def test_two_half_batch_chains_equal_one_chain_and_the_unfused_form(monkeypatch)
         for s_, k in zip((0, n - 1, n, 2 * n - 1), kp_ref):
             np.testing.assert_array_equal(alt.keypoints(s_), k, err_msg=env)
             for l in (1, 4, 7):
-                np.testing.assert_array_equal(alt.level_pixels(s_, l), two.level_pixels(s_, l), err_msg="%s L%d" % (env, l))
+                np.testing.assert_array_equal(alt.level_pixels(s_, l), one.level_pixels(s_, l), err_msg="%s L%d" % (env, l))
         alt.close()
         monkeypatch.delenv(env)
 
 
 @pytest.mark.gpu
-def test_split_extraction_equals_single_pass(monkeypatch):
-    """Opt-in MSF_ORB_SPLIT2=2: batches of >= 256 frames are extracted as two pipelined sub-batches on two streams
-    (OrbPipeline::extract).  Same frames, same slots: identical match lists to the one-pass default, and the stage
-    times of the split run (sums over the parts) are all reported."""
+def test_one_launch_walker_back_to_back_calls_and_small_batches():
+    """The one-launch walker's per-(frame, level) state is reset by every call: the same handle run again, on other
+    frames, and with batches of 8, 9 and 31 pairs (fewer units than wave slots: every dependency is really waited for)
+    gives the oracle's lists each time."""
     from mono_slam_framework_amd import _lib
     from mono_slam_framework_amd.matcher import FeatureMatcher
-    n = 160                                          # 320 frames
-    A, B = synth.synth_batch(9100, n, 320, 240, mode=0)
-    fl = _lib.MSF_FLAG_NO_FRAME_CACHE | _lib.MSF_FLAG_PROFILE
-    assert FeatureMatcher.extract_parts(2 * n) == 1
-    whole = FeatureMatcher(0.7, 320, 240, max_batch_pairs=n, flags=fl)
-    ref = whole.match_batch(list(A), list(B), cap=1024)
-    assert sum(len(m) for m in ref) > 10 * n
-    monkeypatch.setenv("MSF_ORB_SPLIT2", "2")
-    assert FeatureMatcher.extract_parts(2 * n) == 2
-    split = FeatureMatcher(0.7, 320, 240, max_batch_pairs=n, flags=fl)
-    got = split.match_batch(list(A), list(B), cap=1024)
-    st = split.stage_times()
-    # (the first stage is "pyramid_fast" when the walker makes the pyramid, "pyramid" in the unfused form)
-    assert set(st) in ({"pyramid_fast", "fast_nms", "select_harris", "orient_describe", "match"},
-                       {"pyramid", "fast_nms", "select_harris", "orient_describe", "match"}) and all(v > 0 for v in st.values())
-    for r, g in zip(ref, got):
-        np.testing.assert_array_equal(r, g)
+    w, h = 640, 480
+    fm = FeatureMatcher(0.7, w, h, max_batch_pairs=31, flags=_lib.MSF_FLAG_NO_FRAME_CACHE | _lib.MSF_FLAG_PROFILE)
+    orc = oracle_orb.FeatureMatcherOracle(0.7)
+    for rep, n in enumerate((31, 8, 9, 31)):
+        A, B = synth.synth_batch(9700 + 50 * rep, n, w, h, mode=rep % 3)
+        got = fm.match_batch(list(A), list(B), cap=1024)
+        for i in (0, n // 2, n - 1):
+            np.testing.assert_array_equal(got[i], orc.MatchFrames(A[i], B[i]), err_msg="call %d pair %d" % (rep, i))
+    st = fm.stage_times()                            # sums over the four calls; the first stage is the one walker launch
+    assert set(st) == {"pyramid_fast", "fast_nms", "select_harris", "orient_describe", "match"} and all(v > 0 for v in st.values())
+    fm.close()
