@@ -528,9 +528,14 @@ constexpr int kQStat = kTauBins + 4;
 constexpr uint32_t kQReady = 0x80000000u;
 constexpr int RK = 16;                   // ring rows (power of two)
 constexpr int kWkMaxPx = 244;            // strip pitch <= 244: a group of 4 output px reads two aligned 8-byte pairs <= 8 B apart
-constexpr int kWkMaxRows = 112;          // owned rows per strip at most (a strip's emit table lives in two registers per lane)
-constexpr int kWkRowsTarget = 80;        // owned rows per strip aimed at: 48 / 64 / 80 / 96 / 112 rows measured 8.19 / 7.97 / 7.83 /
-                                         // 7.88 / 7.96 ms per 720p step (r03), flat at 640 x 480
+constexpr int kWkMaxRows = 240;          // owned rows per strip at most (a strip's emit table lives in four registers per lane)
+// Owned rows per strip aimed at.  With the levels as separate launches 80 rows measured best (r03: 48 / 64 / 80 / 96 / 112
+// rows 8.19 / 7.97 / 7.83 / 7.88 / 7.96 ms per 720p step: taller strips lengthen every launch's tail).  In the one-launch
+// form there is one tail, and what counts is the work a strip repeats -- 8 halo rows, its prologue, its drain:
+// 64 / 80 / 112 / 144 / 180 / 240 rows measured 5.47 / 5.24 / 4.97 / 4.86 / 4.78 / 4.79 ms for the stage at 1280 x 720
+// (1024 pairs) and 9.92 (80) / 9.45 (112) / 8.80 (144) / 8.62 (240) ms at 640 x 480 (4096 pairs).  Handles for small
+// batches keep short strips: their calls are latency-bound chains of (quarter, rest) x 8 levels.
+constexpr int kWkRowsTall = 240, kWkRowsShort = 80, kWkTallMinSlots = 4 * 64;
 constexpr int kTauSites = 1024;          // sampled runs of 4 px per (frame, level) of the threshold sampler (512 / 2048 / 4096: slower)
 constexpr int kSGCap = 288, kSPCap = 256, kSHCap = 64, kSOCap = 64;   // 10 240 B of LDS per wave: exactly 16 waves per CU
 constexpr uint32_t kSGFlush = 32;        // records that trigger a flush at the end of a four-step group (<= 4 x 64 more arrive)
@@ -539,7 +544,10 @@ static_assert(kSGCap >= (int)kSGFlush + 256, "record list capacity");
 // score rows >= last_flush - 1: the flush interval (a multiple of the four-step group) must stay below 11 rows.
 constexpr int kFlushRows = 8;
 static_assert(kFlushRows < RK - 5 && kFlushRows % 4 == 0, "ring too short for the flush interval");
-constexpr int kTau2MarginPct = 200, kTau2MinStrips = 2;
+// kTau2MinStrips: sampled strips a level needs for its refinement / for the prediction of the level below.  1 since the
+// tall strips (a 640 x 480 frame has levels of two to four strips): 640 x 480 stage 8.93 -> 8.45 ms, 1280 x 720 unchanged,
+// no additional dense pass in either.
+constexpr int kTau2MarginPct = 200, kTau2MinStrips = 1;
 constexpr int kTau2MarginPctMany = 150, kTau2ManyStrips = 8;
 
 struct StreamSmem {
@@ -596,6 +604,9 @@ __device__ __forceinline__ int stream_score(const uint8_t* ring, uint32_t r0, ui
 // on the reading side; thresholds may differ from run to run in principle, the candidate lists they lead to contain
 // every corner retainBest(2N) can keep either way (k_fast_check).
 constexpr uint32_t kSpinMax = 1u << 19;
+#ifndef MSF_X
+#define MSF_X 0   // TEMPORARY timing experiments (bit 0: no acquire, 1: plain stores, 2: early loads, 4: no drain)
+#endif
 
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -652,7 +663,7 @@ __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g,
   // Level 0 is the caller's frame: its first ten pixel rows are requested before anything else, together with the state
   // of the (frame, level) -- one memory latency for both.  A level the walker made is only read once that state says it
   // is complete (the threshold unit of this (frame, level) waited for it) and behind an acquire.
-  const bool early = !(chain && l > 0);          // uniform
+  const bool early = (MSF_X & 4) ? true : !(chain && l > 0);          // uniform
   uint32_t w0_ = 0, w1_ = 0, w2_ = 0, w3_ = 0, w4_ = 0, w5_ = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
   if (early) {
     w0_ = LOAD_ROW(y0 - 3); w1_ = LOAD_ROW(y0 - 2); w2_ = LOAD_ROW(y0 - 1); w3_ = LOAD_ROW(y0); w4_ = LOAD_ROW(y0 + 1);
@@ -682,7 +693,7 @@ __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g,
     }
   }
   if (!early) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (!(MSF_X & 1)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     w0_ = LOAD_ROW(y0 - 3); w1_ = LOAD_ROW(y0 - 2); w2_ = LOAD_ROW(y0 - 1); w3_ = LOAD_ROW(y0); w4_ = LOAD_ROW(y0 + 1);
     w5_ = LOAD_ROW(y0 + 2);
     q0 = LOAD_ROW(y0 + 3); q1 = LOAD_ROW(y0 + 4); q2 = LOAD_ROW(y0 + 5); q3 = LOAD_ROW(y0 + 6);
@@ -740,7 +751,7 @@ __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g,
   uint8_t* scb = sm.sc;
 
   // ---- resize state: this lane's group of 4 output columns of level l + 1
-  uint32_t rsel[4] = {0, 0, 0, 0}, rwxp[4] = {0, 0, 0, 0}, roff0 = 0, roff3 = 0, em_lo = 0, em_hi = 0;
+  uint32_t rsel[4] = {0, 0, 0, 0}, rwxp[4] = {0, 0, 0, 0}, roff0 = 0, roff3 = 0, em0 = 0, em1 = 0, em2 = 0, em3 = 0;
   __amdgpu_buffer_rsrc_t dst_rs = img_rs;         // level l + 1 of this frame (set below)
   uint32_t dxoff = 0;                             // the lane's byte offset inside an output row
   bool rz_lane = false;
@@ -765,13 +776,18 @@ __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g,
     dpitch = uniform_u32((uint32_t)Ld.pitch);
     dst_rs = uniform_rsrc(pyr + (long long)slot * g.pyr_bytes + Ld.pix_off, (uint32_t)Ld.h * (uint32_t)Ld.pitch);
     dxoff = 4u * (uint32_t)gq;
-    // emit entries of the source rows R0 - 4 + j, j = lane (em_lo) and 64 + lane (em_hi): output row | w1 << 16 | 1 << 31
+    // emit entries of the source rows R0 - 4 + j, j = 64 k + lane in em<k>: output row | w1 << 16 | 1 << 31
     // if an output row has source rows (y, y + 1) as its taps and y is owned by this strip
     const int ra = R0 - 4 + lane, rb = ra + 64;
-    if (ra >= R0 && ra < R1) em_lo = yemit[ra];
-    if (rb >= R0 && rb < R1) em_hi = yemit[rb];
+    if (ra >= R0 && ra < R1) em0 = yemit[ra];
+    if (rb >= R0 && rb < R1) em1 = yemit[rb];
+    if (rb + 64 >= R0 && rb + 64 < R1) em2 = yemit[rb + 64];
+    if (rb + 128 >= R0 && rb + 128 < R1) em3 = yemit[rb + 128];
   }
 
+  // the two 64-entry blocks of the emit table the current rows use (entries 64 em_k .. 64 em_k + 127)
+  uint32_t em_a = em0, em_b = em1;
+  int em_k = 0;
   // wave-uniform state
   uint32_t nG = 0, nH = 0, nO = 0;
   int nms_lo = 1, last_flush = -1;               // first rel row whose NMS is pending; rel row of the last flush
@@ -800,7 +816,7 @@ __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g,
   do {                                                                                                                 \
     const int jj_ = (j_);                                                                                              \
     /* one select + one v_readlane (a ternary of two readlanes compiles to branches) */                                 \
-    const uint32_t em_ = (uint32_t)__builtin_amdgcn_readlane((int)(jj_ < 64 ? em_lo : em_hi), jj_ & 63);               \
+    const uint32_t em_ = (uint32_t)__builtin_amdgcn_readlane((int)((jj_ >> 6) == em_k ? em_a : em_b), jj_ & 63);        \
     if ((int)em_ < 0) {                                                                                                \
       const uint32_t wy1_ = (em_ >> 16) & 0x1FFu, wy0_ = 256u - wy1_, rnd_ = 32768u;                                   \
       const uint32_t v0_ = mad_u24_s(hu_[0], wy0_, mad_u24_s(hl_[0], wy1_, rnd_));                                     \
@@ -809,7 +825,7 @@ __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g,
       const uint32_t v3_ = mad_u24_s(hu_[3], wy0_, mad_u24_s(hl_[3], wy1_, rnd_));                                     \
       const uint32_t pk_ = __builtin_amdgcn_perm(v1_, v0_, 0x0c0c0602u) | __builtin_amdgcn_perm(v3_, v2_, 0x06020c0cu); \
       /* aux 16 = sc1: write-through, so that the level is in memory when this strip counts itself done (k_walk) */     \
-      if (rz_lane) __builtin_amdgcn_raw_buffer_store_b32(pk_, dst_rs, dxoff, (em_ & 0xFFFFu) * dpitch, 16);             \
+      if (rz_lane) __builtin_amdgcn_raw_buffer_store_b32(pk_, dst_rs, dxoff, (em_ & 0xFFFFu) * dpitch, (MSF_X & 2) ? 0 : 16); \
     }                                                                                                                  \
   } while (0)
 
@@ -855,36 +871,18 @@ __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g,
     // the hit list was rebuilt from one row's scores at the end of the last flush: if that row held more corners than
     // the list, this NMS is the dense one
     bool overflow = nH > (uint32_t)kSHCap;
-    // 32 records per round: at most 32 x 8 pixel entries (a pixel can pass both polarity prefilters)
-    for (uint32_t c0 = 0; c0 < nG; c0 += 32) {
-      uint32_t e0 = 0, mb = 0, md = 0;
-      if (lane < 32 && c0 + lane < nG) {
-        const uint32_t rec = sm.g[c0 + lane];
-        // only the low four bits of the rel row matter here (ring row = (rel row + 3) mod 16)
-        // pixel entry: byte in row (8 bits) | ring row (4 bits) << 8 | dark << 12
-        e0 = ((rec & 63u) << 2) | ((rec + 0x300u) & 0xF00u);
-        mb = rec & 0x80808080u;
-        md = (rec << 1) & 0x80808080u;
-      }
-      const uint32_t mine = __popc(mb) + __popc(md);
-      const uint32_t incl = wave_incl_scan(mine);
-      const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-      uint32_t k = incl - mine;
-      if (mb & 0x80u) sm.p[k++] = (uint16_t)e0;
-      if (mb & 0x8000u) sm.p[k++] = (uint16_t)(e0 + 1);
-      if (mb & 0x800000u) sm.p[k++] = (uint16_t)(e0 + 2);
-      if (mb & 0x80000000u) sm.p[k++] = (uint16_t)(e0 + 3);
-      e0 |= 0x1000u;
-      if (md & 0x80u) sm.p[k++] = (uint16_t)e0;
-      if (md & 0x8000u) sm.p[k++] = (uint16_t)(e0 + 1);
-      if (md & 0x800000u) sm.p[k++] = (uint16_t)(e0 + 2);
-      if (md & 0x80000000u) sm.p[k++] = (uint16_t)(e0 + 3);
+    // The records are expanded into the pixel-entry list 64 at a time and the list is scored in full rounds of 64 whenever
+    // it could not take the next round's entries (32 records at a time went through expansion + scoring with the lanes
+    // 40 % used).  A record holds up to 8 entries (a pixel can pass both polarity prefilters): a round whose 64 records
+    // hold more than the list takes 32 of them.
+    uint32_t nP = 0;
+    auto score_pending = [&]() {
       MSF_WAVE_SYNC();
-      for (uint32_t i0 = 0; i0 < total; i0 += 64) {
+      for (uint32_t i0 = 0; i0 < nP; i0 += 64) {
         const uint32_t i = i0 + lane;
         int sv = 0;
         uint32_t pe = 0;
-        if (i < total) {
+        if (i < nP) {
           pe = sm.p[i];
           sv = stream_score(pxb, (pe >> 8) & 15u, pe & 255u, (pe & 0x1000u) != 0u, tv);
           if (sv) scb[pe & 0xFFFu] = (uint8_t)sv;
@@ -900,7 +898,41 @@ __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g,
         }
       }
       MSF_WAVE_SYNC();
+      nP = 0;
+    };
+    for (uint32_t c0 = 0; c0 < nG;) {
+      uint32_t e0 = 0, mb = 0, md = 0;
+      if (c0 + lane < nG) {
+        const uint32_t rec = sm.g[c0 + lane];
+        // only the low four bits of the rel row matter here (ring row = (rel row + 3) mod 16)
+        // pixel entry: byte in row (8 bits) | ring row (4 bits) << 8 | dark << 12
+        e0 = ((rec & 63u) << 2) | ((rec + 0x300u) & 0xF00u);
+        mb = rec & 0x80808080u;
+        md = (rec << 1) & 0x80808080u;
+      }
+      const uint32_t mine = __popc(mb) + __popc(md);
+      const uint32_t incl = wave_incl_scan(mine);
+      uint32_t total = __builtin_amdgcn_readlane(incl, 63), take = 64;
+      if (total > (uint32_t)kSPCap) {              // uniform, rare: the first 32 records only (at most 256 entries)
+        take = 32;
+        total = __builtin_amdgcn_readlane(incl, 31);
+        if (lane >= 32) mb = md = 0u;
+      }
+      if (nP + total > (uint32_t)kSPCap) score_pending();
+      uint32_t k = nP + incl - mine;
+      if (mb & 0x80u) sm.p[k++] = (uint16_t)e0;
+      if (mb & 0x8000u) sm.p[k++] = (uint16_t)(e0 + 1);
+      if (mb & 0x800000u) sm.p[k++] = (uint16_t)(e0 + 2);
+      if (mb & 0x80000000u) sm.p[k++] = (uint16_t)(e0 + 3);
+      e0 |= 0x1000u;
+      if (md & 0x80u) sm.p[k++] = (uint16_t)e0;
+      if (md & 0x8000u) sm.p[k++] = (uint16_t)(e0 + 1);
+      if (md & 0x800000u) sm.p[k++] = (uint16_t)(e0 + 2);
+      if (md & 0x80000000u) sm.p[k++] = (uint16_t)(e0 + 3);
+      nP += total;
+      c0 += take;
     }
+    score_pending();
     nG = 0;
     // ---- NMS of rel rows [nms_lo, s - 1]: all their neighbours' scores are final
     const int hi = s - 1;
@@ -1020,13 +1052,18 @@ __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g,
     }                                                                                                                  \
   } while (0)
   const uint32_t lane_rec = (uint32_t)lane;
-  static_assert(kWkMaxRows + 8 < 128, "a record holds 7 bits of rel row");
+  static_assert(kWkMaxRows + 12 < 256, "rel rows: 8 bits in a buffered corner, 4 x 64 emit entries");
   static_assert(RK == 16, "the group body below exists in four copies, one per position of the group in the 16-row ring");
   // The ring slot of a row is (ring index) mod 16 and a group starts at a multiple of 4: the body is instantiated for the
   // four values of (s mod 16), so that every slot is a compile-time constant and every LDS access of the group is
   // lane base + immediate offset (18 vector instructions per group went into ring addresses).  P_ = s mod 16.
   auto group = [&](auto ph_, const int s) {
     constexpr int P_ = decltype(ph_)::value * 4;
+    if (RESIZE && ((s + 5) >> 6) != em_k) {          // uniform, once per 64 rows: the window of the emit table moves on
+      em_k++;
+      em_a = em_b;
+      em_b = em_k == 1 ? em2 : em_k == 2 ? em3 : 0u;
+    }
     const uint32_t d0 = q0, d1 = q1, d2 = q2, d3 = q3;
     PUT_ROW(P_ + 6, d0); q0 = LOAD_ROW(y0 + s + 7);
     PUT_ROW(P_ + 7, d1); q1 = LOAD_ROW(y0 + s + 8);
@@ -1094,7 +1131,7 @@ __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g,
     // Every store of this strip has left the wave's queue before the strip counts as done: the write-through stores of
     // level l + 1's pixels are then in memory (what the next level's units wait for) and the histogram adds have been
     // performed (agent-scope atomics both sides).  Inline asm: the compiler may not drop or move this wait.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(MSF_X & 16) || count_me) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) {
       if (count_me) atomicAdd(&qs[kQDone], 1u);
       if (RESIZE) atomicAdd(&qs[kQAll], 1u);
@@ -2293,7 +2330,8 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     // walker strips over the whole level: 256-px windows wk_px apart ((nx - 1) * wk_px + 256 >= w), wk_rows owned rows
     L.wk_nx = L.w > 256 ? (L.w - 256 + kWkMaxPx - 1) / kWkMaxPx + 1 : 1;
     L.wk_px = L.wk_nx > 1 ? (((L.w - 256 + L.wk_nx - 2) / (L.wk_nx - 1)) + 3) & ~3 : kWkMaxPx;
-    L.wk_ny = (L.h + kWkRowsTarget - 1) / kWkRowsTarget;
+    const int rows_target = max_slots >= kWkTallMinSlots ? kWkRowsTall : kWkRowsShort;
+    L.wk_ny = (L.h + rows_target - 1) / rows_target;
     L.wk_rows = (((L.h + L.wk_ny - 1) / L.wk_ny) + 3) & ~3;
     L.wk_ny = (L.h + L.wk_rows - 1) / L.wk_rows;
     L.wk_base = strips;
