@@ -604,9 +604,7 @@ __device__ __forceinline__ int stream_score(const uint8_t* ring, uint32_t r0, ui
 // on the reading side; thresholds may differ from run to run in principle, the candidate lists they lead to contain
 // every corner retainBest(2N) can keep either way (k_fast_check).
 constexpr uint32_t kSpinMax = 1u << 19;
-#ifndef MSF_X
-#define MSF_X 0   // TEMPORARY timing experiments (bit 0: no acquire, 1: plain stores, 2: early loads, 4: no drain)
-#endif
+
 
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -663,7 +661,7 @@ __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g,
   // Level 0 is the caller's frame: its first ten pixel rows are requested before anything else, together with the state
   // of the (frame, level) -- one memory latency for both.  A level the walker made is only read once that state says it
   // is complete (the threshold unit of this (frame, level) waited for it) and behind an acquire.
-  const bool early = (MSF_X & 4) ? true : !(chain && l > 0);          // uniform
+  const bool early = !(chain && l > 0);          // uniform
   uint32_t w0_ = 0, w1_ = 0, w2_ = 0, w3_ = 0, w4_ = 0, w5_ = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
   if (early) {
     w0_ = LOAD_ROW(y0 - 3); w1_ = LOAD_ROW(y0 - 2); w2_ = LOAD_ROW(y0 - 1); w3_ = LOAD_ROW(y0); w4_ = LOAD_ROW(y0 + 1);
@@ -693,7 +691,7 @@ __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g,
     }
   }
   if (!early) {
-    if (!(MSF_X & 1)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     w0_ = LOAD_ROW(y0 - 3); w1_ = LOAD_ROW(y0 - 2); w2_ = LOAD_ROW(y0 - 1); w3_ = LOAD_ROW(y0); w4_ = LOAD_ROW(y0 + 1);
     w5_ = LOAD_ROW(y0 + 2);
     q0 = LOAD_ROW(y0 + 3); q1 = LOAD_ROW(y0 + 4); q2 = LOAD_ROW(y0 + 5); q3 = LOAD_ROW(y0 + 6);
@@ -825,7 +823,7 @@ __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g,
       const uint32_t v3_ = mad_u24_s(hu_[3], wy0_, mad_u24_s(hl_[3], wy1_, rnd_));                                     \
       const uint32_t pk_ = __builtin_amdgcn_perm(v1_, v0_, 0x0c0c0602u) | __builtin_amdgcn_perm(v3_, v2_, 0x06020c0cu); \
       /* aux 16 = sc1: write-through, so that the level is in memory when this strip counts itself done (k_walk) */     \
-      if (rz_lane) __builtin_amdgcn_raw_buffer_store_b32(pk_, dst_rs, dxoff, (em_ & 0xFFFFu) * dpitch, (MSF_X & 2) ? 0 : 16); \
+      if (rz_lane) __builtin_amdgcn_raw_buffer_store_b32(pk_, dst_rs, dxoff, (em_ & 0xFFFFu) * dpitch, 16);             \
     }                                                                                                                  \
   } while (0)
 
@@ -1025,7 +1023,14 @@ __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g,
   //  2. the cardinal prefilters of the four rows (ring indices s_, s_ + 3, s_ + 6; see fast_tile for the SWAR form):
   //     the row three below comes from the register just stored, the others from the ring;
   //  3. the four record appends.
-#define STREAM_PRE(U_, C_, D_, vmr_, cb_, cd_)                                                                          \
+  // The tests against the pixel three rows ABOVE are not computed: row y - 3 has already compared itself with row y (its
+  // pixel three rows below), and "U brighter than C by more than tau" is "C darker than U by more than tau" seen from
+  // row y - 3.  With bu_ / nu_ = the "below is brighter" / "below is not darker" bits of row y - 3 (bit 7 of each byte):
+  //   above brighter  [U > C + tau]  is taken as  ~nu_ = [U >= C + tau]   (a superset: the equality case passes too)
+  //   above not darker               is taken as  ~bu_ = [U >= C - tau]   (dark-up = bu_ = [U < C - tau], FAST's strict test)
+  // Both keep the prefilter a necessary condition for a corner of score > tau (exact scores decide), and a row costs 9
+  // v_lerp_u8 instead of 12 and no ring read of the row above.  b0o_ / n0o_: this row's bits for the row three below.
+#define STREAM_PRE(C_, D_, bu_, nu_, vmr_, cb_, cd_, b0o_, n0o_)                                                        \
   do {                                                                                                                 \
     const uint32_t Lf_ = __builtin_amdgcn_update_dpp(0u, C_, 0x138, 0xf, 0xf, true); /* wave_shr:1: lane i <- i-1 */   \
     const uint32_t Rt_ = __builtin_amdgcn_update_dpp(0u, C_, 0x130, 0xf, 0xf, true); /* wave_shl:1: lane i <- i+1 */   \
@@ -1033,13 +1038,22 @@ __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g,
     const uint32_t E3_ = __builtin_amdgcn_alignbyte(Rt_, C_, 3);                                                       \
     const uint32_t nC_ = ~(C_);                                                                                        \
     const uint32_t l0_ = __builtin_amdgcn_lerp(D_, nC_, 0), l4_ = __builtin_amdgcn_lerp(E3_, nC_, 0);                  \
-    const uint32_t l8_ = __builtin_amdgcn_lerp(U_, nC_, 0), l12_ = __builtin_amdgcn_lerp(W3_, nC_, 0);                 \
+    const uint32_t l12_ = __builtin_amdgcn_lerp(W3_, nC_, 0);                                                          \
     const uint32_t b0_ = __builtin_amdgcn_lerp(l0_, lerp_bright, 0), b4_ = __builtin_amdgcn_lerp(l4_, lerp_bright, 0);     \
-    const uint32_t b8_ = __builtin_amdgcn_lerp(l8_, lerp_bright, 0), b12_ = __builtin_amdgcn_lerp(l12_, lerp_bright, 0);   \
+    const uint32_t b12_ = __builtin_amdgcn_lerp(l12_, lerp_bright, 0);                                                 \
     const uint32_t n0_ = __builtin_amdgcn_lerp(l0_, lerp_not_dark, 0), n4_ = __builtin_amdgcn_lerp(l4_, lerp_not_dark, 0); \
-    const uint32_t n8_ = __builtin_amdgcn_lerp(l8_, lerp_not_dark, 0), n12_ = __builtin_amdgcn_lerp(l12_, lerp_not_dark, 0); \
-    cb_ = ((b0_ | b8_) & (b4_ | b12_)) & (vmr_);                                                                       \
-    cd_ = ~((n0_ & n8_) | (n4_ & n12_)) & (vmr_);                                                                      \
+    const uint32_t n12_ = __builtin_amdgcn_lerp(l12_, lerp_not_dark, 0);                                               \
+    cb_ = ((b0_ | ~(nu_)) & (b4_ | b12_)) & (vmr_);                                                                    \
+    cd_ = ~((n0_ & ~(bu_)) | (n4_ & n12_)) & (vmr_);                                                                   \
+    b0o_ = b0_;                                                                                                        \
+    n0o_ = n0_;                                                                                                        \
+  } while (0)
+  // the same for a row whose record is never made (the three rows above the strip's first): only its bits for the row below
+#define STREAM_PRE_DOWN(C_, D_, b0o_, n0o_)                                                                            \
+  do {                                                                                                                 \
+    const uint32_t l0_ = __builtin_amdgcn_lerp(D_, ~(C_), 0);                                                          \
+    b0o_ = __builtin_amdgcn_lerp(l0_, lerp_bright, 0);                                                                 \
+    n0o_ = __builtin_amdgcn_lerp(l0_, lerp_not_dark, 0);                                                               \
   } while (0)
 #define STREAM_APPEND(s_, cb_, cd_)                                                                                    \
   do {                                                                                                                 \
@@ -1057,6 +1071,11 @@ __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g,
   // The ring slot of a row is (ring index) mod 16 and a group starts at a multiple of 4: the body is instantiated for the
   // four values of (s mod 16), so that every slot is a compile-time constant and every LDS access of the group is
   // lane base + immediate offset (18 vector instructions per group went into ring addresses).  P_ = s mod 16.
+  // rel rows -3 .. -1 (ring indices 0 .. 2) against the rows three below them (ring indices 3 .. 5)
+  uint32_t pb1, pn1, pb2, pn2, pb3, pn3;
+  STREAM_PRE_DOWN(w0_, w3_, pb1, pn1);
+  STREAM_PRE_DOWN(w1_, w4_, pb2, pn2);
+  STREAM_PRE_DOWN(w2_, w5_, pb3, pn3);
   auto group = [&](auto ph_, const int s) {
     constexpr int P_ = decltype(ph_)::value * 4;
     if (RESIZE && ((s + 5) >> 6) != em_k) {          // uniform, once per 64 rows: the window of the emit table moves on
@@ -1069,8 +1088,7 @@ __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g,
     PUT_ROW(P_ + 7, d1); q1 = LOAD_ROW(y0 + s + 8);
     PUT_ROW(P_ + 8, d2); q2 = LOAD_ROW(y0 + s + 9);
     PUT_ROW(P_ + 9, d3); q3 = LOAD_ROW(y0 + s + 10);
-    const uint32_t u0 = pxw[((P_) & (RK - 1)) * 64 + lane], u1 = pxw[((P_ + 1) & (RK - 1)) * 64 + lane];
-    const uint32_t u2 = pxw[((P_ + 2) & (RK - 1)) * 64 + lane], u3 = pxw[((P_ + 3) & (RK - 1)) * 64 + lane];   // = c0
+    const uint32_t c0 = pxw[((P_ + 3) & (RK - 1)) * 64 + lane];
     const uint32_t c1 = pxw[((P_ + 4) & (RK - 1)) * 64 + lane], c2 = pxw[((P_ + 5) & (RK - 1)) * 64 + lane];
     if (RESIZE) {
       // the four rows just stored are source rows y0 + s + 3 .. y0 + s + 6 = R0 + s + 2 .. (table entries s + 6 ..);
@@ -1096,10 +1114,12 @@ __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g,
       vm2 = (s + 2 >= s_lo && s + 2 <= s_hi) ? vm : 0u;
       vm3 = (s + 3 >= s_lo && s + 3 <= s_hi) ? vm : 0u;
     }
-    STREAM_PRE(u0, u3, d0, vm0, cb0, cd0);
-    STREAM_PRE(u1, c1, d1, vm1, cb1, cd1);
-    STREAM_PRE(u2, c2, d2, vm2, cb2, cd2);
-    STREAM_PRE(u3, d0, d3, vm3, cb3, cd3);         // the centre row of step s + 3 is the row stored first in this group
+    // (pb1, pn1) .. (pb3, pn3): the "below" bits of rel rows s - 3 .. s - 1; this group's rows s + 1 .. s + 3 replace them
+    uint32_t rb0, rn0;
+    STREAM_PRE(c0, d0, pb1, pn1, vm0, cb0, cd0, rb0, rn0);
+    STREAM_PRE(c1, d1, pb2, pn2, vm1, cb1, cd1, pb1, pn1);
+    STREAM_PRE(c2, d2, pb3, pn3, vm2, cb2, cd2, pb2, pn2);
+    STREAM_PRE(d0, d3, rb0, rn0, vm3, cb3, cd3, pb3, pn3);   // the centre row of step s + 3 is the row stored first in this group
     STREAM_APPEND(s, cb0, cd0);
     STREAM_APPEND(s + 1, cb1, cd1);
     STREAM_APPEND(s + 2, cb2, cd2);
@@ -1120,6 +1140,7 @@ __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g,
     }
   }
 #undef STREAM_PRE
+#undef STREAM_PRE_DOWN
 #undef STREAM_APPEND
   flush_out();
 #undef LOAD_ROW
@@ -1131,7 +1152,7 @@ __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g,
     // Every store of this strip has left the wave's queue before the strip counts as done: the write-through stores of
     // level l + 1's pixels are then in memory (what the next level's units wait for) and the histogram adds have been
     // performed (agent-scope atomics both sides).  Inline asm: the compiler may not drop or move this wait.
-    if (!(MSF_X & 16) || count_me) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) {
       if (count_me) atomicAdd(&qs[kQDone], 1u);
       if (RESIZE) atomicAdd(&qs[kQAll], 1u);
