@@ -85,10 +85,12 @@ typedef struct msf_config {
                                 LoFTR: confidence threshold (dnnfeaturematcher.h:11 default 0.15f) */
   int32_t image_width;       /* all frames of one handle share one size (dnnfeaturematcher.h:12-13) */
   int32_t image_height;
-  int32_t max_batch_pairs;   /* P: device workspace is sized for this many pairs per call.  ORB keeps 4 P + 64 full feature
-                                slots (2 P caller-visible, 2 P scratch of the stateless calls, 64 of the frame cache), each
-                                with its pyramid, candidate lists and key points: about 5 MB per 1280x720 slot, i.e. about
-                                20 GB at P = 1024; LoFTR about 20 MB of activations per pair of a backbone chunk (<= 256) */
+  int32_t max_batch_pairs;   /* P: device workspace is sized for this many pairs per call.  ORB keeps the per-CALL arrays
+                                (pyramid, FAST candidate lists, stage-1 lists, walker state) once per frame of a call --
+                                2 P rows of about 4.8 MB at 1280x720 -- and key points + descriptors (128 KB) per feature
+                                slot, of which there are 4 P + 64 (2 P caller-visible, 2 P scratch of the stateless calls,
+                                64 of the frame cache): about 10.4 GB at P = 1024 (round 3 kept everything per slot:
+                                20 GB); LoFTR about 20 MB of activations per pair of a backbone chunk (<= 256) */
   uint32_t flags;
   const char* weights_path;  /* LoFTR: the model file, as DNNFeatureMatcher's model_file_path (dnnfeaturematcher.cpp:11-21):
                                 the reference's model/LoFTR_teacher.onnx is read directly (its initializers and constants);

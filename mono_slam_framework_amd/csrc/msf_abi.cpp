@@ -347,7 +347,7 @@ int msf_create(const msf_config* cfg, msf_handle** out) {
       err = h->orb.init(cfg->image_width, cfg->image_height, 4 * cfg->max_batch_pairs + n_cache,
                         (cfg->flags & MSF_FLAG_BLUR_TIE_HALF_UP) != 0, profile, (cfg->flags & MSF_FLAG_FAST_DENSE) != 0,
                         (cfg->flags & MSF_FLAG_LEVEL_SIZE_MUL_INV) != 0, (cfg->flags & MSF_FLAG_FAST_STREAM) ? 1 : 8,
-                        (cfg->flags & MSF_FLAG_BLUR_SUM256) != 0);
+                        (cfg->flags & MSF_FLAG_BLUR_SUM256) != 0, 2 * cfg->max_batch_pairs);
     } else {
       if (cfg->image_width != 640 || cfg->image_height != 480) {
           return fail(nullptr, MSF_ERR_UNSUPPORTED, "LoFTR_teacher is a fixed-shape 1x1x480x640 graph (model/LoFTR_teacher.onnx)");

@@ -2244,10 +2244,13 @@ void OrbPipeline::destroy() {
   } while (0)
 
 std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_half_up, bool profile, bool dense_fast,
-                              bool level_size_mul_inv, int stream_min_frames, bool blur_sum256) {
+                              bool level_size_mul_inv, int stream_min_frames, bool blur_sum256, int work_frames) {
   if (width < 64 || height < 64 || width > 8192 || height > 8192) return "arg: ORB image size must be in [64, 8192] x [64, 8192]";
   if (max_slots < 2) return "arg: ORB max_slots < 2";
   max_slots_ = max_slots;
+  // frames one extraction may hold: the pyramid, the candidate and stage-1 lists and the walker's state exist once per
+  // frame of a CALL (work rows), only key points and descriptors once per feature slot
+  work_frames_ = work_frames <= 0 || work_frames > max_slots ? max_slots : work_frames < 2 ? 2 : work_frames;
   half_up_ = blur_half_up;
   blur_sum256_ = blur_sum256;
   profile_ = profile;
@@ -2453,22 +2456,22 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     for (int c = 0; c <= kWkMaxNx; c++) g.lv[l].wk_xg[c] = (int)xstrip[c < Ls.wk_nx ? c : Ls.wk_nx];
     g.lv[l].wk_fused = fused ? 1 : 0;
   }
-  const size_t S = (size_t)max_slots;
-  MSF_HIP_TRY(hipMalloc(&d_pyr_, S * g.pyr_bytes));
+  const size_t S = (size_t)max_slots, Wk = (size_t)work_frames_;
+  MSF_HIP_TRY(hipMalloc(&d_pyr_, Wk * g.pyr_bytes));
   MSF_HIP_TRY(hipMalloc(&d_tab_, htab.size() * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMemcpy(d_tab_, htab.data(), htab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  MSF_HIP_TRY(hipMalloc(&d_cand_cnt_, S * kOrbLevels * sizeof(uint32_t)));
-  MSF_HIP_TRY(hipMalloc(&d_tau_, 2 * S * kOrbLevels * sizeof(uint32_t)));
-  MSF_HIP_TRY(hipMemset(d_tau_, 0, 2 * S * kOrbLevels * sizeof(uint32_t)));
-  MSF_HIP_TRY(hipMalloc(&d_redo_, (1 + S * kOrbLevels) * sizeof(uint32_t)));
-  MSF_HIP_TRY(hipMalloc(&d_qstat_, S * kOrbLevels * kQStat * sizeof(uint32_t)));
-  MSF_HIP_TRY(hipMemset(d_qstat_, 0, S * kOrbLevels * kQStat * sizeof(uint32_t)));
-  MSF_HIP_TRY(hipMalloc(&d_cand_, S * g.cand_total * sizeof(uint32_t)));
-  MSF_HIP_TRY(hipMalloc(&d_cand_sc_, S * g.cand_total));
+  MSF_HIP_TRY(hipMalloc(&d_cand_cnt_, Wk * kOrbLevels * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMalloc(&d_tau_, 2 * Wk * kOrbLevels * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMemset(d_tau_, 0, 2 * Wk * kOrbLevels * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMalloc(&d_redo_, (1 + Wk * kOrbLevels) * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMalloc(&d_qstat_, Wk * kOrbLevels * kQStat * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMemset(d_qstat_, 0, Wk * kOrbLevels * kQStat * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMalloc(&d_cand_, Wk * g.cand_total * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMalloc(&d_cand_sc_, Wk * g.cand_total));
   MSF_HIP_TRY(hipMalloc(&d_walk_abort_, 16));
   MSF_HIP_TRY(hipMemset(d_walk_abort_, 0, 16));
-  MSF_HIP_TRY(hipMalloc(&d_s1_cnt_, S * kOrbLevels * sizeof(uint32_t)));
-  MSF_HIP_TRY(hipMalloc(&d_s1_, S * g.s1_total * sizeof(uint4)));
+  MSF_HIP_TRY(hipMalloc(&d_s1_cnt_, Wk * kOrbLevels * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMalloc(&d_s1_, Wk * g.s1_total * sizeof(uint4)));
   MSF_HIP_TRY(hipMalloc(&d_kp_, S * kKpCap * sizeof(msf_keypoint)));
   MSF_HIP_TRY(hipMalloc(&d_desc_, S * kKpCap * 32));
   MSF_HIP_TRY(hipMalloc(&d_kp_cnt_, S * sizeof(uint32_t)));
@@ -2478,8 +2481,8 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   MSF_HIP_TRY(hipMemset(d_done_, 0, (size_t)kSplitMaxPairs * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMemset(d_kp_cnt_, 0, S * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMemset(d_status_, 0, S * sizeof(uint32_t)));
-  MSF_HIP_TRY(hipMemset(d_cand_cnt_, 0, S * kOrbLevels * sizeof(uint32_t)));
-  MSF_HIP_TRY(hipMemset(d_s1_cnt_, 0, S * kOrbLevels * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMemset(d_cand_cnt_, 0, Wk * kOrbLevels * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMemset(d_s1_cnt_, 0, Wk * kOrbLevels * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), k_orb_bit_pattern_31, 1024));
   {
     std::vector<uint32_t> disc(2 * kDiscTasks, 0u);   // padding tasks: zero weights
@@ -2515,8 +2518,9 @@ __global__ __launch_bounds__(256) void k_fill_u32(uint32_t* a, uint32_t* b, uint
 
 hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
   if (n <= 0) return hipSuccess;
-  if (src.slot0 < 0 || src.slot0 + n > max_slots_) return hipErrorInvalidValue;
+  if (src.slot0 < 0 || src.slot0 + n > max_slots_ || n > work_frames_) return hipErrorInvalidValue;
   last_src_ = src;
+  last_n_ = n;
   if (ev_ok_) ev_begin_call();
   const hipError_t e = extract_range(src, n, st, ev_ok_ ? ev_ : nullptr);
   if (ev_ok_) ev_extract_pending_ = true;
@@ -2528,12 +2532,23 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
 hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st, hipEvent_t* evs) {
   const OrbGeometry& g = g_;
   hipError_t e;
-  if ((e = hipMemsetAsync(d_cand_cnt_ + (size_t)src.slot0 * kOrbLevels, 0, (size_t)n * kOrbLevels * 4, st))) return e;
+  // Work rows: frame i of this call uses row i of the per-call arrays (pyramid, candidate and stage-1 lists, thresholds,
+  // walker state), whatever feature slot its key points go to.  The kernels index everything by slot = slot0 + i, so the
+  // per-call arrays are passed as bases moved back by slot0 rows (never dereferenced below row 0: slots start at slot0).
+  const ptrdiff_t back = (ptrdiff_t)src.slot0;
+  uint8_t* const d_pyr_ = this->d_pyr_ - back * g.pyr_bytes;
+  uint32_t* const d_cand_cnt_ = this->d_cand_cnt_ - back * kOrbLevels;
+  uint32_t* const d_cand_ = this->d_cand_ - back * g.cand_total;
+  uint8_t* const d_cand_sc_ = this->d_cand_sc_ - back * g.cand_total;
+  uint32_t* const d_qstat_ = this->d_qstat_ - back * kOrbLevels * kQStat;
+  uint32_t* const d_s1_cnt_ = this->d_s1_cnt_ - back * kOrbLevels;
+  uint4* const d_s1_ = this->d_s1_ - back * g.s1_total;
+  if ((e = hipMemsetAsync(this->d_cand_cnt_, 0, (size_t)n * kOrbLevels * 4, st))) return e;
   if ((e = hipMemsetAsync(d_status_ + src.slot0, 0, (size_t)n * 4, st))) return e;
   if ((e = hipMemsetAsync(d_redo_, 0, 4, st))) return e;
   if (evs) hipEventRecord(evs[0], st);
-  uint32_t* tau = d_tau_;
-  uint32_t* tau_first = d_tau_ + (size_t)max_slots_ * kOrbLevels;
+  uint32_t* tau = d_tau_ - back * kOrbLevels;
+  uint32_t* tau_first = d_tau_ + (ptrdiff_t)work_frames_ * kOrbLevels - back * kOrbLevels;
   // A call of a few frames (the single-pair MatchFrames, a key frame upload) is latency-bound: a wave of the
   // streaming pass walks its strip in ~90 dependent steps, whereas the dense tile kernel is one short workgroup per
   // tile.  Such calls take k_resize + the dense kernel directly; the result is the same either way.
@@ -2572,7 +2587,7 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
   last_fused_ = fused;
   if (!dense && g.total_tiles > 0) {
     // the walker's per-(frame, level) state starts from zero: histograms, counters, "threshold published" words
-    if ((e = hipMemsetAsync(d_qstat_ + (size_t)src.slot0 * kOrbLevels * kQStat, 0, (size_t)n * kOrbLevels * kQStat * 4, st))) return e;
+    if ((e = hipMemsetAsync(this->d_qstat_, 0, (size_t)n * kOrbLevels * kQStat * 4, st))) return e;
     if ((e = hipMemsetAsync(d_walk_abort_, 0, 16, st))) return e;
   }
   if (fused) {
@@ -2737,25 +2752,29 @@ int OrbPipeline::debug_get(int what, int slot, int level, void* host_out, size_t
     return 0;
   }
   if (slot < 0 || slot >= max_slots_) return fail("slot out of range");
+  // key points and descriptors live per slot; everything else per work row of the LAST extraction
+  const int row = slot - last_src_.slot0;
+  if (what != MSF_DBG_KEYPOINTS && what != MSF_DBG_DESCRIPTORS && (row < 0 || row >= last_n_))
+    return fail("only the frames of the last extraction have a pyramid / candidate lists (per-call workspace)");
   switch (what) {
     case MSF_DBG_LEVEL_PIXELS: {
       if (level < 1 || level >= g.nlevels) return fail("level must be 1..7 (level 0 is the input frame)");
-      return copy_out(d_pyr_ + (size_t)slot * g.pyr_bytes + g.lv[level].pix_off, (size_t)g.lv[level].pitch * g.lv[level].h);
+      return copy_out(d_pyr_ + (size_t)row * g.pyr_bytes + g.lv[level].pix_off, (size_t)g.lv[level].pitch * g.lv[level].h);
     }
     case MSF_DBG_FAST_CANDS: {
       if (level < 0 || level >= g.nlevels) return fail("bad level");
       uint32_t n = 0;
-      hipMemcpy(&n, d_cand_cnt_ + (size_t)slot * kOrbLevels + level, 4, hipMemcpyDeviceToHost);
+      hipMemcpy(&n, d_cand_cnt_ + (size_t)row * kOrbLevels + level, 4, hipMemcpyDeviceToHost);
       if (n > (uint32_t)g.lv[level].cand_cap) n = g.lv[level].cand_cap;
       std::vector<uint32_t> tk(n);
       std::vector<uint8_t> ts(n);
       if (n) {
-        hipMemcpy(tk.data(), d_cand_ + (size_t)slot * g.cand_total + g.lv[level].cand_off, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
-        hipMemcpy(ts.data(), d_cand_sc_ + (size_t)slot * g.cand_total + g.lv[level].cand_off, n, hipMemcpyDeviceToHost);
+        hipMemcpy(tk.data(), d_cand_ + (size_t)row * g.cand_total + g.lv[level].cand_off, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        hipMemcpy(ts.data(), d_cand_sc_ + (size_t)row * g.cand_total + g.lv[level].cand_off, n, hipMemcpyDeviceToHost);
       }
       // the sampled quarter of a two-part streaming pass also lists corners below the level's final threshold
       uint32_t tfin = 0;
-      hipMemcpy(&tfin, d_tau_ + (size_t)slot * kOrbLevels + level, 4, hipMemcpyDeviceToHost);
+      hipMemcpy(&tfin, d_tau_ + (size_t)row * kOrbLevels + level, 4, hipMemcpyDeviceToHost);
       std::vector<int32_t> o;
       o.reserve(n * 3);
       for (uint32_t i = 0; i < n; i++)
@@ -2769,8 +2788,8 @@ int OrbPipeline::debug_get(int what, int slot, int level, void* host_out, size_t
     case MSF_DBG_FAST_TAU: {
       int32_t v[kOrbLevels][2];
       uint32_t t[2][kOrbLevels];
-      hipMemcpy(t[0], d_tau_ + (size_t)slot * kOrbLevels, sizeof(t[0]), hipMemcpyDeviceToHost);
-      hipMemcpy(t[1], d_tau_ + ((size_t)max_slots_ + slot) * kOrbLevels, sizeof(t[1]), hipMemcpyDeviceToHost);
+      hipMemcpy(t[0], d_tau_ + (size_t)row * kOrbLevels, sizeof(t[0]), hipMemcpyDeviceToHost);
+      hipMemcpy(t[1], d_tau_ + ((size_t)work_frames_ + row) * kOrbLevels, sizeof(t[1]), hipMemcpyDeviceToHost);
       for (int l = 0; l < kOrbLevels; l++) { v[l][0] = (int32_t)t[0][l]; v[l][1] = (int32_t)t[1][l]; }
       *n_bytes = sizeof(v);
       memcpy(host_out, v, sizeof(v) < cap ? sizeof(v) : cap);
@@ -2779,9 +2798,9 @@ int OrbPipeline::debug_get(int what, int slot, int level, void* host_out, size_t
     case MSF_DBG_STAGE1: {
       if (level < 0 || level >= g.nlevels) return fail("bad level");
       uint32_t n = 0;
-      hipMemcpy(&n, d_s1_cnt_ + (size_t)slot * kOrbLevels + level, 4, hipMemcpyDeviceToHost);
+      hipMemcpy(&n, d_s1_cnt_ + (size_t)row * kOrbLevels + level, 4, hipMemcpyDeviceToHost);
       std::vector<uint4> tmp(n);
-      if (n) hipMemcpy(tmp.data(), d_s1_ + (size_t)slot * g.s1_total + g.lv[level].s1_off, n * sizeof(uint4), hipMemcpyDeviceToHost);
+      if (n) hipMemcpy(tmp.data(), d_s1_ + (size_t)row * g.s1_total + g.lv[level].s1_off, n * sizeof(uint4), hipMemcpyDeviceToHost);
       std::vector<msf_keypoint> o(n);
       for (uint32_t i = 0; i < n; i++) {
         o[i].lx = tmp[i].x & 0xFFFF; o[i].ly = tmp[i].x >> 16; o[i].x = (float)o[i].lx; o[i].y = (float)o[i].ly;

@@ -71,7 +71,8 @@ class OrbPipeline {
   ~OrbPipeline();
   // returns empty string on success
   std::string init(int width, int height, int max_slots, bool blur_half_up, bool profile, bool dense_fast = false,
-                   bool level_size_mul_inv = false, int stream_min_frames = 8, bool blur_sum256 = false);
+                   bool level_size_mul_inv = false, int stream_min_frames = 8, bool blur_sum256 = false,
+                   int work_frames = 0);
   void destroy();
 
   // extract features of n frames into slots [src.slot0, src.slot0 + n)
@@ -90,10 +91,13 @@ class OrbPipeline {
  private:
   OrbGeometry g_{};
   int max_slots_ = 0;
+  int work_frames_ = 0;            // frames one extraction may hold = rows of the per-call arrays (0 at init: max_slots)
+  int last_n_ = 0;                 // frames of the last extraction (debug_get maps a slot to its work row)
   bool half_up_ = false, profile_ = false, blur_sum256_ = false;
   int stream_min_frames_ = 8;      // calls with fewer frames take the dense FAST kernel (latency), others the streaming pass
   int force_tau_ = 0;              // > 0: every (frame, level) starts at this FAST score threshold (20 = dense)
   // device storage
+  // per CALL (work_frames_ rows): pyramid, candidate lists, thresholds, walker state, stage-1 lists
   uint8_t* d_pyr_ = nullptr;
   uint32_t* d_tab_ = nullptr;      // resize tables per level: per group of 4 columns selectors / weights / pair offsets, per row source row | w1 << 16
   bool resize_shared_[kOrbLevels] = {};   // per level: k_resize may read three pixels' taps from one dword pair
@@ -114,6 +118,7 @@ class OrbPipeline {
   uint8_t* d_cand_sc_ = nullptr;   // [slots][cand_total] FAST score
   uint32_t* d_s1_cnt_ = nullptr;   // [slots][8]
   uint4* d_s1_ = nullptr;          // [slots][s1_total] (key, response bits, score, 0)
+  // per feature SLOT (max_slots_): what a later match reads
   msf_keypoint* d_kp_ = nullptr;   // [slots][kKpCap]
   uint8_t* d_desc_ = nullptr;      // [slots][kKpCap][32]
   uint32_t* d_kp_cnt_ = nullptr;   // [slots]
