@@ -94,13 +94,35 @@ def cpu_baseline_loftr(args, A, B, gpu_lists):
     one = max(time.perf_counter() - t0, 1e-4)
     n = int(min(len(A), max(args.cpu_loftr_pairs, args.cpu_seconds / one)))
     t0 = time.perf_counter()
-    res = [orc.MatchFrames(A[i], B[i]) for i in range(n)]
+    confs = [orc.run(A[i], B[i])["conf"] for i in range(n)]
+    res = [orc.decode(c) for c in confs]
     dt = time.perf_counter() - t0
-    mism = sum(0 if (len(m) == len(gpu_lists[i]) and np.array_equal(m, gpu_lists[i])) else 1 for i, m in enumerate(res))
+    # Parity rule for the lists: identical wherever |conf - threshold| > 1e-3.  An entry that only one side
+    # lists is therefore within tolerance iff the restatement's confidence of that (token, token) pair lies within 1e-3
+    # of the threshold; anything else is a real mismatch.
+    thr, tol = float(args.threshold), 1e-3
+    pairs_diff = entries_diff = beyond = 0
+    worst = 0.0
+    for i, m in enumerate(res):
+        a = set(map(tuple, np.asarray(m).reshape(-1, 4).tolist()))
+        b = set(map(tuple, np.asarray(gpu_lists[i]).reshape(-1, 4).tolist()))
+        d = a ^ b
+        if d or len(m) != len(gpu_lists[i]):
+            pairs_diff += 1
+        for (x1, y1, x2, y2) in d:
+            # token t <-> pixel ((t % 40) * 16, (t // 40) * 16) (dnnfeaturematcher.cpp:88-99)
+            margin = abs(float(confs[i][(y1 // 16) * 40 + x1 // 16, (y2 // 16) * 40 + x2 // 16]) - thr)
+            entries_diff += 1
+            worst = max(worst, margin)
+            beyond += int(margin > tol)
     return {"value": round(n / dt, 3), "unit": "frame-pairs/sec", "cores": cores, "kind": "port",
             "sample": "%d of the same 640x480 pairs, oracle/loftr_oracle.c (f32 C restatement, OpenMP with %d unpinned "
                       "threads), %.1f s" % (n, cores, dt),
-            "host": host, "match_list_mismatches_vs_gpu": mism}
+            "host": host,
+            "match_lists_vs_gpu": {"pairs": n, "pairs_with_a_difference": pairs_diff, "entries_on_one_side_only": entries_diff,
+                                   "entries_beyond_tolerance": beyond,
+                                   "largest_margin_of_such_an_entry": round(worst, 6), "tolerance": tol,
+                                   "rule": "lists identical wherever |conf - threshold| > 1e-3 (conf of the CPU restatement)"}}
 
 
 ORB_SWITCHES = ("blur_tie_even", "level_size_mul_inv", "blur_kernel_sum256")   # the oracle's / product's open choices
@@ -201,7 +223,7 @@ def run_workload(args, matcher, W, H, P, ratio_or_thr, loftr_f32, rank, world, l
     import torch
     import torch.distributed as dist
     from mono_slam_framework_amd import _lib, synth
-    from mono_slam_framework_amd.gather import MatchListGather
+    from mono_slam_framework_amd.gather import MatchListGather, RcclMatchListGather
     from mono_slam_framework_amd.matcher import DNNFeatureMatcher, FeatureMatcher
 
     mode = args.synth_mode if args.synth_mode is not None else (1 if matcher == "loftr" else 0)
@@ -215,27 +237,72 @@ def run_workload(args, matcher, W, H, P, ratio_or_thr, loftr_f32, rank, world, l
                                flags=_lib.MSF_FLAG_PROFILE | (_lib.MSF_FLAG_LOFTR_F32 if loftr_f32 else 0))
     out = torch.zeros((P, args.cap, 4), dtype=torch.int32, device=dev)
     cnt = torch.zeros((P,), dtype=torch.int32, device=dev)
-    packed = torch.zeros((P * args.cap, 4), dtype=torch.int32, device=dev)
-    offs = torch.zeros((P + 1,), dtype=torch.int32, device=dev)
+    # N > 1: the packed lists are double-buffered, so that the gather of step k (its own stream) runs beside the
+    # kernels of step k + 1
+    nbuf = 2 if world > 1 else 1
+    packed_b = [torch.zeros((P * args.cap, 4), dtype=torch.int32, device=dev) for _ in range(nbuf)]
+    offs_b = [torch.zeros((P + 1,), dtype=torch.int32, device=dev) for _ in range(nbuf)]
+    packed, offs = packed_b[0], offs_b[0]
     torch.cuda.synchronize()
     # the whole step is enqueued on ONE stream of its own (the *_device entry points are asynchronous on the stream
     # they are given; one stream in flight per handle: include/msf_abi.h)
     side = torch.cuda.Stream(device=dev)
     stream = side.cuda_stream
-    gather = MatchListGather(P, cdev, capacity_records=P * args.cap) if world > 1 else None
+    gather, gstream = None, None
+    if world > 1:
+        gstream = torch.cuda.Stream(device=dev)
+        if args.gather == "product":
+            # the product-side gather of libmsf.so (msf_gather_*: RCCL bound by the library); its 128-byte id travels
+            # over the process group that exists anyway
+            if args.backend != "nccl":
+                raise SystemExit("--gather product needs one GPU per rank (--backend nccl): RCCL refuses two ranks on one device")
+            idt = torch.zeros((128,), dtype=torch.uint8, device=cdev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(RcclMatchListGather.unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            gather = RcclMatchListGather(P, local_rank, rank, world, bytes(idt.cpu().numpy().tobytes()), P * args.cap)
+        else:
+            gather = MatchListGather(P, cdev, capacity_records=P * args.cap)
+    ev_packed = [torch.cuda.Event() for _ in range(nbuf)]     # step's lists are packed (recorded on `side`)
+    ev_gathered = [torch.cuda.Event() for _ in range(nbuf)]   # ... and have been sent (recorded on `gstream`)
     stage_acc = {}
     gathered = [0]
 
-    def step(timed):
+    def compute(k):
+        """extract + match + pack of step k on the compute stream; nothing here waits on the host"""
+        b = k % nbuf
         with torch.cuda.stream(side):
+            if gather is not None and k >= nbuf:
+                side.wait_event(ev_gathered[b])            # the gather of step k - 2 has read this buffer
             fm.match_batch_device(dA, dB, out, cnt, stream=stream)
-            fm.pack_matches_device(out, cnt, packed, offs, stream=stream)
-            if gather is not None:
-                # gather of variable-length match lists to rank 0 (all-gather of offsets, then exact-size
-                # ncclSend/ncclRecv over xGMI); no all-reduce in the data path
-                res = gather(packed.to(cdev), offs.to(cdev))
-                if res is not None:
-                    gathered[0] = sum(int(r[0].shape[0]) for r in res)
+            fm.pack_matches_device(out, cnt, packed_b[b], offs_b[b], stream=stream)
+            ev_packed[b].record(side)
+
+    def do_gather(k):
+        """gather of step k's variable-length match lists to rank 0 (all-gather of offsets, then exact-size
+        ncclSend / ncclRecv over xGMI; no all-reduce in the data path) on the gather stream: its one host wait -- the
+        totals -- is a wait for THAT stream, the compute stream already holds the next step's kernels"""
+        b = k % nbuf
+        with torch.cuda.stream(gstream):
+            gstream.wait_event(ev_packed[b])
+            if args.gather == "product":
+                res = gather(packed_b[b], offs_b[b], stream=gstream.cuda_stream)
+            else:
+                res = gather(packed_b[b].to(cdev), offs_b[b].to(cdev))
+            ev_gathered[b].record(gstream)
+        if res is not None:
+            gathered[0] = sum(int(r[0].shape[0]) for r in res)
+
+    def run_steps(n):
+        if gather is None:
+            for k in range(n):
+                compute(k)
+            return
+        compute(0)
+        for k in range(1, n):
+            compute(k)               # step k's kernels are enqueued ...
+            do_gather(k - 1)         # ... before the host waits for step k - 1's totals
+        do_gather(n - 1)
 
 
     def fence():
@@ -243,13 +310,12 @@ def run_workload(args, matcher, W, H, P, ratio_or_thr, loftr_f32, rank, world, l
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
+    if args.warmup:
+        run_steps(args.warmup)
     fence()
     fm.stage_times()          # drop the warm-up calls' stage times (msf_stage_times sums over the calls since the last query)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)            # enqueue only: nothing waits for the device inside the timed region
+    run_steps(args.steps)     # N = 1: enqueue only, nothing waits for the device inside the timed region
     fence()
     dt = time.perf_counter() - t0
     # HIP events recorded on the launch stream by every timed call (a ring of event sets), read after the region
@@ -321,7 +387,11 @@ def run_workload(args, matcher, W, H, P, ratio_or_thr, loftr_f32, rank, world, l
                        "overflow_pairs": int((cnt_h < 0).sum()),
                        "gathered_match_records_per_step": gathered[0] if world > 1 else int(offs[P].item()),
                        "shard": "pair p of a step -> rank p // pairs_per_gpu (contiguous blocks)",
-                       "collective_backend": args.backend if world > 1 else None},
+                       "collective_backend": args.backend if world > 1 else None,
+                       "gather": (None if world == 1 else
+                                  ("product: msf_gather_* of libmsf.so (ncclAllGather + ncclSend/ncclRecv)" if args.gather == "product"
+                                   else "torch.distributed (all_gather_into_tensor + batch_isend_irecv)") +
+                                  ", pipelined: step k's gather on its own stream beside step k+1's kernels")},
             "roofline": roofline,
         }
         if with_cpu:
@@ -331,7 +401,9 @@ def run_workload(args, matcher, W, H, P, ratio_or_thr, loftr_f32, rank, world, l
             if matcher == "orb":
                 res["cpu_baseline"]["reference_lib"] = opencv_probe(cargs, A, B, lists)
     fm.close()
-    del dA, dB, out, cnt, packed, offs
+    if world > 1 and args.gather == "product":
+        gather.close()
+    del dA, dB, out, cnt, packed, offs, packed_b, offs_b
     torch.cuda.empty_cache()
     return res
 
@@ -341,19 +413,34 @@ def synth_first_pair(rank, world, P):
     return rank * P
 
 
+def csrc_digest():
+    """sha256 (16 hex digits) over the kernel and host sources of libmsf.so: what a committed counter pass was measured on"""
+    import hashlib
+    d = os.path.join(ROOT, "mono_slam_framework_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".cpp", ".h", ".c")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def traffic_record(matcher, dom, P, W, H):
     """HBM bytes per launch of the dominant stage from the committed PMC passes (profiles/traffic_*.json, collected by
     tools/collect_profiles.sh: separate --pmc runs, FETCH_SIZE x 2 + WRITE_SIZE).  Not measured inside this run: the
     record names its source and the kernel versions it was taken at, and is dropped when the batch differs."""
-    tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % matcher)
+    name = "orb_vga" if (matcher == "orb" and W == 640) else matcher
+    tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % name)
     try:
         tj = json.load(open(tfile))
     except Exception:
         return None
     if tj.get("_pairs_per_gpu") != P or tj.get("_width", W) != W or dom not in tj:
         return None
-    return {"bytes": tj[dom], "per": "step (all launches of the stage)", "source": "profiles/traffic_%s.json" % matcher,
-            "measured_at": tj.get("_commit")}
+    return {"bytes": tj[dom], "per": "step (all launches of the stage)", "source": "profiles/traffic_%s.json" % name,
+            "measured_at": tj.get("_commit"),
+            # the kernel sources have changed since the counter pass: the figure describes an older build
+            "stale": tj.get("_csrc_sha16") != csrc_digest()}
 
 
 def mfma_busy_record(dom, P, loftr_f32):
@@ -369,7 +456,8 @@ def mfma_busy_record(dom, P, loftr_f32):
     if not mb or tj.get("_pairs_per_gpu") != P or dom not in mb:
         return None
     return {"value": mb[dom], "per_kernel": mb.get("_per_kernel"), "derivation": mb.get("_derivation"),
-            "source": "profiles/traffic_loftr%s.json" % ("_f32" if loftr_f32 else ""), "measured_at": tj.get("_commit")}
+            "source": "profiles/traffic_loftr%s.json" % ("_f32" if loftr_f32 else ""), "measured_at": tj.get("_commit"),
+            "stale": tj.get("_csrc_sha16") != csrc_digest()}
 
 
 def self_launch(args):
@@ -416,6 +504,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured configuration); gloo = rehearsal of the N > 1 code path "
                          "on a box with fewer GPUs than ranks (all ranks share cuda:0, results staged through host)")
+    ap.add_argument("--gather", default="torch", choices=["torch", "product"],
+                    help="N > 1: the gather of the match lists to rank 0 through torch.distributed (default) or through "
+                         "the product's own msf_gather_* (libmsf.so binds RCCL itself; never run on more than one GPU yet)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")

@@ -12,8 +12,9 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# r03: the fused walker (k_walk<true> of levels 0..6, k_walk<false> of the last level) and the threshold samplers between
-# its launches are the stage "pyramid_fast"; what is left of "fast_nms" is the check and the dense redo
+sys.path.insert(0, ROOT)
+# r04: ONE k_walk launch (threshold units + strips of all eight levels) is the stage "pyramid_fast"; "fast_nms" is the
+# check and the dense redo
 STAGE = {"k_resize": "pyramid", "k_fast": "fast_nms", "k_fast_tau": "pyramid_fast", "k_walk": "pyramid_fast",
          "k_fast_check": "fast_nms", "k_fast_redo": "fast_nms", "k_thr_harris": "select_harris", "k_select": "select_harris",
          "k_describe": "orient_describe", "k_match": "match", "k_conv": "backbone_convs", "k_tokens": "backbone_convs",
@@ -71,8 +72,9 @@ def mfma_busy(write):
     return out
 
 
-def main(tag="r03", steps=6):
+def main(tag="r04", steps=6, orb_width=1280, orb_pairs=1024, orb_name="orb"):
     base = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    steps = int(steps)
     for which in ("orb", "loftr", "loftr_f32"):
         if not os.path.isdir(os.path.join(base, which + "_fetch")):
             continue
@@ -91,16 +93,19 @@ def main(tag="r03", steps=6):
         mb = mfma_busy(write)
         if mb:
             out["_mfma_busy"] = mb
-        out["_pairs_per_gpu"] = 1024 if which == "orb" else 256   # the bench defaults the passes were run with
-        out["_width"] = 1280 if which == "orb" else 640
+        out["_pairs_per_gpu"] = int(orb_pairs) if which == "orb" else 256   # the bench arguments the passes were run with
+        out["_width"] = int(orb_width) if which == "orb" else 640
+        # the kernel sources the passes were measured on: bench.py marks the record stale when they have changed since
+        from bench import csrc_digest
+        out["_csrc_sha16"] = csrc_digest()
         try:
             import subprocess
             out["_commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
         except Exception:
             out["_commit"] = None
         out["_note"] = "HBM bytes per bench step (launch of the stage): 2 * FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, " + tag
-        json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_%s.json" % which), "w"), indent=1)
+        json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_%s.json" % (orb_name if which == "orb" else which)), "w"), indent=1)
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:2])
+    main(*sys.argv[1:6])
