@@ -30,24 +30,12 @@
 // queue is a statically named register set and the step loop is unrolled by the depth, so the depth sets the register
 // count: at 4 k_down16x / k_strip32x needed 164 registers and ran ONE workgroup of eight waves per CU (three waves per
 // SIMD allow twelve); see the defaults' comments for what each kernel measured.
-#ifndef MSF_LOFTR_STRIP8_DEPTH
 #define MSF_LOFTR_STRIP8_DEPTH 3   // k_strip8x: 4 / 3 / 2 steps measured 649 / 641 / 657 us per 512 images (120 / 108 / 96 registers)
-#endif
-#ifndef MSF_LOFTR_STEM_DEPTH
 #define MSF_LOFTR_STEM_DEPTH 4   // k_stem_strip8x: 858 / 867 / 898 us
-#endif
-#ifndef MSF_LOFTR_STRIP16_DEPTH
 #define MSF_LOFTR_STRIP16_DEPTH 2   // k_strip16x: 452 / 435 / 419 us
-#endif
-#ifndef MSF_LOFTR_STRIP32_DEPTH
 #define MSF_LOFTR_STRIP32_DEPTH 2   // k_strip32x: 484 / 492 us at one workgroup per CU (164 / 145 registers); 2 steps + the 128-register cap below: two workgroups, 368-375 us
-#endif
-#ifndef MSF_LOFTR_DOWN32_DEPTH
 #define MSF_LOFTR_DOWN32_DEPTH 4   // k_down32x: 479 / 484 / 505 us (232 / 200 / 164 registers: one workgroup per CU at any depth)
-#endif
-#ifndef MSF_LOFTR_DOWN16_DEPTH
 #define MSF_LOFTR_DOWN16_DEPTH 3   // 110 registers, two workgroups per CU, no spills (4: 164 registers, one workgroup): 584 -> 475 us
-#endif
 
 namespace msf {
 
@@ -761,16 +749,11 @@ constexpr int WAVES = 8;
 // waves one wave of stage 1 takes two jobs.  Tried (r03): 10 waves, 5 per stage, every wave at most one job -- the kernel
 // needs 118 VGPRs (24 of weight fragments, 32 of load queue), two workgroups per CU would need <= 96: forced there it
 // spills 60 B per lane and runs 1.47 ms against 0.62 (one workgroup per CU, unforced: not faster either).  8 it stays.
-#ifndef MSF_LOFTR_STRIP8_WAVES
-#define MSF_LOFTR_STRIP8_WAVES 8
-#endif
-constexpr int BLK_WAVES = MSF_LOFTR_STRIP8_WAVES;
 // Tried (r03): strips of 62 columns (MSF_LOFTR_STRIP8_S=62) -- stage 1 then writes 64 columns = 4 M tiles and stage 2
 // 62 = 4 tiles, 8 jobs for 8 waves in ONE round per step instead of 5 + 4 jobs in two; six strips instead of five, the last
 // overlapping its neighbour.  774 vs 617 us: exactly the 6 / 5 more strips, i.e. a step costs the same with one job less
 // on its busiest wave.  The kernel moves 2.46 GB in 0.617 ms = 4.0 TB/s of mixed read + write traffic: it runs at what
 // the memory system gives, and the step time is the prefetch distance (4 steps) into the loaded-memory latency.
-constexpr int SB_NARROW = 62;
 template <int NB>
 constexpr int lds_bytes() { return 16 * (2 * NB * 2 * RING + TAIL); }
 __device__ __forceinline__ int ring_row(int r) {   // r mod 12 for r >= -24 (multiply-shift exact below 1200)
@@ -962,31 +945,16 @@ __global__ __launch_bounds__(64 * WV) void k_strip8x(const float* __restrict__ i
   auto run = [&](auto is_loader) {
     constexpr bool kLd = decltype(is_loader)::value;
     float q0[8]; float q1[8];
-#if MSF_LOFTR_STRIP8_DEPTH >= 3
     float q2[8];
-#endif
-#if MSF_LOFTR_STRIP8_DEPTH >= 4
-    float q3[8];
-#endif
     if (kLd) {
       MSF_ST_ISSUE(q0, 0)
       MSF_ST_ISSUE(q1, 1)
-#if MSF_LOFTR_STRIP8_DEPTH >= 3
       MSF_ST_ISSUE(q2, 2)
-#endif
-#if MSF_LOFTR_STRIP8_DEPTH >= 4
-      MSF_ST_ISSUE(q3, 3)
-#endif
     }
     for (int n = 0; n < nsteps; n += kQDepth) {
       MSF_ST_STEP(q0, n)
       MSF_ST_STEP(q1, n + 1)
-#if MSF_LOFTR_STRIP8_DEPTH >= 3
       MSF_ST_STEP(q2, n + 2)
-#endif
-#if MSF_LOFTR_STRIP8_DEPTH >= 4
-      MSF_ST_STEP(q3, n + 3)
-#endif
     }
   };
   if (ldwave) run(std::true_type{});
@@ -1191,31 +1159,19 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8
   auto run = [&](auto is_loader) {
     constexpr bool kLd = decltype(is_loader)::value;
     uint32_t q0 = 0; uint32_t q1 = 0;
-#if MSF_LOFTR_STEM_DEPTH >= 3
     uint32_t q2 = 0;
-#endif
-#if MSF_LOFTR_STEM_DEPTH >= 4
     uint32_t q3 = 0;
-#endif
     if (kLd) {
       MSF_SS_ISSUE(q0, 0)
       MSF_SS_ISSUE(q1, 1)
-#if MSF_LOFTR_STEM_DEPTH >= 3
       MSF_SS_ISSUE(q2, 2)
-#endif
-#if MSF_LOFTR_STEM_DEPTH >= 4
       MSF_SS_ISSUE(q3, 3)
-#endif
     }
     for (int n = 0; n < nsteps; n += kQDepth) {
       MSF_SS_STEP(q0, n)
       MSF_SS_STEP(q1, n + 1)
-#if MSF_LOFTR_STEM_DEPTH >= 3
       MSF_SS_STEP(q2, n + 2)
-#endif
-#if MSF_LOFTR_STEM_DEPTH >= 4
       MSF_SS_STEP(q3, n + 3)
-#endif
     }
   };
   if (ldwave) run(std::true_type{});
@@ -1260,16 +1216,9 @@ struct DownW {
   const float *b1, *bsc, *b2;
 };
 
-#ifndef MSF_LOFTR_DOWN16_WPE
 #define MSF_LOFTR_DOWN16_WPE 0     // > 0: cap k_down16x's registers for this many waves per SIMD (with the 4-step queue the cap 4 spilled
                                    // 10 registers and still gained 7 %: two workgroups per CU; the 3-step queue needs no cap)
-#endif
-#if MSF_LOFTR_DOWN16_WPE
-#define MSF_DOWN16_ATTR __attribute__((amdgpu_waves_per_eu(MSF_LOFTR_DOWN16_WPE, MSF_LOFTR_DOWN16_WPE)))
-#else
-#define MSF_DOWN16_ATTR
-#endif
-__global__ __launch_bounds__(64 * down16::WAVES) MSF_DOWN16_ATTR void k_down16x(const float* __restrict__ in, DownW dw, float* __restrict__ out,
+__global__ __launch_bounds__(64 * down16::WAVES) void k_down16x(const float* __restrict__ in, DownW dw, float* __restrict__ out,
                                                                 int H, int W, int n_strips) {
   using namespace down16;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1451,24 +1400,15 @@ __global__ __launch_bounds__(64 * down16::WAVES) MSF_DOWN16_ATTR void k_down16x(
   auto run = [&](auto is_loader) {
     constexpr bool kLd = decltype(is_loader)::value;
     float q0[8], q1[8], q2[8];
-#if MSF_LOFTR_DOWN16_DEPTH == 4
-    float q3[8];
-#endif
     if (kLd) {
       MSF_DN_ISSUE(q0, 0)
       MSF_DN_ISSUE(q1, 1)
       MSF_DN_ISSUE(q2, 2)
-#if MSF_LOFTR_DOWN16_DEPTH == 4
-      MSF_DN_ISSUE(q3, 3)
-#endif
     }
     for (int n = 0; n < nsteps; n += kDepth) {
       MSF_DN_STEP(q0, n)
       MSF_DN_STEP(q1, n + 1)
       MSF_DN_STEP(q2, n + 2)
-#if MSF_LOFTR_DOWN16_DEPTH == 4
-      MSF_DN_STEP(q3, n + 3)
-#endif
     }
   };
   if (ldwave) run(std::true_type{});
@@ -1667,31 +1607,13 @@ __global__ __launch_bounds__(64 * strip16::WAVES) void k_strip16x(const float* _
   auto run = [&](auto is_loader) {
     constexpr bool kLd = decltype(is_loader)::value;
     float q0[8]; float q1[8];
-#if MSF_LOFTR_STRIP16_DEPTH >= 3
-    float q2[8];
-#endif
-#if MSF_LOFTR_STRIP16_DEPTH >= 4
-    float q3[8];
-#endif
     if (kLd) {
       MSF_S16_ISSUE(q0, 0)
       MSF_S16_ISSUE(q1, 1)
-#if MSF_LOFTR_STRIP16_DEPTH >= 3
-      MSF_S16_ISSUE(q2, 2)
-#endif
-#if MSF_LOFTR_STRIP16_DEPTH >= 4
-      MSF_S16_ISSUE(q3, 3)
-#endif
     }
     for (int n = 0; n < nsteps; n += kQDepth) {
       MSF_S16_STEP(q0, n)
       MSF_S16_STEP(q1, n + 1)
-#if MSF_LOFTR_STRIP16_DEPTH >= 3
-      MSF_S16_STEP(q2, n + 2)
-#endif
-#if MSF_LOFTR_STRIP16_DEPTH >= 4
-      MSF_S16_STEP(q3, n + 3)
-#endif
     }
   };
   if (ldwave) run(std::true_type{});
@@ -1723,14 +1645,8 @@ constexpr int NLOAD = 4 * 2 * XW;                  // loader threads: (channel b
 constexpr int LDS_BYTES = 16 * (XRING + TRING + 16);
 }  // namespace strip32
 
-#ifndef MSF_LOFTR_STRIP32_WPE
 #define MSF_LOFTR_STRIP32_WPE 4   // k_strip32x capped at 128 registers (with the 2-step queue 9 are spilled): two workgroups per CU instead of one
-#endif
-#if MSF_LOFTR_STRIP32_WPE
 #define MSF_STRIP32_ATTR __attribute__((amdgpu_waves_per_eu(MSF_LOFTR_STRIP32_WPE, MSF_LOFTR_STRIP32_WPE)))
-#else
-#define MSF_STRIP32_ATTR
-#endif
 __global__ __launch_bounds__(64 * strip32::WAVES) MSF_STRIP32_ATTR void k_strip32x(const float* __restrict__ in, const uint16_t* __restrict__ wx1,
                                                                   const float* __restrict__ b1, const uint16_t* __restrict__ wx2,
                                                                   const float* __restrict__ b2, float* __restrict__ out, int H,
@@ -1898,31 +1814,13 @@ __global__ __launch_bounds__(64 * strip32::WAVES) MSF_STRIP32_ATTR void k_strip3
   auto run = [&](auto is_loader) {
     constexpr bool kLd = decltype(is_loader)::value;
     float q0[8]; float q1[8];
-#if MSF_LOFTR_STRIP32_DEPTH >= 3
-    float q2[8];
-#endif
-#if MSF_LOFTR_STRIP32_DEPTH >= 4
-    float q3[8];
-#endif
     if (kLd) {
       MSF_S32_ISSUE(q0, 0)
       MSF_S32_ISSUE(q1, 1)
-#if MSF_LOFTR_STRIP32_DEPTH >= 3
-      MSF_S32_ISSUE(q2, 2)
-#endif
-#if MSF_LOFTR_STRIP32_DEPTH >= 4
-      MSF_S32_ISSUE(q3, 3)
-#endif
     }
     for (int n = 0; n < nsteps; n += kQDepth) {
       MSF_S32_STEP(q0, n)
       MSF_S32_STEP(q1, n + 1)
-#if MSF_LOFTR_STRIP32_DEPTH >= 3
-      MSF_S32_STEP(q2, n + 2)
-#endif
-#if MSF_LOFTR_STRIP32_DEPTH >= 4
-      MSF_S32_STEP(q3, n + 3)
-#endif
     }
   };
   if (ldwave) run(std::true_type{});
@@ -1954,15 +1852,8 @@ constexpr int NLOAD = 2 * 4 * INW;                 // loader threads: (channel b
 constexpr int LDS_BYTES = 16 * (IRING + 2 * TRING + 16);
 }  // namespace down32
 
-#ifndef MSF_LOFTR_DOWN32_WPE
 #define MSF_LOFTR_DOWN32_WPE 0     // > 0: cap k_down32x's registers for this many waves per SIMD
-#endif
-#if MSF_LOFTR_DOWN32_WPE
-#define MSF_DOWN32_ATTR __attribute__((amdgpu_waves_per_eu(MSF_LOFTR_DOWN32_WPE, MSF_LOFTR_DOWN32_WPE)))
-#else
-#define MSF_DOWN32_ATTR
-#endif
-__global__ __launch_bounds__(64 * down32::WAVES) MSF_DOWN32_ATTR void k_down32x(const float* __restrict__ in, DownW dw, float* __restrict__ out,
+__global__ __launch_bounds__(64 * down32::WAVES) void k_down32x(const float* __restrict__ in, DownW dw, float* __restrict__ out,
                                                                 int H, int W, int n_strips) {
   using namespace down32;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2151,31 +2042,19 @@ __global__ __launch_bounds__(64 * down32::WAVES) MSF_DOWN32_ATTR void k_down32x(
   auto run = [&](auto is_loader) {
     constexpr bool kLd = decltype(is_loader)::value;
     float q0[8]; float q1[8];
-#if MSF_LOFTR_DOWN32_DEPTH >= 3
     float q2[8];
-#endif
-#if MSF_LOFTR_DOWN32_DEPTH >= 4
     float q3[8];
-#endif
     if (kLd) {
       MSF_D32_ISSUE(q0, 0)
       MSF_D32_ISSUE(q1, 1)
-#if MSF_LOFTR_DOWN32_DEPTH >= 3
       MSF_D32_ISSUE(q2, 2)
-#endif
-#if MSF_LOFTR_DOWN32_DEPTH >= 4
       MSF_D32_ISSUE(q3, 3)
-#endif
     }
     for (int n = 0; n < nsteps; n += kQDepth) {
       MSF_D32_STEP(q0, n)
       MSF_D32_STEP(q1, n + 1)
-#if MSF_LOFTR_DOWN32_DEPTH >= 3
       MSF_D32_STEP(q2, n + 2)
-#endif
-#if MSF_LOFTR_DOWN32_DEPTH >= 4
       MSF_D32_STEP(q3, n + 3)
-#endif
     }
   };
   if (ldwave) run(std::true_type{});
@@ -3032,9 +2911,7 @@ __device__ __forceinline__ void layer_norm_cols(f32x4* v, const float* w, const 
 }
 
 // phase B: features on MFMA rows, tokens on columns; one wave carries 16 tokens through the whole block.
-#ifndef MSF_LOFTR_UPD_TILES
 #define MSF_LOFTR_UPD_TILES 2
-#endif
 constexpr int kUpdTilesPerWave = MSF_LOFTR_UPD_TILES;   // token tiles per wave and workgroup item (1 / 2 / 3 / 5 measured)
 __global__ __launch_bounds__(256) void k_attn_update(const float* __restrict__ xsrc, long long x_stride,
                                                      const float* __restrict__ kv, BlockW w, float* __restrict__ dst,
@@ -3255,8 +3132,8 @@ __global__ __launch_bounds__(256) void k_attn_update_x(const float* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tl = lane & 15, g = lane >> 4;
   // The block's weights (32 KB of fragments) are the same for every sequence: a workgroup stages them once and then walks
   // a contiguous run of (sequence, group of 8 token tiles) items, re-staging only the sequence's KV when it changes.
-  // Runs longer than one item did not pay (see Impl::upd_wgs): the other workgroups of a CU cover a prologue better than
-  // a serial run of items amortises it.
+  // Runs longer than one item did not pay (the host launches one item per workgroup): the other workgroups of a CU cover
+  // a prologue better than a serial run of items amortises it.
   for (int i = tid; i < 2 * 2 * 64; i += 256) {
     sWq[i] = reinterpret_cast<const bf16x8*>(w.wq_x)[i];
     sWm[i] = reinterpret_cast<const bf16x8*>(w.wm_x)[i];
@@ -3680,9 +3557,7 @@ __global__ __launch_bounds__(64 * kSimWaves) void k_sim_stats3(const __bf16* __r
 // owns three row tiles over a third of the column tiles, leaves its row sums in rpart[pair][third][1200] and its column
 // partials in cpart[pair][triple 0..24][1200]; k_sim_finish adds the 3 and the 25 in order.  Deterministic, no atomics.
 constexpr int kSimParts = NTOK / 16 / kSimRT;         // 25 row-tile triples per pair
-#ifndef MSF_LOFTR_SIM_COLPARTS
 #define MSF_LOFTR_SIM_COLPARTS 3
-#endif
 constexpr int kSimColParts = MSF_LOFTR_SIM_COLPARTS;  // an item covers 1 / kSimColParts of the column tiles (1, 3, 5 measured)
 constexpr int kSimColTiles = NTOK / 16 / kSimColParts;
 static_assert(kSimColTiles * kSimColParts == NTOK / 16, "column thirds");
@@ -4121,9 +3996,6 @@ struct LoftrPipeline::Impl {
   float* cpart = nullptr;    // [max_pairs][25][1200] column-sum partials
   float* rpart = nullptr;    // [max_pairs][3][1200] row-sum partials (one per third of the columns)
   uint32_t* sim_redo = nullptr;   // [max_pairs] pairs whose single-pass sums left the f32 range
-  int upd_wgs = 1 << 30;     // MSF_LOFTR_UPD_WGS: at most this many workgroups of k_attn_update_x, each walking a run of items with
-                             // the block's weights staged once.  Default: one item per workgroup -- 1 024 / 2 048 workgroups (one / two
-                             // rounds of the chip, 5 / 3 items each) measured 0.54 / 0.52 ms for the 8 blocks against 0.49
   bool sim_single = true;    // MSF_LOFTR_SIM_SINGLE=0: the two running-maximum passes always
   bool sim_force_redo = false;    // MSF_LOFTR_SIM_FORCE_REDO=1 (tests): every pair takes the fallback
   bool dense_head = false;
@@ -4131,8 +4003,8 @@ struct LoftrPipeline::Impl {
   bool split_bf16 = true;    // MSF_LOFTR_F32=1: every convolution on the f32 MFMA (no split-bf16 kernels)
   bool down_stream = true;   // MSF_LOFTR_DOWN=0: layer2's first block as two kernels instead of the streaming k_down16x
   int strip_min_images = 64; // backbone passes of fewer images use the banded kernels (run_backbone)
-  int strip_mode = 3;        // MSF_LOFTR_STRIP: layer1 as streaming strips: 3 = stem + block 1 in one pass, then block 2
-                             // (default); 1 = stem kernel, one pass per block; 2 = both blocks in one pass; 0 = k_block8x
+  int strip_mode = 3;        // MSF_LOFTR_STRIP: non-zero (default) = the streaming strip kernels (stem + block 1 in one pass,
+                             // then block 2, ...); 0 = the banded kernels calls of fewer than 64 images take anyway
   bool keep_debug = false;   // MSF_FLAG_KEEP_DEBUG: pair 0's confidence matrix + features for the parity tests
   float* conf_dbg = nullptr; // [1200][1200]
   float* feat_dbg = nullptr; // [2][1200][32]
@@ -4211,7 +4083,6 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
   {
     if (const char* d = getenv("MSF_LOFTR_DENSE_HEAD")) P.dense_head = atoi(d) != 0;   // tests: force the dense head
     if (const char* d = getenv("MSF_LOFTR_SIM_SINGLE")) P.sim_single = atoi(d) != 0;
-    if (const char* d = getenv("MSF_LOFTR_UPD_WGS")) { const int v = atoi(d); if (v >= 1) P.upd_wgs = v; }
     if (const char* d = getenv("MSF_LOFTR_SIM_FORCE_REDO")) P.sim_force_redo = atoi(d) != 0;
     if (const char* d = getenv("MSF_LOFTR_UNFUSED")) P.fuse_blocks = atoi(d) == 0;
     P.split_bf16 = !f32_convs;
@@ -4619,27 +4490,20 @@ void launch_block8x(const ConvDesc& ca, const ConvDesc& cb, const float* in, flo
                      out, ca.hout, ca.wout, n_bands);
 }
 
-// NB chained 8-channel BasicBlocks as one streaming pass (k_strip8x): convolutions cv[0 .. 2 NB)
-template <int NB>
+// one 8-channel BasicBlock as a streaming pass (k_strip8x<1>): convolutions cv[0], cv[1]
 void launch_strip8x(const ConvDesc* cv, const float* in, float* out, int n_img, hipStream_t st) {
-  constexpr int WVW = strip8::BLK_WAVES;
-  static const bool narrow = NB == 1 && getenv("MSF_LOFTR_STRIP8_S") && atoi(getenv("MSF_LOFTR_STRIP8_S")) == 62;
-  auto kern_n = k_strip8x<NB, WVW, strip8::SB_NARROW>;
-  auto kern_w = k_strip8x<NB, WVW, strip8::S>;
+  constexpr int NB = 1, WVW = strip8::WAVES;
+  auto kern = k_strip8x<NB, WVW, strip8::S>;
   constexpr int lds = strip8::lds_bytes<NB>();
   static std::once_flag attr_once;     // handles on several host threads (msf_multi) may arrive here together
   std::call_once(attr_once, [&] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern_n), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern_w), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   });
   StripW sw{};
   for (int c = 0; c < 2 * NB; c++) { sw.wx[c] = cv[c].d_wx; sw.b[c] = cv[c].d_b; }
-  const int Wd = cv[0].wout, Sd = narrow ? strip8::SB_NARROW : strip8::S;
+  const int Wd = cv[0].wout, Sd = strip8::S;
   const int n_strips = (Wd - Sd + Sd - 1) / Sd + 1;
-  if (narrow)
-    hipLaunchKernelGGL(kern_n, dim3(n_strips * n_img), dim3(64 * WVW), lds, st, in, sw, out, cv[0].hout, Wd, n_strips);
-  else
-    hipLaunchKernelGGL(kern_w, dim3(n_strips * n_img), dim3(64 * WVW), lds, st, in, sw, out, cv[0].hout, Wd, n_strips);
+  hipLaunchKernelGGL(kern, dim3(n_strips * n_img), dim3(64 * WVW), lds, st, in, sw, out, cv[0].hout, Wd, n_strips);
 }
 
 // stem + first 8-channel BasicBlock as one streaming pass over u8 frames (k_stem_strip8x): convolutions cv[0 .. 3)
@@ -4833,7 +4697,7 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
   // A streaming workgroup walks a whole 240-row strip (~70 us however few images there are): calls of fewer than 64
   // images -- the single-pair drop-in path -- keep the short banded workgroups (stateless pair: 0.84 vs 1.06 ms).
   const int strip_mode = ni >= P.strip_min_images ? P.strip_mode : 0;
-  const bool stem_fused = P.fuse_blocks && P.split_bf16 && strip_mode == 3;   // stem + block 1 in one pass -> cc
+  const bool stem_fused = P.fuse_blocks && P.split_bf16 && strip_mode != 0;   // stem + block 1 in one pass -> cc
   if (stem_fused) {
     launch_stem_strip8x(c, srcA, nA, srcB, nB, frame_stride, row_stride, cc, st);
   } else {
@@ -4843,13 +4707,7 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
   // layer1 @240x320, 8 ch
   if (P.fuse_blocks) {   // each BasicBlock in one kernel: the intermediate activation stays in LDS
     if (stem_fused) {
-      launch_strip8x<1>(c + 3, cc, a, ni, st);                                                       // a = 196
-    } else if (P.split_bf16 && strip_mode == 2) {
-      launch_strip8x<2>(c + 1, a, cc, ni, st);                                                       // both blocks in one pass
-      std::swap(a, cc);                                                                              // a = 196
-    } else if (P.split_bf16 && strip_mode == 1) {
-      launch_strip8x<1>(c + 1, a, cc, ni, st);
-      launch_strip8x<1>(c + 3, cc, a, ni, st);                                                       // a = 196
+      launch_strip8x(c + 3, cc, a, ni, st);                                                          // a = 196
     } else if (P.split_bf16) {
       launch_block8x(c[1], c[2], a, cc, ni, st);
       launch_block8x(c[3], c[4], cc, a, ni, st);                                                     // a = 196
@@ -4943,7 +4801,7 @@ hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf
     else hipLaunchKernelGGL(k_attn_kv, dim3(n), dim3(64 * kKvWaves), 0, st, seq[bi].s, ts, P.blk[bi], P.kv);
     if (P.split_bf16) {
       const int n_items = n * upd_blocks;
-      const int per_wg = (n_items + P.upd_wgs - 1) / P.upd_wgs;
+      const int per_wg = 1;     // one item per workgroup (runs of 3 / 5 items with the weights staged once: 0.52 / 0.54 vs 0.49 ms)
       // blocks 6 and 7 write the final f0 and f1: they also write the head's scaled features and bf16 planes
       float* fs_o = bi == 6 ? P.fsc : bi == 7 ? P.fsc + (long long)P.max_pairs * ts : nullptr;
       __bf16* pl_o = bi == 6 ? P.fsp : bi == 7 ? P.fsp + (long long)P.max_pairs * 3 * ts : nullptr;

@@ -1993,7 +1993,7 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
           // 24 bits of tx (0x400000 + ix) and everything else is folded into samp_base (arithmetic modulo 2^32)
           const uint32_t addr = mad_u24(tx, 2u * HC, (ty << 1) + samp_base);
           const __attribute__((address_space(3))) uint32_t* q =
-              (const __attribute__((address_space(3))) uint32_t*)(addr & ~3u);
+              (const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(addr & ~3u);   // (uintptr_t: the host pass sees a 64-bit pointer)
           const uint32_t sh = addr & 2u;                 // the seven u16 start in the upper half of the first dword
           const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
           const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
