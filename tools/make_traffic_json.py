@@ -72,10 +72,10 @@ def mfma_busy(write):
     return out
 
 
-def main(tag="r04", steps=6, orb_width=1280, orb_pairs=1024, orb_name="orb"):
+def main(tag="r04", steps=6):
     base = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     steps = int(steps)
-    for which in ("orb", "loftr", "loftr_f32"):
+    for which in ("orb", "orb_vga", "loftr", "loftr_f32"):
         if not os.path.isdir(os.path.join(base, which + "_fetch")):
             continue
         fetch, write = load(os.path.join(base, which + "_fetch"), steps), load(os.path.join(base, which + "_write"), steps)
@@ -93,8 +93,9 @@ def main(tag="r04", steps=6, orb_width=1280, orb_pairs=1024, orb_name="orb"):
         mb = mfma_busy(write)
         if mb:
             out["_mfma_busy"] = mb
-        out["_pairs_per_gpu"] = int(orb_pairs) if which == "orb" else 256   # the bench arguments the passes were run with
-        out["_width"] = int(orb_width) if which == "orb" else 640
+        # the bench arguments the passes were run with (tools/collect_profiles.sh)
+        out["_pairs_per_gpu"] = {"orb": 1024, "orb_vga": 4096}.get(which, 256)
+        out["_width"] = 1280 if which == "orb" else 640
         # the kernel sources the passes were measured on: bench.py marks the record stale when they have changed since
         from bench import csrc_digest
         out["_csrc_sha16"] = csrc_digest()
@@ -104,8 +105,8 @@ def main(tag="r04", steps=6, orb_width=1280, orb_pairs=1024, orb_name="orb"):
         except Exception:
             out["_commit"] = None
         out["_note"] = "HBM bytes per bench step (launch of the stage): 2 * FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, " + tag
-        json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_%s.json" % (orb_name if which == "orb" else which)), "w"), indent=1)
+        json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_%s.json" % which), "w"), indent=1)
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:6])
+    main(*sys.argv[1:3])
