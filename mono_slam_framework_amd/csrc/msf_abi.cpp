@@ -281,14 +281,14 @@ int fetch_single(msf_handle* h, msf_match* out, int32_t cap_per_pair, int32_t* n
   if ((e = hipStreamSynchronize(st)) != hipSuccess) return hip_fail(h, "hipStreamSynchronize", e);
   const int32_t c = *reinterpret_cast<const int32_t*>(h->h_pin);
   n_out[0] = c;
-  if (c < 0) return fail(h, MSF_ERR_CAPACITY, "a fixed-capacity device list overflowed for at least one pair");
+  if (c < 0) return fail(h, MSF_ERR_CAPACITY, "at least one pair has no valid result (n_out = -1): a fixed-capacity device list overflowed, or a unit of the ORB walker launch gave up a bounded wait");
   const int avail = c < h->stage_cap ? c : h->stage_cap;
   const int w = avail < cap_per_pair ? avail : cap_per_pair;
   const int w1 = w < wfirst ? w : wfirst;
   if (w1 > 0) std::memcpy(out, h->h_pin + 1, (size_t)w1 * sizeof(msf_match));
   if (w > w1 && (e = hipMemcpy(out + w1, h->d_out + w1, (size_t)(w - w1) * sizeof(msf_match), hipMemcpyDeviceToHost)) != hipSuccess)
     return hip_fail(h, "hipMemcpy", e);
-  if (avail < c && cap_per_pair > avail) return fail(h, MSF_ERR_CAPACITY, "a fixed-capacity device list overflowed for at least one pair");
+  if (avail < c && cap_per_pair > avail) return fail(h, MSF_ERR_CAPACITY, "at least one pair has no valid result (n_out = -1): a fixed-capacity device list overflowed, or a unit of the ORB walker launch gave up a bounded wait");
   return MSF_OK;
 }
 
@@ -491,7 +491,7 @@ int msf_match_batch(msf_handle* h, int32_t n_pairs, const msf_image* a, const ms
           return hip_fail(h, "hipMemcpy", e);
       }
     }
-    if (capacity) return fail(h, MSF_ERR_CAPACITY, "a fixed-capacity device list overflowed for at least one pair");
+    if (capacity) return fail(h, MSF_ERR_CAPACITY, "at least one pair has no valid result (n_out = -1): a fixed-capacity device list overflowed, or a unit of the ORB walker launch gave up a bounded wait");
     return MSF_OK;
   } catch (...) {
     return host_exception(h, "msf_match_batch");
@@ -703,7 +703,7 @@ int msf_match_one_to_many(msf_handle* h, int32_t query_slot, int32_t n, const in
                                     (size_t)w * sizeof(msf_match), hipMemcpyDeviceToHost)) != hipSuccess) return hip_fail(h, "hipMemcpy", e);
       }
     }
-    if (capacity) return fail(h, MSF_ERR_CAPACITY, "a fixed-capacity device list overflowed for at least one pair");
+    if (capacity) return fail(h, MSF_ERR_CAPACITY, "at least one pair has no valid result (n_out = -1): a fixed-capacity device list overflowed, or a unit of the ORB walker launch gave up a bounded wait");
     return MSF_OK;
   } catch (...) {
     return host_exception(h, "msf_match_one_to_many");

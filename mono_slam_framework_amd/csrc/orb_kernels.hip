@@ -1383,7 +1383,7 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
                                              uint32_t* cand_key, uint8_t* cand_sc, uint32_t* redo_cnt, uint32_t* redo_list,
                                              uint32_t* status, uint32_t* abort_word, int l_lo, int l_hi, int n_frames,
                                              int margin_pct, int dyn, int force_tau, int predict_pct, int chain,
-                                             int resize_mask) {
+                                             int resize_mask, int test_stall_frame) {
   __shared__ StreamSmem sm;
   const int xcd = (int)(blockIdx.x & 7u);
   int r = (int)(blockIdx.x >> 3);                // unit of this XCD
@@ -1398,6 +1398,9 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
     r -= units;
   }
   if (r < nfx) {
+    // test hook (MSF_TEST_HOOKS=1 + MSF_ORB_TEST_STALL_FRAME=f, never set otherwise): the threshold of (frame f, level 3)
+    // is never published, so that the bounded waits, the abort word and the per-frame error flag can be exercised
+    if (f0 + r == test_stall_frame && l == 3) return;
     tau_unit(*reinterpret_cast<TauSmem*>(&sm), g, src, pyr, tau, tau_first, redo_cnt, redo_list, qstat, status, abort_word,
              force_tau, predict_pct, chain, l, f0 + r);
     return;
@@ -2271,6 +2274,8 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   // geometries whose tables fail the host checks below; tests compare it with the fused default, in which the walker of
   // level l - 1 also makes level l)
   if (const char* e = getenv("MSF_ORB_UNFUSED")) fused_ = atoi(e) == 0;
+  if (getenv("MSF_TEST_HOOKS"))
+    if (const char* e = getenv("MSF_ORB_TEST_STALL_FRAME")) test_stall_frame_ = atoi(e);
   // MSF_ORB_WALK_PER_LEVEL=1: the fused walker as one launch per level instead of one launch over all levels (tests
   // compare the two: the in-launch dependency waits are then met the moment a unit starts)
   if (const char* e = getenv("MSF_ORB_WALK_PER_LEVEL")) walk_per_level_ = atoi(e) != 0;
@@ -2582,7 +2587,7 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
     const long long wgs = 8ll * ((n + 7) / 8) * per_frame;
     hipLaunchKernelGGL(k_walk, dim3((unsigned)wgs), dim3(64), 0, st, g, src, d_pyr_, d_tab_, tau, tau_first, d_qstat_,
                        d_cand_cnt_, d_cand_, d_cand_sc_, d_redo_, d_redo_ + 1, d_status_, d_walk_abort_, l_lo, l_hi, n,
-                       tau2_margin_pct_, dyn, force_tau, predict_pct, chain, resize_mask);
+                       tau2_margin_pct_, dyn, force_tau, predict_pct, chain, resize_mask, test_stall_frame_);
   };
   last_fused_ = fused;
   if (!dense && g.total_tiles > 0) {

@@ -109,6 +109,7 @@ class OrbPipeline {
   bool fused_ = true;                     // MSF_ORB_UNFUSED=1 clears it: k_resize x 7, then one FAST-only walker launch
   bool walk_per_level_ = false;           // MSF_ORB_WALK_PER_LEVEL=1: the fused walker as one launch per level (the
                                           // in-launch waits are then met at once); tests compare it with the one-launch default
+  int test_stall_frame_ = -1;             // MSF_TEST_HOOKS + MSF_ORB_TEST_STALL_FRAME: see k_walk
   int tau2_margin_pct_ = 200;             // MSF_ORB_TAU2_MARGIN_PCT
   bool resize_generic_ = false;           // MSF_ORB_RESIZE_GENERIC: never
   uint32_t* d_cand_cnt_ = nullptr; // [slots][8]

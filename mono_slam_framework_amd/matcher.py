@@ -99,6 +99,19 @@ class _Matcher:
         self._check(self._L.msf_match_batch(self._h, n, A, B, out.ctypes.data, cap, cnt.ctypes.data))
         return [out[i, :min(cnt[i], cap)].view(np.int32).reshape(-1, 4).copy() for i in range(n)]
 
+    def match_batch_raw(self, frames1, frames2, cap=4096):
+        """match_batch that tolerates MSF_ERR_CAPACITY: returns (n_out int32 [n] with -1 for a pair without a valid result,
+        lists).  Any other error raises."""
+        n = len(frames1)
+        A = (_lib.Image * n)(*[self._image(f) for f in frames1])
+        B = (_lib.Image * n)(*[self._image(f) for f in frames2])
+        out = np.zeros((n, cap), _lib.MATCH_DTYPE)
+        cnt = np.zeros((n,), np.int32)
+        rc = self._L.msf_match_batch(self._h, n, A, B, out.ctypes.data, cap, cnt.ctypes.data)
+        if rc not in (_lib.MSF_OK, _lib.MSF_ERR_CAPACITY):
+            self._check(rc)
+        return cnt, [out[i, :min(max(cnt[i], 0), cap)].view(np.int32).reshape(-1, 4).copy() for i in range(n)]
+
     def match_batch_device(self, d_a, d_b, d_out, d_n_out, stream=None):
         """d_a/d_b: torch uint8 CUDA tensors [n, H, W(pitch)] resident in HBM; d_out int32 [n, cap, 4];
         d_n_out int32 [n].  Asynchronous on `stream` (an int hipStream_t; None = handle stream + sync)."""

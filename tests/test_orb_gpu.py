@@ -576,3 +576,32 @@ def test_one_launch_walker_back_to_back_calls_and_small_batches():
     st = fm.stage_times()                            # sums over the four calls; the first stage is the one walker launch
     assert set(st) == {"pyramid_fast", "fast_nms", "select_harris", "orient_describe", "match"} and all(v > 0 for v in st.values())
     fm.close()
+
+
+@pytest.mark.gpu
+def test_a_unit_that_never_publishes_ends_in_flagged_frames_not_in_a_hang(monkeypatch):
+    """The one-launch walker's waits are bounded: with the test hook that withholds the threshold of (frame 5, level 3),
+    the strips of that (frame, level) give up after ~1 s, flag the frame, raise the abort word, every unit still waiting
+    leaves, and the call returns: the pair of frame 5 reports n_out = -1 (MSF_ERR_CAPACITY from the batch call, never a
+    silent wrong list), every other pair is the oracle's, and the same handle works normally afterwards."""
+    import time
+    from mono_slam_framework_amd import _lib
+    from mono_slam_framework_amd.matcher import FeatureMatcher, MsfError
+    n, w, h = 16, 640, 480
+    A, B = synth.synth_batch(9900, n, w, h, mode=0)
+    monkeypatch.setenv("MSF_TEST_HOOKS", "1")
+    monkeypatch.setenv("MSF_ORB_TEST_STALL_FRAME", "5")
+    fm = FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=_lib.MSF_FLAG_NO_FRAME_CACHE)
+    t0 = time.time()
+    num, lists = fm.match_batch_raw(list(A), list(B), cap=1024)
+    assert time.time() - t0 < 30.0
+    assert num[5] == -1 and (np.delete(num, 5) >= 0).all(), num
+    orc = oracle_orb.FeatureMatcherOracle(0.7)
+    for i in (0, 4, 6, n - 1):
+        np.testing.assert_array_equal(lists[i], orc.MatchFrames(A[i], B[i]))
+    fm.close()
+    monkeypatch.delenv("MSF_ORB_TEST_STALL_FRAME")
+    ok = FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=_lib.MSF_FLAG_NO_FRAME_CACHE)
+    got = ok.match_batch(list(A), list(B), cap=1024)
+    np.testing.assert_array_equal(got[5], orc.MatchFrames(A[5], B[5]))
+    ok.close()
