@@ -125,6 +125,9 @@ int run_device(msf_handle* h, int n_pairs, const uint8_t* d_a, const uint8_t* d_
     msf::FrameSrc src{d_a, d_b, n_pairs, scratch0, frame_stride, (int)row_stride};
     hipError_t e = h->orb.extract(src, 2 * n_pairs, st);
     if (e != hipSuccess) return hip_fail(h, "orb extract", e);
+    if (h->orb.take_degraded_note())    // not an error of THIS call: the text is there for whoever reads msf_last_error
+      h->err = "note: a unit of an earlier ORB walker launch gave up a bounded wait (its pairs reported n_out = -1); "
+               "this handle now launches the walker one level at a time";
     e = h->orb.match(n_pairs, nullptr, nullptr, h->cfg.threshold, d_out, cap, d_n_out, st, scratch0);
     if (e != hipSuccess) return hip_fail(h, "orb match", e);
     return MSF_OK;

@@ -2228,7 +2228,8 @@ OrbPipeline::~OrbPipeline() { destroy(); }
 
 void OrbPipeline::destroy() {
   hipFree(d_tau_); hipFree(d_redo_); hipFree(d_qstat_); hipFree(d_walk_abort_);
-  d_tau_ = nullptr; d_redo_ = nullptr; d_qstat_ = nullptr; d_walk_abort_ = nullptr;
+  if (h_walk_abort_) hipHostFree(h_walk_abort_);
+  d_tau_ = nullptr; d_redo_ = nullptr; d_qstat_ = nullptr; d_walk_abort_ = nullptr; h_walk_abort_ = nullptr;
   hipFree(d_pyr_); hipFree(d_tab_); hipFree(d_cand_cnt_); hipFree(d_cand_); hipFree(d_cand_sc_); hipFree(d_qres_); hipFree(d_done_); hipFree(d_s1_cnt_); hipFree(d_s1_);
   hipFree(d_kp_); hipFree(d_desc_); hipFree(d_kp_cnt_); hipFree(d_status_);
   d_pyr_ = nullptr; d_tab_ = nullptr; d_cand_cnt_ = nullptr; d_cand_ = nullptr; d_cand_sc_ = nullptr; d_qres_ = nullptr; d_done_ = nullptr; d_s1_cnt_ = nullptr;
@@ -2475,6 +2476,8 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   MSF_HIP_TRY(hipMalloc(&d_cand_sc_, Wk * g.cand_total));
   MSF_HIP_TRY(hipMalloc(&d_walk_abort_, 16));
   MSF_HIP_TRY(hipMemset(d_walk_abort_, 0, 16));
+  MSF_HIP_TRY(hipHostMalloc(&h_walk_abort_, 16, hipHostMallocDefault));
+  h_walk_abort_[0] = 0u;
   MSF_HIP_TRY(hipMalloc(&d_s1_cnt_, Wk * kOrbLevels * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMalloc(&d_s1_, Wk * g.s1_total * sizeof(uint4)));
   MSF_HIP_TRY(hipMalloc(&d_kp_, S * kKpCap * sizeof(msf_keypoint)));
@@ -2526,6 +2529,15 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
   if (src.slot0 < 0 || src.slot0 + n > max_slots_ || n > work_frames_) return hipErrorInvalidValue;
   last_src_ = src;
   last_n_ = n;
+  // A unit of an earlier walker launch gave up a bounded wait (its frames were flagged): the one-launch form rests on
+  // workgroups being started in index order, which is observed, not promised.  From now on this handle launches one level
+  // at a time (every wait is then met at once); the word arrives with the asynchronous copy behind each launch, so this
+  // may take effect a few calls after the one that failed.
+  if (h_walk_abort_ && h_walk_abort_[0] != 0u && !walk_per_level_) {
+    walk_per_level_ = true;
+    degraded_note_ = true;
+  }
+  if (test_stall_frame_ >= 0 && test_stall_calls_++ > 0) test_stall_frame_ = -1;   // the test hook stalls the first call only
   if (ev_ok_) ev_begin_call();
   const hipError_t e = extract_range(src, n, st, ev_ok_ ? ev_ : nullptr);
   if (ev_ok_) ev_extract_pending_ = true;
@@ -2607,6 +2619,7 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
     } else {
       launch_walk(0, g.nlevels - 1, 1, mask, predict);
     }
+    hipMemcpyAsync(h_walk_abort_, d_walk_abort_, 4, hipMemcpyDeviceToHost, st);   // read at the start of a later call
     if (evs) hipEventRecord(evs[1], st);
   } else {
     for (int l = 1; l < g.nlevels; l++) launch_resize(l);

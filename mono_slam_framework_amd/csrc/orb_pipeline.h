@@ -87,6 +87,9 @@ class OrbPipeline {
   int max_slots() const { return max_slots_; }
   int debug_get(int what, int slot, int level, void* host_out, size_t cap, size_t* n_bytes, std::string* err);
   int stage_times(const char** names, float* ms, int cap);
+  // true once after the handle switched to per-level walker launches because a unit of an earlier launch gave up waiting
+  bool take_degraded_note() { const bool d = degraded_note_; degraded_note_ = false; return d; }
+  bool walk_per_level() const { return walk_per_level_; }
 
  private:
   OrbGeometry g_{};
@@ -104,6 +107,9 @@ class OrbPipeline {
   uint32_t* d_qstat_ = nullptr;           // [slots][levels][kQStat]: per (slot, level) the score histogram of the sampled quarter's
                                           // corners, the thresholds and the done counters of the walker launch (see k_walk)
   uint32_t* d_walk_abort_ = nullptr;      // [4] the walker launch's abort word (a unit gave up waiting); zeroed per call
+  uint32_t* h_walk_abort_ = nullptr;      // pinned copy of it, written behind every walker launch, read by later calls
+  bool degraded_note_ = false;            // the handle has just fallen back to per-level launches (reported once)
+  int test_stall_calls_ = 0;
   bool fast_two_part_ = true;             // MSF_ORB_FAST_ONE_PART=1 clears it: no refinement of the first threshold
   int tau_predict_pct_ = 300;             // MSF_ORB_TAU_PREDICT (0 = sample every level)
   bool fused_ = true;                     // MSF_ORB_UNFUSED=1 clears it: k_resize x 7, then one FAST-only walker launch

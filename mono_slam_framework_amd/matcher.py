@@ -200,6 +200,10 @@ class _Matcher:
             lists = [out[i, :min(max(num[i], 0), cap)].view(np.int32).reshape(-1, 4).copy() for i in range(n)]
         return num, nmp, lists
 
+    def last_error(self):
+        """msf_last_error(h): the text of the handle's last failure -- or note (a call that succeeded may leave one)"""
+        return self._L.msf_last_error(self._h).decode()
+
     def stage_times(self):
         names = (C.c_char_p * 16)()
         ms = (C.c_float * 16)()
