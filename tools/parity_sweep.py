@@ -14,7 +14,7 @@ from oracle import orb as oracle_orb                           # noqa: E402
 
 
 def sweep(w, h, n, mode, first, ratio=0.6, threads=16):
-    fm = FeatureMatcher(ratio, w, h, max_batch_pairs=128)   # 256 frames per call: the fused walker in two chains
+    fm = FeatureMatcher(ratio, w, h, max_batch_pairs=128)   # 256 frames per call: the one-launch walker with 240-row strips
     bad = 0
     tot = 0
     for p0 in range(0, n, 128):
