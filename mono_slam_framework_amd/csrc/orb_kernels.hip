@@ -489,7 +489,8 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
 // of a level, a 256-px window (lane i holds 4 px), top to bottom, with no barrier:
 //  * every pixel is fetched once, as one dword per lane and row, four rows ahead of its use (register queue q0..q3);
 //  * the rows live in a wave-private LDS ring of 16 rows;
-//  * the cardinal prefilter of row y reads rows y-3, y, y+3 from the ring, the left / right dwords come by DPP;
+//  * the cardinal prefilter of row y compares it with row y+3 and with its own pixels three to the left / right (DPP); its
+//    comparison with row y-3 is the one row y-3 made three rows earlier (see STREAM_PRE);
 //  * groups with a survivor leave one record; every few rows (or when the record list fills) the records are expanded
 //    into one pixel list, scored exactly (darker-type pixels on the complemented values, so one routine serves both
 //    polarities), the scores go into a second ring and, as (address, row) hits, into a list; strict 3x3 NMS +
@@ -505,15 +506,13 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
 // of level l - 1 is then read from HBM once per step (plus the strips' halos) instead of once by k_resize and once by
 // the FAST pass: 17.2 -> 10.5 GB per 1024-pair 720p step for pyramid + FAST.
 //
-// Threshold refinement inside the launch (was: two launches with k_fast_tau2 between them).  The strips whose flat index
-// is a multiple of 4 -- a quarter of the level, spread over it -- come first in the launch order and run at the
-// sampler's tau; each adds the scores of the corners it emitted to a per-(frame, level) histogram and counts itself
-// done.  A strip of the other three quarters that finds the quarter complete when it starts raises tau to the largest
-// multiple of 4 at which the quarter still holds margin % of its share of 2N (k_fast_tau2's rule) and publishes it with
-// an atomic max; one that does not (dispatch order is no contract) runs at the value it read.  Whatever a strip read,
-// it finds every maximum >= its own tau, so every maximum >= the final tau[idx] (the maximum over the strips) is in the
-// list; k_fast_check counts those and a level that falls short is redone densely: the result is the dense one bit for
-// bit in every interleaving.
+// Threshold refinement inside the launch.  The strips of a level whose index is a multiple of 4 -- a quarter of the level,
+// spread over it -- come first in the launch order and run at the level's first threshold (tau_unit); each adds the scores
+// of the corners it emitted to a per-(frame, level) histogram and counts itself done.  A strip of the other three quarters
+// waits for that count, raises tau to the largest multiple of 4 at which the quarter still holds margin % of its share of
+// 2N and publishes it with an atomic max.  Whatever threshold a strip ran at, it finds every maximum >= its own tau, so
+// every maximum >= the final tau[idx] (the maximum over the strips) is in the list; k_fast_check counts those and a level
+// that falls short is redone densely: the result is the dense one bit for bit whatever the thresholds were.
 constexpr int kTauBins = 64;             // score histogram bins of width 4 (the threshold sample, the emitted corners)
 // State of a (slot, level) while the walker launch runs: kQStat words, zeroed (hipMemsetAsync) before the launch, every
 // access an agent-scope atomic.  It is both the statistics the thresholds come from and the dependency tracking of the
@@ -1164,8 +1163,8 @@ __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g,
 // retainBest(2N) (KeyPointsFilter) keeps, per level, the strict maxima whose FAST score reaches the
 // (2N)-th largest one: a few hundred of the tens of thousands a textured frame has.  Every maximum with score >= tau
 // is found exactly by fast_tile(tau), so if at least 2N of them exist the kept set is already complete and nothing
-// below tau was ever needed.  k_fast_tau picks tau per (frame, level) from exact scores on a sparse sample of the
-// level, k_fast_check verifies the count afterwards and queues the (frame, level)s that fell short for a dense
+// below tau was ever needed.  tau_unit (a unit of the walker launch) picks the first tau per (frame, level) -- predicted
+// from the level above or from exact scores on a sparse sample of the level --, k_fast_check verifies the count afterwards and queues the (frame, level)s that fell short for a dense
 // (tau = fastThreshold) second pass by k_fast_redo.  Whatever tau is picked, the result is the dense one bit for bit.
 constexpr int kTauMinHits = 24;       // sample hits the estimate must rest on
 constexpr int kTauOversample = 10;    // estimated pixels with score >= tau per key point to keep: a strict maximum stands
@@ -2369,7 +2368,7 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     L.wk_fused = 0;
     L.tab_yemit = L.tab_xstrip = 0;
     if (L.tiles_x * L.tiles_y > g.max_level_tiles) g.max_level_tiles = L.tiles_x * L.tiles_y;
-    // sample lattice of k_fast_tau: about 4096 pixels of the kept region in runs of 4 (one dword), rows sparser than
+    // sample lattice of tau_unit: about 4096 pixels of the kept region in runs of 4 (one dword), rows sparser than
     // columns (a sampled pixel touches 7 rows); samp_sx counts dwords and is odd, so that block textures with
     // power-of-two periods are not aliased
     L.samp_sx = L.samp_sy = 1;

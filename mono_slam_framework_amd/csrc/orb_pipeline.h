@@ -38,7 +38,7 @@ struct OrbLevelInfo {
   int wk_xg[kWkMaxNx + 1];   // the same numbers inside the kernel arguments (a scalar load instead of a dependent memory
                              // round trip in front of the strip's table loads); more strips than kWkMaxNx: not fused
   int tab_off;         // offset (entries) of this level's resize tables
-  int samp_sx, samp_sy, samp_rows, samp_cols;   // k_fast_tau's sample lattice over [31, w-31) x [31, h-31); rows 0 = none
+  int samp_sx, samp_sy, samp_rows, samp_cols;   // tau_unit's sample lattice over [31, w-31) x [31, h-31); rows 0 = none
   long long pix_off;   // byte offset of this level inside a slot's pyramid blob (levels >= 1)
 };
 

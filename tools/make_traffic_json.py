@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 # r04: ONE k_walk launch (threshold units + strips of all eight levels) is the stage "pyramid_fast"; "fast_nms" is the
 # check and the dense redo
-STAGE = {"k_resize": "pyramid", "k_fast": "fast_nms", "k_fast_tau": "pyramid_fast", "k_walk": "pyramid_fast",
+STAGE = {"k_resize": "pyramid", "k_fast": "fast_nms", "k_walk": "pyramid_fast",
          "k_fast_check": "fast_nms", "k_fast_redo": "fast_nms", "k_thr_harris": "select_harris", "k_select": "select_harris",
          "k_describe": "orient_describe", "k_match": "match", "k_conv": "backbone_convs", "k_tokens": "backbone_convs",
          "k_block8": "backbone_convs", "k_block16": "backbone_convs", "k_block8x": "backbone_convs",
