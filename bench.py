@@ -44,13 +44,45 @@ def host_cpu():
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count() or 1
-    return {"nproc": os.cpu_count() or 1, "usable": usable, "model": model}
+    # a cgroup CPU quota (cpu.max "<quota> <period>") bounds what any number of threads can get
+    quota = None
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            t = open(f).read().split()
+            if f.endswith("cpu.max"):
+                if t[0] != "max":
+                    quota = float(t[0]) / float(t[1])
+            elif int(t[0]) > 0:
+                quota = int(t[0]) / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if quota:
+        usable = max(1, min(usable, int(quota + 0.999)))
+    return {"nproc": os.cpu_count() or 1, "usable": usable, "cgroup_cpu_quota": quota, "model": model}
+
+
+def _orb_cpu_leg(A, B, ratio, threads, seconds, one, floor_per_thread=1):
+    """`threads` Python threads (ctypes drops the GIL), each with its own oracle object, one pair at a time per thread,
+    on a sample sized for about `seconds` of wall time from the one-pair calibration `one`.  -> (pairs, wall, results)"""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import orb as oracle_orb
+    n = int(min(len(A), max(threads * floor_per_thread, threads * (seconds / one))))
+
+    def work(t):
+        orc = oracle_orb.FeatureMatcherOracle(ratio)
+        return [(i, orc.MatchFrames(A[i], B[i])) for i in range(t, n, threads)]
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        results = [r for part in ex.map(work, range(threads)) for r in part]
+    return n, time.perf_counter() - t0, results
 
 
 def cpu_baseline(args, A, B, gpu_lists):
-    """Times the CPU oracle (kind "port") on a bounded sample of the same pairs, one pair per thread.  The sample is
-    sized for about --cpu-seconds of wall time from a short calibration run (never more than the resident batch)."""
-    from concurrent.futures import ThreadPoolExecutor
+    """Times the CPU oracle (kind "port") on bounded samples of the same pairs, one pair per thread: the --cpu-threads
+    figure of the earlier rounds (`value`), and the two SURVEY.md 8d asks for -- `single_thread` and `all_cores` (every
+    hardware thread this process may run on, affinity stated).  Each sample is sized from a one-pair calibration."""
     import numpy as np
     from oracle import orb as oracle_orb
     host = host_cpu()
@@ -59,31 +91,50 @@ def cpu_baseline(args, A, B, gpu_lists):
     t0 = time.perf_counter()
     oracle_orb.FeatureMatcherOracle(args.ratio).MatchFrames(A[0], B[0])
     one = max(time.perf_counter() - t0, 1e-4)
-    n = int(min(len(A), max(cores * args.cpu_pairs_per_thread, cores * (args.cpu_seconds / one))))
-
-    def work(t):
-        orc = oracle_orb.FeatureMatcherOracle(args.ratio)
-        res = []
-        for i in range(t, n, cores):
-            res.append((i, orc.MatchFrames(A[i], B[i])))
-        return res
-
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=cores) as ex:
-        results = [r for part in ex.map(work, range(cores)) for r in part]
-    dt = time.perf_counter() - t0
+    n, dt, results = _orb_cpu_leg(A, B, args.ratio, cores, args.cpu_seconds, one, args.cpu_pairs_per_thread)
     mismatches = 0
     for i, m in results:
         if gpu_lists is not None and not (len(m) == len(gpu_lists[i]) and np.array_equal(m, gpu_lists[i])):
             mismatches += 1
-    return {"value": round(n / dt, 3), "unit": "frame-pairs/sec", "cores": cores, "kind": "port",
-            "sample": "%d of the same %dx%d pairs, oracle/orb_oracle.c (scalar C restatement), one pair per thread, "
-                      "%d unpinned threads, %.1f s" % (n, args.width, args.height, cores, dt),
-            "host": host, "parity_mismatches_vs_gpu": mismatches}
+    out = {"value": round(n / dt, 3), "unit": "frame-pairs/sec", "cores": cores, "kind": "port",
+           "sample": "%d of the same %dx%d pairs, oracle/orb_oracle.c (scalar C restatement), one pair per thread, "
+                     "%d unpinned threads, %.1f s" % (n, args.width, args.height, cores, dt),
+           "host": host, "parity_mismatches_vs_gpu": mismatches}
+    if args.cpu_extra_seconds > 0:
+        n1, dt1, _ = _orb_cpu_leg(A, B, args.ratio, 1, args.cpu_extra_seconds, one)
+        out["single_thread"] = {"value": round(n1 / dt1, 3), "cores": 1, "sample": "%d pairs, %.1f s, unpinned" % (n1, dt1)}
+        na, dta, _ = _orb_cpu_leg(A, B, args.ratio, host["usable"], args.cpu_extra_seconds, one)
+        out["all_cores"] = {"value": round(na / dta, 3), "cores": host["usable"],
+                            "sample": "%d pairs, %.1f s, one pair per thread" % (na, dta),
+                            "affinity": "%d of %d hardware threads usable by this process (sched_getaffinity, capped by "
+                                        "the cgroup CPU quota %s), threads unpinned within that set"
+                                        % (host["usable"], host["nproc"], host["cgroup_cpu_quota"])}
+    return out
+
+
+def _loftr_cpu_pairs_parallel(A, B, threshold, threads, seconds, one):
+    """one pair per thread: every worker thread sets ITS OpenMP team to 1 (omp_set_num_threads acts on the calling
+    thread) and runs whole pairs on an oracle object of its own.  -> (pairs, wall)"""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import loftr as oracle_loftr
+    n = int(min(len(A), max(threads, threads * (seconds / one))))
+
+    def work(t):
+        oracle_loftr.set_threads(1)
+        orc = oracle_loftr.DNNFeatureMatcherOracle(threshold)
+        for i in range(t, n, threads):
+            orc.MatchFrames(A[i], B[i])
+        return 0
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(work, range(threads)))
+    return n, time.perf_counter() - t0
 
 
 def cpu_baseline_loftr(args, A, B, gpu_lists):
-    """LoFTR CPU baseline: the C restatement (OpenMP over its convolutions), pairs one after another."""
+    """LoFTR CPU baseline: the C restatement (OpenMP over its convolutions), pairs one after another (`value`), plus
+    `single_thread` (one OpenMP thread) and `all_cores` (one pair per hardware thread, no OpenMP team)."""
     import numpy as np
     from oracle import loftr as oracle_loftr
     host = host_cpu()
@@ -97,6 +148,25 @@ def cpu_baseline_loftr(args, A, B, gpu_lists):
     confs = [orc.run(A[i], B[i])["conf"] for i in range(n)]
     res = [orc.decode(c) for c in confs]
     dt = time.perf_counter() - t0
+    extra = {}
+    if args.cpu_extra_seconds > 0:
+        oracle_loftr.set_threads(1)
+        t0 = time.perf_counter()
+        orc.MatchFrames(A[0], B[0])
+        one1 = max(time.perf_counter() - t0, 1e-4)
+        n1 = int(min(len(A), max(1, args.cpu_extra_seconds / one1)))
+        t0 = time.perf_counter()
+        for i in range(n1):
+            orc.MatchFrames(A[i], B[i])
+        dt1 = time.perf_counter() - t0
+        extra["single_thread"] = {"value": round(n1 / dt1, 3), "cores": 1, "sample": "%d pairs, %.1f s, unpinned" % (n1, dt1)}
+        na, dta = _loftr_cpu_pairs_parallel(A, B, args.threshold, host["usable"], args.cpu_extra_seconds, one1)
+        extra["all_cores"] = {"value": round(na / dta, 3), "cores": host["usable"],
+                              "sample": "%d pairs, %.1f s, one pair per thread (OpenMP team of 1 each)" % (na, dta),
+                              "affinity": "%d of %d hardware threads usable by this process (sched_getaffinity, capped by "
+                                          "the cgroup CPU quota %s), threads unpinned within that set"
+                                          % (host["usable"], host["nproc"], host["cgroup_cpu_quota"])}
+        oracle_loftr.set_threads(cores)
     # Parity rule for the lists: identical wherever |conf - threshold| > 1e-3.  An entry that only one side
     # lists is therefore within tolerance iff the restatement's confidence of that (token, token) pair lies within 1e-3
     # of the threshold; anything else is a real mismatch.
@@ -115,14 +185,16 @@ def cpu_baseline_loftr(args, A, B, gpu_lists):
             entries_diff += 1
             worst = max(worst, margin)
             beyond += int(margin > tol)
-    return {"value": round(n / dt, 3), "unit": "frame-pairs/sec", "cores": cores, "kind": "port",
-            "sample": "%d of the same 640x480 pairs, oracle/loftr_oracle.c (f32 C restatement, OpenMP with %d unpinned "
-                      "threads), %.1f s" % (n, cores, dt),
-            "host": host,
-            "match_lists_vs_gpu": {"pairs": n, "pairs_with_a_difference": pairs_diff, "entries_on_one_side_only": entries_diff,
-                                   "entries_beyond_tolerance": beyond,
-                                   "largest_margin_of_such_an_entry": round(worst, 6), "tolerance": tol,
-                                   "rule": "lists identical wherever |conf - threshold| > 1e-3 (conf of the CPU restatement)"}}
+    out = {"value": round(n / dt, 3), "unit": "frame-pairs/sec", "cores": cores, "kind": "port",
+           "sample": "%d of the same 640x480 pairs, oracle/loftr_oracle.c (f32 C restatement, OpenMP with %d unpinned "
+                     "threads), %.1f s" % (n, cores, dt),
+           "host": host,
+           "match_lists_vs_gpu": {"pairs": n, "pairs_with_a_difference": pairs_diff, "entries_on_one_side_only": entries_diff,
+                                  "entries_beyond_tolerance": beyond,
+                                  "largest_margin_of_such_an_entry": round(worst, 6), "tolerance": tol,
+                                  "rule": "lists identical wherever |conf - threshold| > 1e-3 (conf of the CPU restatement)"}}
+    out.update(extra)
+    return out
 
 
 ORB_SWITCHES = ("blur_tie_even", "level_size_mul_inv", "blur_kernel_sum256")   # the oracle's / product's open choices
@@ -254,8 +326,12 @@ def run_workload(args, matcher, W, H, P, ratio_or_thr, loftr_f32, rank, world, l
         if args.gather == "product":
             # the product-side gather of libmsf.so (msf_gather_*: RCCL bound by the library); its 128-byte id travels
             # over the process group that exists anyway
-            if args.backend != "nccl":
-                raise SystemExit("--gather product needs one GPU per rank (--backend nccl): RCCL refuses two ranks on one device")
+            # RCCL refuses two ranks on one device: on a box with fewer GPUs than ranks the product gather can only be
+            # REHEARSED, against the test-only stand-in named by MSF_RCCL_LIBRARY (tests/stub_rccl: host shared memory +
+            # hipMemcpy instead of xGMI) -- such a line says so in config.gather and is no RCCL measurement
+            if args.backend != "nccl" and not os.environ.get("MSF_RCCL_LIBRARY"):
+                raise SystemExit("--gather product needs one GPU per rank (--backend nccl), or MSF_RCCL_LIBRARY naming the "
+                                 "test stand-in for a rehearsal: RCCL refuses two ranks on one device")
             idt = torch.zeros((128,), dtype=torch.uint8, device=cdev)
             if rank == 0:
                 idt.copy_(torch.frombuffer(bytearray(RcclMatchListGather.unique_id()), dtype=torch.uint8))
@@ -351,8 +427,7 @@ def run_workload(args, matcher, W, H, P, ratio_or_thr, loftr_f32, rank, world, l
                         "mfma_form": ("f32: v_mfma_f32_16x16x4_f32 everywhere, peak = the f32 matrix rate" if loftr_f32 else
                                       "split-bf16: each f32 product of the ResNet = 3 x v_mfma_f32_16x16x32_bf16 on hi/lo "
                                       "operands (f32 accumulation), peak = the dense bf16 matrix rate"),
-                        "hbm_frac": (round(traffic["bytes"] / (stages[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-                                     if traffic else None)}
+                        "hbm_frac": hbm_frac_of(traffic, stages[dom])}
             if not loftr_f32:
                 # algorithmic FLOPs x 3 = the matrix work actually issued on the split layers; the same time against the
                 # f32 matrix peak is what r01/r02 printed as `frac` (no utilisation figure: the f32 pipe is not used)
@@ -372,8 +447,7 @@ def run_workload(args, matcher, W, H, P, ratio_or_thr, loftr_f32, rank, world, l
                         "stage_ms": {k: round(v, 4) for k, v in stages.items()},
                         "pipeline_frac": round(value / world * bpp / 1e9 / HBM_PEAK_GBS, 5),
                         # the stage's measured HBM bytes (committed PMC passes) over its time: how busy the bus really is
-                        "hbm_frac": (round(traffic["bytes"] / (stages[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-                                     if traffic else None)}
+                        "hbm_frac": hbm_frac_of(traffic, stages[dom])}
         if world > 1:
             assert gathered[0] > 0, "rank 0 gathered no match records"
         res = {
@@ -389,7 +463,10 @@ def run_workload(args, matcher, W, H, P, ratio_or_thr, loftr_f32, rank, world, l
                        "shard": "pair p of a step -> rank p // pairs_per_gpu (contiguous blocks)",
                        "collective_backend": args.backend if world > 1 else None,
                        "gather": (None if world == 1 else
-                                  ("product: msf_gather_* of libmsf.so (ncclAllGather + ncclSend/ncclRecv)" if args.gather == "product"
+                                  ("product: msf_gather_* of libmsf.so (ncclAllGather + ncclSend/ncclRecv)" +
+                                   (" bound to the stand-in MSF_RCCL_LIBRARY=%s: a REHEARSAL of offsets and ordering, "
+                                    "not RCCL" % os.path.basename(os.environ["MSF_RCCL_LIBRARY"])
+                                    if os.environ.get("MSF_RCCL_LIBRARY") else "") if args.gather == "product"
                                    else "torch.distributed (all_gather_into_tensor + batch_isend_irecv)") +
                                   ", pipelined: step k's gather on its own stream beside step k+1's kernels")},
             "roofline": roofline,
@@ -406,6 +483,23 @@ def run_workload(args, matcher, W, H, P, ratio_or_thr, loftr_f32, rank, world, l
     del dA, dB, out, cnt, packed, offs, packed_b, offs_b
     torch.cuda.empty_cache()
     return res
+
+
+HBM_FRAC_PLAUSIBLE = 0.85   # measured streaming copies reach 0.79 of the 8 TB/s spec (MI355X_MICROARCH.md, HBM)
+
+
+def hbm_frac_of(traffic, stage_ms):
+    """Measured HBM bytes of the stage (committed PMC pass) over its time, as a fraction of the 8 TB/s peak.  A record
+    that would put the bus above what a pure copy reaches is a broken record, not a fast kernel (r04's were 3 x one
+    pass): it is marked `implausible` and no fraction is printed for it."""
+    if not traffic:
+        return None
+    frac = traffic["bytes"] / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if frac > HBM_FRAC_PLAUSIBLE:
+        traffic["implausible"] = True
+        traffic["implied_hbm_frac"] = round(frac, 5)
+        return None
+    return round(frac, 5)
 
 
 def synth_first_pair(rank, world, P):
@@ -494,7 +588,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--cpu-pairs-per-thread", type=int, default=2)
     ap.add_argument("--cpu-loftr-pairs", type=int, default=8)
-    ap.add_argument("--cpu-seconds", type=float, default=10.0,
+    ap.add_argument("--cpu-extra-seconds", type=float, default=5.0,
+                    help="wall time of each of the two further CPU legs (single thread, all usable hardware threads); 0 = skip")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0,
                     help="wall time each CPU-baseline leg aims for (its sample is sized from a one-pair calibration)")
     ap.add_argument("--threshold", type=float, default=0.15, help="LoFTR confidence threshold (dnnfeaturematcher.h:11)")
     ap.add_argument("--loftr-f32", action="store_true",

@@ -295,6 +295,18 @@ int msf_gather_plan(int32_t n_ranks, int32_t pairs_per_rank, const int32_t* all_
 int msf_gather_matches_device(msf_gather* g, const msf_match* d_packed, const int32_t* d_offsets, int32_t* d_all_offsets,
                               msf_match* d_recv, int32_t* totals, void* stream);
 
+/* -------- Walker stall: a caller-visible failure mode of ORB batch extraction --------
+ * Calls of >= 8 frames run pyramid + FAST of all eight levels as ONE launch whose one-wave units wait for units of lower
+ * workgroup index (orb_kernels.hip, k_walk).  That is live as long as the hardware starts workgroups of a grid in index
+ * order -- observed on gfx950, not promised by HIP -- so every wait is bounded (2^19 polls, about one second).  A unit
+ * that gives up flags its frame: the pairs of that frame come back with n_out = -1 and the call returns MSF_ERR_CAPACITY
+ * like any other per-pair failure (never a silent wrong list); every other waiter of the launch leaves at once, the grid
+ * drains.  The stall is counted in a device word that is never cleared; the next extraction that finds it non-zero
+ * switches the handle to one launch per level for the rest of its life (no in-launch waits; about 9 % slower at
+ * 1280x720), and msf_last_error carries a note once.  MSF_DBG_WALK_MODE reports both.  Two handles extracting at the same
+ * time on one device (msf_multi shards, per-size handles, a gather stream) do not stall each other: every grid's own
+ * units still start in index order (tests/test_orb_gpu.py::test_two_walker_grids_at_once). */
+
 /* -------- introspection used by the parity tests and bench.py (not by the drop-in path) -------- */
 typedef enum msf_debug_what {
   MSF_DBG_LEVEL_SIZES = 0,   /* int32 [nlevels][4] = w, h, row pitch, quota */
@@ -308,6 +320,9 @@ typedef enum msf_debug_what {
   MSF_DBG_LOFTR_FEAT = 7,    /* float [2][1200][32] coarse features after the transformer of pair `slot` */
   MSF_DBG_FAST_TAU = 8,      /* int32 [nlevels][2] of slot: FAST score threshold the candidate list was built with
                                 (20 = dense, also after a failed check), and the first estimate */
+  MSF_DBG_WALK_MODE = 10,    /* ORB, int32 [2]: {1 if the handle launches the pyramid + FAST walker level by level (after a
+                                stalled one-launch walker, or MSF_ORB_WALK_PER_LEVEL=1), else 0; units of one-launch
+                                walkers that gave up a bounded wait since msf_create} -- see "Walker stall" below */
   MSF_DBG_LOFTR_ACT = 9      /* float NCHW activation of the first frame of the last backbone pass after ResNet stage
                                 `level` + 1: [8][240][320], [16][120][160], [32][60][80], [32][30][40] (level 0..3) */
 } msf_debug_what;

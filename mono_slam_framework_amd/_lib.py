@@ -27,7 +27,7 @@ MSF_FLAG_LOFTR_F32 = 128
 MSF_FLAG_BLUR_SUM256 = 256
 
 (DBG_LEVEL_SIZES, DBG_LEVEL_PIXELS, DBG_FAST_CANDS, DBG_KEYPOINTS, DBG_DESCRIPTORS, DBG_STAGE1,
- DBG_LOFTR_CONF, DBG_LOFTR_FEAT, DBG_FAST_TAU, DBG_LOFTR_ACT) = range(10)
+ DBG_LOFTR_CONF, DBG_LOFTR_FEAT, DBG_FAST_TAU, DBG_LOFTR_ACT, DBG_WALK_MODE) = range(11)
 
 # every symbol include/msf_abi.h declares
 ABI_SYMBOLS = ["msf_abi_version", "msf_default_config", "msf_create", "msf_destroy", "msf_set_threshold",

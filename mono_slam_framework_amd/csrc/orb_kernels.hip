@@ -613,6 +613,9 @@ __device__ __forceinline__ void unit_stall(uint32_t* status, int slot, uint32_t*
   if (lane == 0) {
     atomicOr(&status[slot], kStatusOverflow);
     __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // word 1 is STICKY: counted up, never zeroed between calls.  The host reads it behind an asynchronous copy, possibly
+    // many calls later (a caller may enqueue dozens of calls without a host wait: word 0 is long zero again by then).
+    atomicAdd(abort_word + 1, 1u);
   }
 }
 
@@ -2476,7 +2479,7 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   MSF_HIP_TRY(hipMalloc(&d_walk_abort_, 16));
   MSF_HIP_TRY(hipMemset(d_walk_abort_, 0, 16));
   MSF_HIP_TRY(hipHostMalloc(&h_walk_abort_, 16, hipHostMallocDefault));
-  h_walk_abort_[0] = 0u;
+  h_walk_abort_[0] = h_walk_abort_[1] = 0u;
   MSF_HIP_TRY(hipMalloc(&d_s1_cnt_, Wk * kOrbLevels * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMalloc(&d_s1_, Wk * g.s1_total * sizeof(uint4)));
   MSF_HIP_TRY(hipMalloc(&d_kp_, S * kKpCap * sizeof(msf_keypoint)));
@@ -2532,7 +2535,7 @@ hipError_t OrbPipeline::extract(const FrameSrc& src, int n, hipStream_t st) {
   // workgroups being started in index order, which is observed, not promised.  From now on this handle launches one level
   // at a time (every wait is then met at once); the word arrives with the asynchronous copy behind each launch, so this
   // may take effect a few calls after the one that failed.
-  if (h_walk_abort_ && h_walk_abort_[0] != 0u && !walk_per_level_) {
+  if (h_walk_abort_ && !walk_per_level_ && __atomic_load_n(&h_walk_abort_[1], __ATOMIC_RELAXED) != 0u) {
     walk_per_level_ = true;
     degraded_note_ = true;
   }
@@ -2604,7 +2607,7 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
   if (!dense && g.total_tiles > 0) {
     // the walker's per-(frame, level) state starts from zero: histograms, counters, "threshold published" words
     if ((e = hipMemsetAsync(this->d_qstat_, 0, (size_t)n * kOrbLevels * kQStat * 4, st))) return e;
-    if ((e = hipMemsetAsync(d_walk_abort_, 0, 16, st))) return e;
+    if ((e = hipMemsetAsync(d_walk_abort_, 0, 4, st))) return e;      // word 0 only: word 1 is the sticky stall count
   }
   if (fused) {
     // ONE launch: the walker of level l - 1 makes level l and finds level l - 1's corners in one pass over its pixels;
@@ -2618,7 +2621,9 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
     } else {
       launch_walk(0, g.nlevels - 1, 1, mask, predict);
     }
-    hipMemcpyAsync(h_walk_abort_, d_walk_abort_, 4, hipMemcpyDeviceToHost, st);   // read at the start of a later call
+    // both words: this launch's abort word and the sticky stall count (read at the start of a later call; the count
+    // survives however many calls are enqueued before the host looks)
+    hipMemcpyAsync(h_walk_abort_, d_walk_abort_, 8, hipMemcpyDeviceToHost, st);
     if (evs) hipEventRecord(evs[1], st);
   } else {
     for (int l = 1; l < g.nlevels; l++) launch_resize(l);
@@ -2764,6 +2769,17 @@ int OrbPipeline::debug_get(int what, int slot, int level, void* host_out, size_t
   if (what == MSF_DBG_LEVEL_SIZES) {
     int32_t v[kOrbLevels][4];
     for (int l = 0; l < kOrbLevels; l++) { v[l][0] = g.lv[l].w; v[l][1] = g.lv[l].h; v[l][2] = g.lv[l].pitch; v[l][3] = g.lv[l].quota; }
+    *n_bytes = sizeof(v);
+    memcpy(host_out, v, sizeof(v) < cap ? sizeof(v) : cap);
+    return 0;
+  }
+  if (what == MSF_DBG_WALK_MODE) {
+    uint32_t stalls = 0;
+    if (d_walk_abort_ && hipMemcpy(&stalls, d_walk_abort_ + 1, 4, hipMemcpyDeviceToHost) != hipSuccess) {
+      *err = "hipMemcpy failed in debug_get";
+      return (int)MSF_ERR_HIP;
+    }
+    const int32_t v[2] = {walk_per_level_ || stalls != 0u ? 1 : 0, (int32_t)stalls};
     *n_bytes = sizeof(v);
     memcpy(host_out, v, sizeof(v) < cap ? sizeof(v) : cap);
     return 0;

@@ -230,13 +230,18 @@ class FeatureMatcher(_Matcher):
     def level_sizes(self):
         return self._debug(_lib.DBG_LEVEL_SIZES, 0, 0, np.int32, 8 * 4 * 4).reshape(8, 4)
 
-    @staticmethod
-    def walker_launches(stage):
+    def walk_mode(self):
+        """(per_level, stalls): whether this handle launches the walker level by level -- MSF_ORB_WALK_PER_LEVEL=1, or
+        after a unit of a one-launch walker gave up a bounded wait (include/msf_abi.h, "Walker stall") -- and how many
+        units have given up since the handle was made.  Asked of the handle, not of the environment."""
+        v = self._debug(_lib.DBG_WALK_MODE, 0, 0, np.int32, 8)
+        return bool(v[0]), int(v[1])
+
+    def walker_launches(self, stage):
         """Launches of the dominant kernel (the streaming walker k_walk) in one extraction of a batch: ONE -- all levels,
-        their thresholds and the pyramid in one launch (r03: 2 chains x 8 levels of sampler + walker launches); eight with
-        MSF_ORB_WALK_PER_LEVEL=1."""
-        import os
-        return 8 if (stage == "pyramid_fast" and os.environ.get("MSF_ORB_WALK_PER_LEVEL", "0") not in ("", "0")) else 1
+        their thresholds and the pyramid in one launch (r03: 2 chains x 8 levels of sampler + walker launches); eight when
+        the handle runs level by level (walk_mode)."""
+        return 8 if (stage == "pyramid_fast" and self.walk_mode()[0]) else 1
 
     # Introspection of the feature slots.  `slot` counts from the scratch slots of the last MatchFrames / match_batch
     # call (frame A of pair i = i, frame B = n_pairs + i); cache=True addresses the per-frame cache slots of

@@ -609,3 +609,68 @@ def test_a_unit_that_never_publishes_ends_in_flagged_frames_not_in_a_hang(monkey
     got = fm.match_batch(list(A), list(B), cap=1024)
     np.testing.assert_array_equal(got[5], orc.MatchFrames(A[5], B[5]))
     fm.close()
+
+
+@pytest.mark.gpu
+def test_two_walker_grids_at_once():
+    """Two k_walk grids on one device at the same time: two handles with P >= 48 (240-row strips, the bench's form), each
+    driven by its own host thread on its own stream for several calls, then one msf_multi with two shards on device 0.
+    A unit only ever waits for units of lower index in ITS grid, so a second grid takes wave slots but cannot stall the
+    first: every list is what the same handle gives alone (three per call also against the oracle), no frame is flagged
+    (n_out >= 0 everywhere), no unit gave up a wait and no handle fell back to per-level launches (walk_mode,
+    msf_last_error empty).  Reference call pattern: src/main.cpp:131-139 (the caller's thread changes every frame)."""
+    import threading
+    from mono_slam_framework_amd import _lib
+    from mono_slam_framework_amd.matcher import FeatureMatcher, MultiDeviceMatcher
+    n, w, h, calls = 64, 640, 480, 4
+    fl = _lib.MSF_FLAG_NO_FRAME_CACHE
+    data = [synth.synth_batch(12000 + 1000 * t, n, w, h, mode=t % 3) for t in range(2)]
+    fms = [FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=fl) for _ in range(2)]
+    alone = []
+    for fm, (A, B) in zip(fms, data):                 # each handle on its own first: the reference lists
+        num, lists = fm.match_batch_raw(list(A), list(B), cap=1024)
+        assert (num >= 0).all()
+        alone.append(lists)
+    orc = oracle_orb.FeatureMatcherOracle(0.7)
+    for (A, B), lists in zip(data, alone):
+        for i in (0, 31, n - 1):
+            np.testing.assert_array_equal(lists[i], orc.MatchFrames(A[i], B[i]))
+    start = threading.Barrier(2)
+    results, errors = [None, None], []
+
+    def drive(t):
+        try:
+            A, B = data[t]
+            out = []
+            start.wait()
+            for _ in range(calls):
+                out.append(fms[t].match_batch_raw(list(A), list(B), cap=1024))
+            results[t] = out
+        except Exception as e:                           # noqa: BLE001 -- reported by the main thread
+            errors.append((t, e))
+
+    th = [threading.Thread(target=drive, args=(t,)) for t in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors
+    for t in range(2):
+        for num, lists in results[t]:
+            assert (num >= 0).all(), "handle %d: flagged frames %s" % (t, np.nonzero(num < 0)[0])
+            for i in range(n):
+                np.testing.assert_array_equal(lists[i], alone[t][i], err_msg="handle %d pair %d" % (t, i))
+        assert fms[t].walk_mode() == (False, 0)
+        assert fms[t].last_error() == ""
+    for fm in fms:
+        fm.close()
+    # one msf_multi, two shards on device 0: 2 x 64 pairs, each shard's k_walk grid beside the other's
+    multi = MultiDeviceMatcher("orb", 0.7, w, h, devices=(0, 0), max_batch_pairs=n, flags=fl)
+    A = list(data[0][0]) + list(data[1][0])
+    B = list(data[0][1]) + list(data[1][1])
+    for _ in range(2):
+        got = multi.match_batch(A, B, cap=1024)
+        for i in range(n):
+            np.testing.assert_array_equal(got[i], alone[0][i], err_msg="shard 0 pair %d" % i)
+            np.testing.assert_array_equal(got[n + i], alone[1][i], err_msg="shard 1 pair %d" % i)
+    multi.close()

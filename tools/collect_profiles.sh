@@ -5,7 +5,7 @@
 # Outputs land under gpurun_out/prof_<tag>/ ; tools/pmc_summary.py + tools/make_traffic_json.py digest them.
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT
 mkdir -p $OUT

@@ -29,10 +29,25 @@ STAGE = {"k_resize": "pyramid", "k_fast": "fast_nms", "k_walk": "pyramid_fast",
          "k_sim_stats": "match_head", "k_sim_stats3": "match_head", "k_conf_mask": "match_head", "k_decode": "match_head"}
 
 
+def one_collection(d):
+    """The counter CSV of ONE profiled process.  gpurun merges what a call wrote into the local gpurun_out/, it never
+    deletes: a pass directory that was collected more than once holds one <pid>_counter_collection.csv per collection,
+    and summing them multiplies every figure (the r04 records were 3x one pass).  More than one file is an error here;
+    tools/collect_profiles.sh's caller clears the local directory first (tools/pull_clean.sh)."""
+    files = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True))
+    if not files:
+        raise SystemExit("no counter_collection.csv under %s" % d)
+    if len(files) > 1:
+        raise SystemExit("%d counter collections under %s (%s): stale pulls of earlier runs -- remove the local "
+                         "directory, collect once, run again" % (len(files), d, ", ".join(os.path.basename(f) for f in files)))
+    return files[0]
+
+
 def load(d, steps):
-    """sum of a counter over all dispatches of a kernel, divided by the number of bench steps (incl. warmup)"""
+    """sum of a counter over all dispatches of a kernel in ONE collection, divided by the number of bench steps (incl.
+    warmup)"""
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
-    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    for f in [one_collection(d)]:
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0].split("<")[0].replace("msf::", "").replace("void ", "")
             if k.startswith("_ZN3msf"):          # a name rocprofv3 left mangled: _ZN3msf<len><identifier>...
@@ -72,7 +87,7 @@ def mfma_busy(write):
     return out
 
 
-def main(tag="r04", steps=6):
+def main(tag="r05", steps=6):
     base = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     steps = int(steps)
     for which in ("orb", "orb_vga", "loftr", "loftr_f32"):
