@@ -49,13 +49,13 @@ def build_lib(force=False, verbose=False):
     return LIB
 
 
-def build_variant(name, defines=()):
+def build_variant(name, defines=(), flags=()):
     """Developer A/B builds: the same sources with extra -D flags into libmsf_<name>.so next to libmsf.so (the library
     finds the LoFTR weights relative to itself; git-ignored, travels with the gpurun snapshot); selected at run time
     with MSF_LIB_PATH."""
     out = os.path.join(_HERE, "libmsf_%s.so" % name)
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [HIPCC] + HIP_FLAGS + ["-D" + d for d in defines] + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", out] + srcs + ["-ldl"]
+    cmd = [HIPCC] + HIP_FLAGS + list(flags) + ["-D" + d for d in defines] + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", out] + srcs + ["-ldl"]
     subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
     return out
 

@@ -539,12 +539,49 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {   // (bf16(a
   return r;
 }
 typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+
+// ---- "split pixels": the HBM format of the activations that travel between the streaming kernels (r05)
+// An image of C = 8 CB channels, H x W, is  [y][plane: hi | lo][channel block cb][x]  pixels of 16 bytes (8 x bf16):
+// exactly the operand format of the LDS rings, split ONCE by the producer on its accumulators (the split the consumer's
+// loader used to redo on f32 NCHW: 24 VALU instructions and four 8-byte LDS writes per pixel block and step).  A loader
+// thread fetches its pixel block as two 16-byte loads and commits two 16-byte LDS writes; a producer lane stores its
+// four channels as two 8-byte halves, 16 lanes = 256 contiguous bytes per (row, plane, channel block).  Same bytes per
+// value (4) and the same image stride (4 C H W) as f32 NCHW, so the ping-pong buffers are unchanged.  Values: hi =
+// bf16(v), lo = bf16(v - hi) -- what split4 gives; every consumer then computes exactly what it computed from f32 input.
+// sx_off: byte offset of pixel x of (row y, plane, channel block cb) in an image of CB channel blocks and width W.
+__device__ __forceinline__ uint32_t sx_off(int y, int plane, int cb, int x, int W, int CB) {
+  return 16u * (uint32_t)(((y * 2 + plane) * CB + cb) * W + x);
+}
+__device__ __forceinline__ u32x4v sx_ld(const void* base, uint32_t off) {      // SGPR base + 32-bit lane offset
+#ifdef MSF_ABL_NOLOADS   // timing-only build (results invalid): no global loads in the streaming kernels' loaders
+  u32x4v r = u32x4v{off, off, off, off};
+  asm volatile("" : "+v"(r));
+  return r;
+#else
+  return *reinterpret_cast<const u32x4v*>(reinterpret_cast<const char*>(base) + off);
+#endif
+}
+// a producer lane's four channels 4 half .. 4 half + 3 of pixel (y, x), channel block cb: hi and lo halves
+__device__ __forceinline__ void sx_st4(void* base, int y, int cb, int x, int half, int W, int CB, f32x4 v);
 __device__ __forceinline__ void split4(f32x4 v, bf16x4& vh, bf16x4& vl) {   // 12 instructions for four values
   const uint32_t h0 = cvt_pk_bf16(v.x, v.y), h1 = cvt_pk_bf16(v.z, v.w);
   const float rx = v.x - __uint_as_float(h0 << 16), ry = v.y - __uint_as_float(h0 & 0xffff0000u);
   const float rz = v.z - __uint_as_float(h1 << 16), rw = v.w - __uint_as_float(h1 & 0xffff0000u);
   vh = __builtin_bit_cast(bf16x4, u32x2v{h0, h1});
   vl = __builtin_bit_cast(bf16x4, u32x2v{cvt_pk_bf16(rx, ry), cvt_pk_bf16(rz, rw)});
+}
+__device__ __forceinline__ void sx_st4(void* base, int y, int cb, int x, int half, int W, int CB, f32x4 v) {
+  bf16x4 vh, vl;
+  split4(v, vh, vl);
+  char* ob = reinterpret_cast<char*>(base);
+  const uint32_t oo = sx_off(y, 0, cb, x, W, CB) + 8u * (uint32_t)half;
+#ifdef MSF_ABL_NOSTORES  // timing-only build (results invalid): the values are formed but not stored
+  asm volatile("" :: "v"(vh), "v"(vl), "v"(ob + oo));
+#else
+  *reinterpret_cast<bf16x4*>(ob + oo) = vh;
+  *reinterpret_cast<bf16x4*>(ob + (oo + 16u * (uint32_t)(CB * W))) = vl;
+#endif
 }
 
 __global__ __launch_bounds__(256, 2) void k_block8x(const float* __restrict__ in, const uint16_t* __restrict__ wx1,
@@ -741,7 +778,13 @@ constexpr int S = 64;                              // output columns per strip
 // multiple of 256 B apart, so that the 16 slots a ds_read_b128 lane group takes from two ring rows meet no bank twice)
 // changed nothing: 642 vs 617 us -- the conflicts are not in the fragment reads, and they are not what bounds the step.
 constexpr int XP = 72;
-constexpr int RROWS = 12;                          // six row pairs per ring (five are live in a step)
+// MSF_LOFTR_DEFER = 1: a stage runs a pair's epilogue one step after its sums (see k_strip8x); rings then hold seven pairs
+// (pair p of x is still read -- as the residual -- at step p + 6, while pair p + 6 arrives) instead of six
+#ifndef MSF_LOFTR_DEFER
+#define MSF_LOFTR_DEFER 0
+#endif
+constexpr bool kDefer = MSF_LOFTR_DEFER != 0;
+constexpr int RROWS = kDefer ? 14 : 12;
 constexpr int RING = RROWS * XP;                   // pixel slots per plane
 constexpr int TAIL = 16;                           // the fifth M tile of a stage reads up to 10 slots past a ring row
 constexpr int WAVES = 8;
@@ -756,9 +799,8 @@ constexpr int WAVES = 8;
 // the memory system gives, and the step time is the prefetch distance (4 steps) into the loaded-memory latency.
 template <int NB>
 constexpr int lds_bytes() { return 16 * (2 * NB * 2 * RING + TAIL); }
-__device__ __forceinline__ int ring_row(int r) {   // r mod 12 for r >= -24 (multiply-shift exact below 1200)
-  const int x = r + 24;
-  return x - 12 * ((x * 2731) >> 15);
+__device__ __forceinline__ int ring_row(int r) {   // r mod RROWS for r >= -4 RROWS (used when the cursors are set up; they are carried afterwards)
+  return (r + 4 * RROWS) % RROWS;
 }
 }  // namespace strip8
 
@@ -791,9 +833,8 @@ __global__ __launch_bounds__(64 * WV) void k_strip8x(const float* __restrict__ i
   float* outf = out + (long long)img * 8 * HW;
   const int npairs = H / 2;
   // this wave's stage (1-based) and its share of the stage's M tiles
-  const int cst = __builtin_amdgcn_readfirstlane(wave / WPS) + 1, ws = __builtin_amdgcn_readfirstlane(wave % WPS);
-  const bool last = cst == NS, has_res = (cst & 1) == 0;
-  const int MT = (S + 2 * (NS - cst) + 15) / 16;   // M tiles: S (+ 2 (NS - c) halo) columns
+  // (the stage's LAST wave takes M tile 0 and the extra fifth tile: the first ones carry the loader)
+  const int cst = __builtin_amdgcn_readfirstlane(wave / WPS) + 1, ws = WPS - 1 - __builtin_amdgcn_readfirstlane(wave % WPS);
 
   bf16x8 wh[3], wl[3];
   {
@@ -811,17 +852,22 @@ __global__ __launch_bounds__(64 * WV) void k_strip8x(const float* __restrict__ i
     for (int j = 0; j < 8; j++) z[j] = (__bf16)0.f;
     for (int idx = tid; idx < NS * 2 * RING + TAIL; idx += 64 * WAVES) ring[idx] = z;
   }
-  // x loader (the last 2 XW threads of the workgroup: the waves with the fewest M tiles): thread (row lr of the pair,
-  // ring column lc) fetches one pixel = 8 channel dwords per step
+  // x loader (the FIRST 2 XW threads of the workgroup): thread (row lr of the pair, ring column lc) fetches one pixel
+  // (16 bytes hi + 16 bytes lo) per step.  r05: the loaders sit in stage-1 waves, which never store to global memory.
+  // s_waitcnt vmcnt counts loads and stores together, in order, and the compiler counts only the operations every path
+  // issues: in a wave that also ran the last stage, the wait for a load requested three steps earlier became "all but
+  // the four youngest operations" -- the stores of the step just finished included, i.e. a wait for a store
+  // acknowledgement (microseconds under load) in every step.
   constexpr int XW = S + 2 * NS;
-  const int ltid = tid - (64 * WAVES - 2 * XW);
+  const int ltid = tid < 2 * XW ? tid : -1;
   const bool ld = ltid >= 0;
   const int lr = ld ? ltid / XW : 0, lc = ld ? ltid - lr * XW : 0;
   const int lgx = X0 - NS + lc;
   const bool colok = ld && lgx >= 0 && lgx < W;
   const uint32_t lofs = colok ? (uint32_t)lgx : 0u;
-  const bool ldwave = wave >= (64 * WAVES - 2 * XW) / 64;        // wave-uniform: waves with loader threads
-  // The loads of a step are consumed four steps later.  The compiler's s_waitcnt insertion only keeps that distance if
+  const bool ldwave = wave <= (2 * XW - 1) / 64;                 // wave-uniform: waves with loader threads
+  static_assert((2 * XW - 1) / 64 < WPS, "the loader must fit into the stage-1 waves");
+  // The loads of a step are consumed kQDepth steps later.  The compiler's s_waitcnt insertion only keeps that distance if
   // every path between issue and use issues the same loads: no guard around an issue (addresses are clamped to valid
   // ones instead, the value is discarded at commit time), and loader and non-loader waves run separate copies of the
   // step loop (with a per-wave `if` around the issue it waited for vmcnt(0) at every step).
@@ -829,69 +875,66 @@ __global__ __launch_bounds__(64 * WV) void k_strip8x(const float* __restrict__ i
   {                                                                                               \
     const int gy = 2 * (n_) + lr;                                                                 \
     const bool ok = colok && gy < H;                                                              \
-    const uint32_t so = ok ? 4u * (lofs + (uint32_t)(gy * W)) : 0u;   /* byte offset from the SGPR base */ \
-    _Pragma("unroll") for (int c = 0; c < 8; c++)                                                 \
-      q_[c] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(inf) + (so + 4u * (uint32_t)(c * HW))); \
+    const uint32_t so = ok ? sx_off(gy, 0, 0, (int)lofs, W, 1) : 0u;   /* byte offset from the SGPR base */ \
+    q_[0] = sx_ld(inf, so);                                                                       \
+    q_[1] = sx_ld(inf, so + 16u * (uint32_t)W);                                                   \
   }
 #define MSF_ST_COMMIT(q_, n_)                                                                     \
   if (ld) {                                                                                       \
     const bool ok = colok && 2 * (n_) + lr < H;   /* outside the image: the (valid-address) load is discarded */ \
-    bf16x4 h0, l0, h1, l1;                                                                        \
-    split4(ok ? f32x4{q_[0], q_[1], q_[2], q_[3]} : f32x4{0.f, 0.f, 0.f, 0.f}, h0, l0);           \
-    split4(ok ? f32x4{q_[4], q_[5], q_[6], q_[7]} : f32x4{0.f, 0.f, 0.f, 0.f}, h1, l1);           \
-    bf16x4* dst = reinterpret_cast<bf16x4*>(ring + (crow + lc));                                  \
-    dst[0] = h0; dst[1] = h1; dst[2 * RING] = l0; dst[2 * RING + 1] = l1;                         \
+    const u32x4v z4 = u32x4v{0u, 0u, 0u, 0u};                                                     \
+    u32x4v* dst = reinterpret_cast<u32x4v*>(ring + (crow + lc));                                  \
+    dst[0] = ok ? q_[0] : z4; dst[RING] = ok ? q_[1] : z4;                                        \
   }
-  // this wave's stage makes pair p of ring cst (or of the output) from pairs p-1 .. p+1 of ring cst-1
-  const bf16x8* inh = ring + (cst - 1) * 2 * RING;
-  const bf16x4* resh = reinterpret_cast<const bf16x4*>(ring + (has_res ? cst - 2 : 0) * 2 * RING);
-  bf16x4* outh = reinterpret_cast<bf16x4*>(ring + (last ? 0 : cst) * 2 * RING);
   // Ring rows advance by two per step: the row cursors (row * XP, modulo the ring) are carried from step to step
   // instead of being re-derived (a multiply-shift modulo per cursor and step showed in the VALU-bound profile).
   constexpr int RWRAP = RROWS * XP;
-  int crow = ring_row(lr) * XP;                    // loader: row 2n + lr
-  int rin = ring_row(-4 * cst - 1 + kq) * XP;      // stage: fragment row 2p - 1 + kq, p = n - 2 cst
-  int ror = ring_row(-4 * cst + (kq >> 1)) * XP;   // stage: output row 2p + (kq >> 1)
   const bool edge = X0 == 0 || X0 + S == W;        // wave-uniform: only the outer strips have columns outside the image
-  auto stage = [&](int p) {
-    if (p >= npairs) {                             // the pair below the image: the next stage's zero padding, nothing to compute
-      if (!last) {
-        bf16x4 z;
-        z[0] = z[1] = z[2] = z[3] = (__bf16)0.f;
-#pragma unroll
-        for (int jb = 0; jb < MAXJOBS; jb++) {
-          const int j = 16 * (ws + WPS * jb) + i;
-          if (ws + WPS * jb < MT && j < XP) {
-            bf16x4* op = outh + (2 * (ror + j) + (kq & 1));
-            op[0] = z; op[2 * RING] = z;
-          }
-        }
-      }
-      return;
-    }
-    f32x4 acc[MAXJOBS];
-#pragma unroll
-    for (int jb = 0; jb < MAXJOBS; jb++) {
-      acc[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int q = ws + WPS * jb;
-      if (q < MT) {
-        const bf16x8* src = inh + (rin + 16 * q + i);
-#pragma unroll
-        for (int g = 0; g < 3; g++) {
-          const bf16x8 ph = src[g], pl = src[RING + g];
-          acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[g], ph, acc[jb], 0, 0, 0);
-          acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g], pl, acc[jb], 0, 0, 0);
-          acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g], ph, acc[jb], 0, 0, 0);
-        }
-      }
-    }
-#pragma unroll
-    for (int jb = 0; jb < MAXJOBS; jb++) {
-      const int q = ws + WPS * jb;
-      if (q >= MT) continue;
+  constexpr int kQDepth = MSF_LOFTR_STRIP8_DEPTH;  // load queue: steps ahead, each step's registers named statically, loop unrolled by it
+  static_assert(kQDepth >= 2 && kQDepth <= 4, "load queue depth");
+  // stage c lags LAG(c) steps behind the loader (which writes pair n at step n): it makes pair n - LAG at step n.
+  //   plain (kDefer = 0): LAG = 2c, the whole pair in its step.
+  //   deferred: LAG = 3c - 1 for the sums (fragment reads + MFMAs); the EPILOGUE of a pair (bias, residual, ReLU, split,
+  //   ring write or store) runs one step later, between the next pair's fragment reads and its MFMAs, so that it executes
+  //   while those reads are in flight and nothing waits for an MFMA in the step that issued it; sums cross the barrier in
+  //   registers.  Results are identical either way.
+  const int nsteps = ((npairs + (kDefer ? 3 : 2) * NS + kQDepth - 1) / kQDepth) * kQDepth;
+  // r05: ONE COPY OF THE STEP LOOP PER (loader?, stage), everything a stage decides -- last stage / residual / number of M
+  // tiles / ring addresses -- a compile-time constant, and the steps in which every pair index is inside the image (all
+  // but the first and last few) without a single range check.  r04's loop was one body for all stages: its uniform
+  // `if`s were 12 scalar branches per wave and step in k_strip8x and 24 in k_stem_strip8x (SQ_INSTS_BRANCH), each a
+  // fetch bubble for its wave, on waves that issue ~70 vector instructions per step.
+  auto run = [&](auto is_loader, auto stage_c) {
+    constexpr bool kLd = decltype(is_loader)::value;
+    constexpr int CST = decltype(stage_c)::value;
+    constexpr bool last = CST == NS, has_res = (CST & 1) == 0;
+    constexpr int MT = (S + 2 * (NS - CST) + 15) / 16;   // M tiles: S (+ 2 (NS - c) halo) columns
+    static_assert(MT >= WPS && MT <= 2 * WPS, "one or two M tiles per wave");
+    constexpr int LAG = kDefer ? 3 * CST - 1 : 2 * CST;
+    const bool two = ws + WPS < MT;                      // wave-uniform: this wave also makes the stage's extra tile
+    const bf16x8* inh = ring + (CST - 1) * 2 * RING;
+    const bf16x4* resh = reinterpret_cast<const bf16x4*>(ring + (has_res ? CST - 2 : 0) * 2 * RING);
+    bf16x4* outh = reinterpret_cast<bf16x4*>(ring + (last ? 0 : CST) * 2 * RING);
+    int crow = ring_row(lr) * XP;                        // loader: row 2n + lr
+    int rin = ring_row(-2 * LAG - 1 + kq) * XP;          // sums: fragment row 2p - 1 + kq, p = n - LAG
+    // epilogue: row 2pe + (kq >> 1) of the output / residual ring, pe = p (plain) or p - 1 (deferred)
+    int ror = ring_row(-2 * LAG - (kDefer ? 2 : 0) + (kq >> 1)) * XP;
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;   // deferred: the sums made in the previous step
+    // epilogue of M tile q of pair pe (sums v) -- or, for pe == npairs (CHK only), the zero rows below the image
+    auto epilogue = [&](auto chk, int pe, int q, f32x4 v) {
+      constexpr bool CHK = decltype(chk)::value;
       const int j = 16 * q + i;                    // this lane's pixel slot in the stage's output geometry
-      f32x4 v = acc[jb] + bias;
-      if (has_res) {                               // second convolution of a block: + block input (ring cst-2, slot j + 2)
+      if (CHK && pe >= npairs) {                   // the pair below the image: the next stage's zero padding
+        if (!last && j < XP) {
+          bf16x4 z;
+          z[0] = z[1] = z[2] = z[3] = (__bf16)0.f;
+          bf16x4* op = outh + (2 * (ror + j) + (kq & 1));
+          op[0] = z; op[2 * RING] = z;
+        }
+        return;
+      }
+      v += bias;
+      if (has_res) {                               // second convolution of a block: + block input (ring CST-2, slot j + 2)
         const bf16x4* rp = resh + (2 * (ror + j + 2) + (kq & 1));
         const bf16x4 a = rp[0], b = rp[2 * RING];
         v.x += (float)a[0] + (float)b[0]; v.y += (float)a[1] + (float)b[1];
@@ -899,18 +942,11 @@ __global__ __launch_bounds__(64 * WV) void k_strip8x(const float* __restrict__ i
       }
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       if (last) {
-        if (j < S) {                               // (the last tile of a 62-column strip holds two columns of the next strip)
-          const int orow = 2 * p + (kq >> 1);
-          const uint32_t oo = 4u * (uint32_t)((4 * (kq & 1) * H + orow) * W + X0 + j);   // byte offset from the SGPR base
-          char* ob = reinterpret_cast<char*>(outf);
-          *reinterpret_cast<float*>(ob + oo) = v.x;
-          *reinterpret_cast<float*>(ob + (oo + 4u * (uint32_t)HW)) = v.y;
-          *reinterpret_cast<float*>(ob + (oo + 8u * (uint32_t)HW)) = v.z;
-          *reinterpret_cast<float*>(ob + (oo + 12u * (uint32_t)HW)) = v.w;
-        }
+        if (j < S)                                 // (the last tile of a 62-column strip holds two columns of the next strip)
+          sx_st4(outf, 2 * pe + (kq >> 1), 0, X0 + j, kq & 1, W, 1, v);
       } else {
         if (edge) {
-          const int gx = X0 - (NS - cst) + j;      // image column of slot j of ring cst
+          const int gx = X0 - (NS - CST) + j;      // image column of slot j of ring CST
           if (gx < 0 || gx >= W) v = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (j < XP) {
@@ -920,48 +956,82 @@ __global__ __launch_bounds__(64 * WV) void k_strip8x(const float* __restrict__ i
           op[0] = vh; op[2 * RING] = vl;
         }
       }
-    }
-  };
-  // one step: barrier (everything written in the previous step is visible; nothing read in it is overwritten before),
-  // pair n of x into its ring, the queue slot refilled with pair n+4, this wave's stage on pair n - 2 cst.  Steps past
-  // the last one (the count is rounded up to the unrolled four) find no pair to make and commit zero rows.
-#define MSF_ST_STEP(q_, n_)                                                                       \
+    };
+    // M tile q of this wave at a step whose sums pair is p: fragment reads of pair p, [deferred: epilogue of pair p - 1],
+    // MFMAs of pair p, [plain: epilogue of pair p]
+    auto tile = [&](auto chk, int q, int p, f32x4& accp) {
+      constexpr bool CHK = decltype(chk)::value;
+      const bool sums = !CHK || (p >= 0 && p < npairs);     // wave-uniform
+      bf16x8 fh[3], fl[3];
+      if (sums) {
+        const bf16x8* src = inh + (rin + 16 * q + i);
+#pragma unroll
+        for (int g = 0; g < 3; g++) { fh[g] = src[g]; fl[g] = src[RING + g]; }
+      }
+      if (kDefer && (!CHK || (p >= 1 && p <= npairs + 1))) epilogue(chk, p - 1, q, accp);
+      if (sums) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[g], fh[g], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g], fl[g], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g], fh[g], acc, 0, 0, 0);
+        }
+        accp = acc;
+      }
+      if (!kDefer && (!CHK || (p >= 0 && p <= npairs))) epilogue(chk, p, q, accp);
+    };
+    // one step: barrier (everything written in the previous step is visible; nothing read in it is overwritten before),
+    // pair n of x into its ring, the queue slot refilled with pair n + depth, this wave's stage
+#define MSF_ST_STEP(chk_, q_, n_)                                                                 \
   {                                                                                               \
     __syncthreads();                                                                              \
     if (kLd) {                                                                                    \
       MSF_ST_COMMIT(q_, n_)                                                                       \
-      MSF_ST_ISSUE(q_, (n_) + MSF_LOFTR_STRIP8_DEPTH)                                                                  \
+      MSF_ST_ISSUE(q_, (n_) + kQDepth)                                                            \
     }                                                                                             \
-    const int p_ = (n_) - 2 * cst;                                                                \
-    if (p_ >= 0 && p_ <= npairs) stage(p_);                                                       \
+    tile(chk_, ws, (n_) - LAG, acc0);                                                             \
+    if (two) tile(chk_, ws + WPS, (n_) - LAG, acc1);                                              \
     crow += 2 * XP; crow = crow >= RWRAP ? crow - RWRAP : crow;                                   \
     rin += 2 * XP; rin = rin >= RWRAP ? rin - RWRAP : rin;                                        \
     ror += 2 * XP; ror = ror >= RWRAP ? ror - RWRAP : ror;                                        \
   }
-  // the load queue is MSF_LOFTR_STRIP8_DEPTH steps deep (2, 3 or 4), each step's registers named statically; the loop is unrolled by the depth
-  constexpr int kQDepth = MSF_LOFTR_STRIP8_DEPTH;
-  static_assert(kQDepth >= 2 && kQDepth <= 4, "load queue depth");
-  const int nsteps = ((npairs + 2 * NS + kQDepth - 1) / kQDepth) * kQDepth;   // the last stage's last pair is made at step npairs - 1 + 2 NS
-  auto run = [&](auto is_loader) {
-    constexpr bool kLd = decltype(is_loader)::value;
-    float q0[8]; float q1[8];
-    float q2[8];
+    u32x4v q0[2]; u32x4v q1[2];
+    u32x4v q2[2];
     if (kLd) {
       MSF_ST_ISSUE(q0, 0)
       MSF_ST_ISSUE(q1, 1)
       MSF_ST_ISSUE(q2, 2)
     }
+    // steps n with 1 <= n - LAG and n - LAG <= npairs - 1 need no range check on the stage's pairs
+    const int n_lo = ((LAG + 1 + kQDepth - 1) / kQDepth) * kQDepth, n_hi = ((npairs + LAG) / kQDepth) * kQDepth;
     for (int n = 0; n < nsteps; n += kQDepth) {
-      MSF_ST_STEP(q0, n)
-      MSF_ST_STEP(q1, n + 1)
-      MSF_ST_STEP(q2, n + 2)
+      if (n >= n_lo && n < n_hi) {
+        MSF_ST_STEP(std::false_type{}, q0, n)
+        MSF_ST_STEP(std::false_type{}, q1, n + 1)
+        MSF_ST_STEP(std::false_type{}, q2, n + 2)
+      } else {
+        MSF_ST_STEP(std::true_type{}, q0, n)
+        MSF_ST_STEP(std::true_type{}, q1, n + 1)
+        MSF_ST_STEP(std::true_type{}, q2, n + 2)
+      }
     }
+#undef MSF_ST_STEP
   };
-  if (ldwave) run(std::true_type{});
-  else run(std::false_type{});
+  static_assert(kQDepth == 3, "the step macro is written out for a three-step queue");
+  // dispatch: the loader lives in stage-1 waves only
+  if (cst == 1) {
+    if (ldwave) run(std::true_type{}, std::integral_constant<int, 1>{});
+    else run(std::false_type{}, std::integral_constant<int, 1>{});
+  } else if (NS == 2 || cst == 2) {
+    run(std::false_type{}, std::integral_constant<int, 2>{});
+  } else if (cst == 3) {
+    run(std::false_type{}, std::integral_constant<int, NS >= 3 ? 3 : 1>{});
+  } else {
+    run(std::false_type{}, std::integral_constant<int, NS >= 4 ? 4 : 1>{});
+  }
 #undef MSF_ST_ISSUE
 #undef MSF_ST_COMMIT
-#undef MSF_ST_STEP
 }
 
 // ------------------------------------------------------------------ stem + first BasicBlock as one streaming pass
@@ -1007,9 +1077,6 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8
   // this wave's stage: 0 = stem (waves 0-2), 1 / 2 = the block's convolutions (waves 3-5 / 6-7)
   const int sid = __builtin_amdgcn_readfirstlane(wave < 3 ? 0 : wave < 6 ? 1 : 2);
   const int ws = __builtin_amdgcn_readfirstlane(wave < 3 ? wave : wave < 6 ? wave - 3 : wave - 6);
-  const int wps = sid == 2 ? 2 : 3;
-  const bool last = sid == NS, has_res = sid == 2;
-  const int MT = last ? 4 : 5;
 
   bf16x8 wh[3], wl[3];
   {
@@ -1027,13 +1094,14 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8
   }
   // image loader (the last NLOAD threads): thread (row r4 of the step's four, aligned dword d) fetches 4 pixels.  The
   // tile's pixel 0 is image column CB = 2 (X0 - NS) - 3 == 1 (mod 4): the dword at CB - 1 + 4d holds tile pixels 4d-1 .. 4d+2.
-  const int ltid = tid - (64 * WAVES - NLOAD);
+  // (r05: the FIRST NLOAD threads, i.e. the stem waves, which never store to global memory -- see k_strip8x)
+  const int ltid = tid < NLOAD ? tid : -1;
   const bool ld = ltid >= 0;
   const int r4 = ld ? ltid / IDW : 0, dd = ld ? ltid - r4 * IDW : 0;
   const int cx = 2 * (X0 - NS) - 4 + 4 * dd;                      // image column of the dword (a multiple of 4)
   const bool colok = ld && cx >= 0 && cx < Win;
   const uint32_t lofs = colok ? (uint32_t)cx : 0u;
-  const bool ldwave = wave >= (64 * WAVES - NLOAD) / 64;
+  const bool ldwave = wave <= (NLOAD - 1) / 64;
 #define MSF_SS_ISSUE(q_, n_)                                                                      \
   {                                                                                               \
     const int gy = 4 * (n_) + r4;                                                                 \
@@ -1050,65 +1118,41 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8
     if (dd > 0) dst[-1] = p0;                                                                     \
     dst[0] = p1; dst[1] = p2; dst[2] = p3;                                                        \
   }
-  const bf16x8* inh = ring + (sid > 0 ? sid - 1 : 0) * 2 * RING;
-  const bf16x4* resh = reinterpret_cast<const bf16x4*>(ring);
-  bf16x4* outh = reinterpret_cast<bf16x4*>(ring + (last ? 0 : sid) * 2 * RING);
   constexpr int RWRAP = RROWS * XP;
-  // row cursors of this wave's stage; its pair at step n is p = n - 2 - 2 sid
-  int rin = ring_row(-4 - 4 * sid - 1 + kq) * XP;
-  int ror = ring_row(-4 - 4 * sid + (kq >> 1)) * XP;
   const bool edge = X0 == 0 || X0 + S == W;
-  auto stage = [&](int p) {
-    if (p >= npairs) {                             // the pair below the image: the next stage's zero padding, nothing to compute
-      if (!last) {
-        bf16x4 z;
-        z[0] = z[1] = z[2] = z[3] = (__bf16)0.f;
-#pragma unroll
-        for (int jb = 0; jb < 2; jb++) {
-          const int j = 16 * (ws + wps * jb) + i;
-          if (ws + wps * jb < MT && j < XP) {
-            bf16x4* op = outh + (2 * (ror + j) + (kq & 1));
-            op[0] = z; op[2 * RING] = z;
-          }
-        }
-      }
-      return;
-    }
-    f32x4 acc[2];
-#pragma unroll
-    for (int jb = 0; jb < 2; jb++) {
-      acc[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int q = ws + wps * jb;
-      if (q < MT) {
-        if (sid == 0) {
-          // stem: image rows 4p - 3 + 4g + kq, pixels 2j .. 2j + 7 of the tile
-#pragma unroll
-          for (int g = 0; g < 3; g++) {
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(iring + (((4 * p - 3 + 4 * g + kq) & (IROWS - 1)) * IP + 2 * (16 * q + i)));
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 raw = u32x4{src[0], src[1], src[2], src[3]};
-            const bf16x8 px = __builtin_bit_cast(bf16x8, raw);
-            acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[g], px, acc[jb], 0, 0, 0);
-            acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g], px, acc[jb], 0, 0, 0);
-          }
-        } else {
-          const bf16x8* src = inh + (rin + 16 * q + i);
-#pragma unroll
-          for (int g = 0; g < 3; g++) {
-            const bf16x8 ph = src[g], pl = src[RING + g];
-            acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[g], ph, acc[jb], 0, 0, 0);
-            acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g], pl, acc[jb], 0, 0, 0);
-            acc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g], ph, acc[jb], 0, 0, 0);
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int jb = 0; jb < 2; jb++) {
-      const int q = ws + wps * jb;
-      if (q >= MT) continue;
+  constexpr int kQDepth = MSF_LOFTR_STEM_DEPTH;    // load queue: steps ahead, statically named registers, loop unrolled by it
+  static_assert(kQDepth == 4, "the step macro is written out for a four-step queue");
+  // Lags behind the image loader (rows 4n .. 4n + 3 arrive at step n; the stem's sums of pair p need rows up to 4p + 5,
+  // arrived at step p + 1): plain: stage s makes pair n - 2 - 2s in its step; deferred (k_strip8x): sums of pair
+  // n - 2 - 3s, that pair's epilogue one step later.
+  const int nsteps = ((npairs + (kDefer ? 3 * NS + 4 : 2 * NS + 2) + kQDepth - 1) / kQDepth) * kQDepth;
+  // one copy of the step loop per stage (the loader lives in the stem waves), see k_strip8x
+  auto run = [&](auto is_loader, auto stage_c) {
+    constexpr bool kLd = decltype(is_loader)::value;
+    constexpr int SID = decltype(stage_c)::value;
+    constexpr bool last = SID == NS, has_res = SID == 2;
+    constexpr int MT = last ? 4 : 5, wps = SID == 2 ? 2 : 3;
+    constexpr int LAG = kDefer ? 2 + 3 * SID : 2 + 2 * SID;
+    const bool two = ws + wps < MT;                      // wave-uniform
+    const bf16x8* inh = ring + (SID > 0 ? SID - 1 : 0) * 2 * RING;
+    const bf16x4* resh = reinterpret_cast<const bf16x4*>(ring);
+    bf16x4* outh = reinterpret_cast<bf16x4*>(ring + (last ? 0 : SID) * 2 * RING);
+    int rin = ring_row(-2 * LAG - 1 + kq) * XP;          // sums: fragment row 2p - 1 + kq of ring SID - 1
+    int ror = ring_row(-2 * LAG - (kDefer ? 2 : 0) + (kq >> 1)) * XP;   // epilogue: row 2pe + (kq >> 1)
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    auto epilogue = [&](auto chk, int pe, int q, f32x4 v) {
+      constexpr bool CHK = decltype(chk)::value;
       const int j = 16 * q + i;
-      f32x4 v = acc[jb] + bias;
+      if (CHK && pe >= npairs) {                   // the pair below the image: the next stage's zero padding
+        if (!last && j < XP) {
+          bf16x4 z;
+          z[0] = z[1] = z[2] = z[3] = (__bf16)0.f;
+          bf16x4* op = outh + (2 * (ror + j) + (kq & 1));
+          op[0] = z; op[2 * RING] = z;
+        }
+        return;
+      }
+      v += bias;
       if (has_res) {
         const bf16x4* rp = resh + (2 * (ror + j + 2) + (kq & 1));
         const bf16x4 a = rp[0], b = rp[2 * RING];
@@ -1117,18 +1161,10 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8
       }
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       if (last) {
-        {
-          const int orow = 2 * p + (kq >> 1);
-          const uint32_t oo = 4u * (uint32_t)((4 * (kq & 1) * H + orow) * W + X0 + j);
-          char* ob = reinterpret_cast<char*>(outf);
-          *reinterpret_cast<float*>(ob + oo) = v.x;
-          *reinterpret_cast<float*>(ob + (oo + 4u * (uint32_t)HW)) = v.y;
-          *reinterpret_cast<float*>(ob + (oo + 8u * (uint32_t)HW)) = v.z;
-          *reinterpret_cast<float*>(ob + (oo + 12u * (uint32_t)HW)) = v.w;
-        }
+        sx_st4(outf, 2 * pe + (kq >> 1), 0, X0 + j, kq & 1, W, 1, v);
       } else {
         if (edge) {
-          const int gx = X0 - (NS - sid) + j;      // image column of slot j of ring sid
+          const int gx = X0 - (NS - SID) + j;      // image column of slot j of ring SID
           if (gx < 0 || gx >= W) v = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (j < XP) {
@@ -1138,26 +1174,59 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8
           op[0] = vh; op[2 * RING] = vl;
         }
       }
-    }
-  };
-#define MSF_SS_STEP(q_, n_)                                                                       \
+    };
+    auto tile = [&](auto chk, int q, int p, f32x4& accp) {
+      constexpr bool CHK = decltype(chk)::value;
+      const bool sums = !CHK || (p >= 0 && p < npairs);     // wave-uniform
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      bf16x8 fh[3], fl[3];
+      if (sums) {
+        if (SID == 0) {
+          // stem: image rows 4p - 3 + 4g + kq, pixels 2j .. 2j + 7 of the tile
+#pragma unroll
+          for (int g = 0; g < 3; g++) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(iring + (((4 * p - 3 + 4 * g + kq) & (IROWS - 1)) * IP + 2 * (16 * q + i)));
+            fh[g] = __builtin_bit_cast(bf16x8, u32x4{src[0], src[1], src[2], src[3]});
+          }
+        } else {
+          const bf16x8* src = inh + (rin + 16 * q + i);
+#pragma unroll
+          for (int g = 0; g < 3; g++) { fh[g] = src[g]; fl[g] = src[RING + g]; }
+        }
+      }
+      if (kDefer && (!CHK || (p >= 1 && p <= npairs + 1))) epilogue(chk, p - 1, q, accp);
+      if (sums) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (SID == 0) {
+#pragma unroll
+          for (int g = 0; g < 3; g++) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[g], fh[g], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g], fh[g], acc, 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int g = 0; g < 3; g++) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[g], fh[g], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g], fl[g], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g], fh[g], acc, 0, 0, 0);
+          }
+        }
+        accp = acc;
+      }
+      if (!kDefer && (!CHK || (p >= 0 && p <= npairs))) epilogue(chk, p, q, accp);
+    };
+#define MSF_SS_STEP(chk_, q_, n_)                                                                 \
   {                                                                                               \
     __syncthreads();                                                                              \
     if (kLd) {                                                                                    \
       MSF_SS_COMMIT(q_, n_)                                                                       \
-      MSF_SS_ISSUE(q_, (n_) + MSF_LOFTR_STEM_DEPTH)                                                                  \
+      MSF_SS_ISSUE(q_, (n_) + kQDepth)                                                            \
     }                                                                                             \
-    const int p_ = (n_) - 2 - 2 * sid;                                                            \
-    if (p_ >= 0 && p_ <= npairs) stage(p_);                                                       \
+    tile(chk_, ws, (n_) - LAG, acc0);                                                             \
+    if (two) tile(chk_, ws + wps, (n_) - LAG, acc1);                                              \
     rin += 2 * XP; rin = rin >= RWRAP ? rin - RWRAP : rin;                                        \
     ror += 2 * XP; ror = ror >= RWRAP ? ror - RWRAP : ror;                                        \
   }
-  // the load queue is MSF_LOFTR_STEM_DEPTH steps deep (2, 3 or 4), each step's registers named statically; the loop is unrolled by the depth
-  constexpr int kQDepth = MSF_LOFTR_STEM_DEPTH;
-  static_assert(kQDepth >= 2 && kQDepth <= 4, "load queue depth");
-  const int nsteps = ((npairs + 2 * NS + 2 + kQDepth - 1) / kQDepth) * kQDepth;
-  auto run = [&](auto is_loader) {
-    constexpr bool kLd = decltype(is_loader)::value;
     uint32_t q0 = 0; uint32_t q1 = 0;
     uint32_t q2 = 0;
     uint32_t q3 = 0;
@@ -1167,18 +1236,28 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8
       MSF_SS_ISSUE(q2, 2)
       MSF_SS_ISSUE(q3, 3)
     }
+    const int n_lo = ((LAG + 1 + kQDepth - 1) / kQDepth) * kQDepth, n_hi = ((npairs + LAG) / kQDepth) * kQDepth;
     for (int n = 0; n < nsteps; n += kQDepth) {
-      MSF_SS_STEP(q0, n)
-      MSF_SS_STEP(q1, n + 1)
-      MSF_SS_STEP(q2, n + 2)
-      MSF_SS_STEP(q3, n + 3)
+      if (n >= n_lo && n < n_hi) {
+        MSF_SS_STEP(std::false_type{}, q0, n)
+        MSF_SS_STEP(std::false_type{}, q1, n + 1)
+        MSF_SS_STEP(std::false_type{}, q2, n + 2)
+        MSF_SS_STEP(std::false_type{}, q3, n + 3)
+      } else {
+        MSF_SS_STEP(std::true_type{}, q0, n)
+        MSF_SS_STEP(std::true_type{}, q1, n + 1)
+        MSF_SS_STEP(std::true_type{}, q2, n + 2)
+        MSF_SS_STEP(std::true_type{}, q3, n + 3)
+      }
     }
+#undef MSF_SS_STEP
   };
-  if (ldwave) run(std::true_type{});
-  else run(std::false_type{});
+  static_assert((NLOAD - 1) / 64 < 3, "the image loader must fit into the stem waves");
+  if (sid == 0) run(std::true_type{}, std::integral_constant<int, 0>{});
+  else if (sid == 1) run(std::false_type{}, std::integral_constant<int, 1>{});
+  else run(std::false_type{}, std::integral_constant<int, 2>{});
 #undef MSF_SS_ISSUE
 #undef MSF_SS_COMMIT
-#undef MSF_SS_STEP
 }
 
 // ------------------------------------------------------------------ streaming down-sampling BasicBlock 8 -> 16 (layer2, block 1)
@@ -1274,18 +1353,16 @@ __global__ __launch_bounds__(64 * down16::WAVES) void k_down16x(const float* __r
 #define MSF_DN_ISSUE(q_, n_)                                                                      \
   {                                                                                               \
     const int gy = 4 * (n_) + r4;                                                                 \
-    const uint32_t so = (colok && gy < Hin) ? 4u * (lofs + (uint32_t)(gy * Win)) : 0u;            \
-    _Pragma("unroll") for (int c = 0; c < 8; c++)                                                 \
-      q_[c] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(inf) + (so + 4u * (uint32_t)(c * HWin))); \
+    const uint32_t so = (colok && gy < Hin) ? sx_off(gy, 0, 0, (int)lofs, Win, 1) : 0u;           \
+    q_[0] = sx_ld(inf, so);                                                                       \
+    q_[1] = sx_ld(inf, so + 16u * (uint32_t)Win);                                                 \
   }
 #define MSF_DN_COMMIT(q_, n_)                                                                     \
   if (ld) {                                                                                       \
     const bool ok = colok && 4 * (n_) + r4 < Hin;                                                 \
-    bf16x4 h0, l0, h1, l1;                                                                        \
-    split4(ok ? f32x4{q_[0], q_[1], q_[2], q_[3]} : f32x4{0.f, 0.f, 0.f, 0.f}, h0, l0);           \
-    split4(ok ? f32x4{q_[4], q_[5], q_[6], q_[7]} : f32x4{0.f, 0.f, 0.f, 0.f}, h1, l1);           \
-    bf16x4* dst = reinterpret_cast<bf16x4*>(xr + (irow + r4 * IPX + lslot));                      \
-    dst[0] = h0; dst[1] = h1; dst[2 * IPLANE] = l0; dst[2 * IPLANE + 1] = l1;                     \
+    const u32x4v z4 = u32x4v{0u, 0u, 0u, 0u};                                                     \
+    u32x4v* dst = reinterpret_cast<u32x4v*>(xr + (irow + r4 * IPX + lslot));                      \
+    dst[0] = ok ? q_[0] : z4; dst[IPLANE] = ok ? q_[1] : z4;                                      \
   }
   int irow = 0;                                    // loader cursor: (4n mod 12) * IPX (a step's four rows never wrap inside)
   constexpr int IWRAP = IROWS * IPX;
@@ -1369,12 +1446,7 @@ __global__ __launch_bounds__(64 * down16::WAVES) void k_down16x(const float* __r
       v.x += (float)a[0] + (float)b[0]; v.y += (float)a[1] + (float)b[1];
       v.z += (float)a[2] + (float)b[2]; v.w += (float)a[3] + (float)b[3];
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-      const uint32_t oo = 4u * (uint32_t)((4 * kq * H + Y) * W + X0 + j);
-      char* ob = reinterpret_cast<char*>(outf);
-      *reinterpret_cast<float*>(ob + oo) = v.x;
-      *reinterpret_cast<float*>(ob + (oo + 4u * (uint32_t)HW)) = v.y;
-      *reinterpret_cast<float*>(ob + (oo + 8u * (uint32_t)HW)) = v.z;
-      *reinterpret_cast<float*>(ob + (oo + 12u * (uint32_t)HW)) = v.w;
+      sx_st4(outf, Y, kq >> 1, X0 + j, kq & 1, W, 2, v);        // channels 4 kq .. +3: block kq >> 1, half kq & 1
     }
   };
 #define MSF_DN_STEP(q_, n_)                                                                       \
@@ -1399,7 +1471,7 @@ __global__ __launch_bounds__(64 * down16::WAVES) void k_down16x(const float* __r
   const int nsteps = ((npairs + 3 + kDepth - 1) / kDepth) * kDepth;
   auto run = [&](auto is_loader) {
     constexpr bool kLd = decltype(is_loader)::value;
-    float q0[8], q1[8], q2[8];
+    u32x4v q0[2], q1[2], q2[2];
     if (kLd) {
       MSF_DN_ISSUE(q0, 0)
       MSF_DN_ISSUE(q1, 1)
@@ -1479,23 +1551,21 @@ __global__ __launch_bounds__(64 * strip16::WAVES) void k_strip16x(const float* _
   const int lr = lrm / XW, lc = lrm - lr * XW;
   const int lgx = X0 - 2 + lc;
   const bool colok = ld && lgx >= 0 && lgx < W;
-  const uint32_t lofs = colok ? (uint32_t)(8 * lcb * HW + lgx) : 0u;
+  const uint32_t lofs = colok ? (uint32_t)lgx : 0u;
   const bool ldwave = wave <= (NLOAD - 1) / 64;
 #define MSF_S16_ISSUE(q_, n_)                                                                     \
   {                                                                                               \
     const int gy = 2 * (n_) + lr;                                                                 \
-    const uint32_t so = (colok && gy < H) ? 4u * (lofs + (uint32_t)(gy * W)) : 0u;                \
-    _Pragma("unroll") for (int c = 0; c < 8; c++)                                                 \
-      q_[c] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(inf) + (so + 4u * (uint32_t)(c * HW))); \
+    const uint32_t so = (colok && gy < H) ? sx_off(gy, 0, lcb, (int)lofs, W, 2) : 0u;             \
+    q_[0] = sx_ld(inf, so);                                                                       \
+    q_[1] = sx_ld(inf, so + 32u * (uint32_t)W);                                                   \
   }
 #define MSF_S16_COMMIT(q_, n_)                                                                    \
   if (ld) {                                                                                       \
     const bool ok = colok && 2 * (n_) + lr < H;                                                   \
-    bf16x4 h0, l0, h1, l1;                                                                        \
-    split4(ok ? f32x4{q_[0], q_[1], q_[2], q_[3]} : f32x4{0.f, 0.f, 0.f, 0.f}, h0, l0);           \
-    split4(ok ? f32x4{q_[4], q_[5], q_[6], q_[7]} : f32x4{0.f, 0.f, 0.f, 0.f}, h1, l1);           \
-    bf16x4* dst = reinterpret_cast<bf16x4*>(xr + (lcb * XCB + crow + lr * XPX + lc));             \
-    dst[0] = h0; dst[1] = h1; dst[4 * XCB] = l0; dst[4 * XCB + 1] = l1;                           \
+    const u32x4v z4 = u32x4v{0u, 0u, 0u, 0u};                                                     \
+    u32x4v* dst = reinterpret_cast<u32x4v*>(xr + (lcb * XCB + crow + lr * XPX + lc));             \
+    dst[0] = ok ? q_[0] : z4; dst[2 * XCB] = ok ? q_[1] : z4;                                     \
   }
   int crow = 0;                                    // loader cursor: (2n mod 12) * XPX
   constexpr int XWRAP = XROWS * XPX;
@@ -1576,12 +1646,7 @@ __global__ __launch_bounds__(64 * strip16::WAVES) void k_strip16x(const float* _
       v.x += (float)a[0] + (float)b[0]; v.y += (float)a[1] + (float)b[1];
       v.z += (float)a[2] + (float)b[2]; v.w += (float)a[3] + (float)b[3];
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-      const uint32_t oo = 4u * (uint32_t)((4 * kq * H + Y) * W + X0 + j);
-      char* ob = reinterpret_cast<char*>(outf);
-      *reinterpret_cast<float*>(ob + oo) = v.x;
-      *reinterpret_cast<float*>(ob + (oo + 4u * (uint32_t)HW)) = v.y;
-      *reinterpret_cast<float*>(ob + (oo + 8u * (uint32_t)HW)) = v.z;
-      *reinterpret_cast<float*>(ob + (oo + 12u * (uint32_t)HW)) = v.w;
+      sx_st4(outf, Y, kq >> 1, X0 + j, kq & 1, W, 2, v);
     }
   };
 #define MSF_S16_STEP(q_, n_)                                                                      \
@@ -1606,7 +1671,7 @@ __global__ __launch_bounds__(64 * strip16::WAVES) void k_strip16x(const float* _
   const int nsteps = ((npairs + 4 + kQDepth - 1) / kQDepth) * kQDepth;
   auto run = [&](auto is_loader) {
     constexpr bool kLd = decltype(is_loader)::value;
-    float q0[8]; float q1[8];
+    u32x4v q0[2]; u32x4v q1[2];
     if (kLd) {
       MSF_S16_ISSUE(q0, 0)
       MSF_S16_ISSUE(q1, 1)
@@ -1681,29 +1746,36 @@ __global__ __launch_bounds__(64 * strip32::WAVES) MSF_STRIP32_ATTR void k_strip3
     for (int idx = tid; idx < LDS_BYTES / 4; idx += 64 * WAVES) z[idx] = 0u;
   }
   // loader (the last NLOAD threads): thread (channel block lcb, row lr of the pair, ring column lc) fetches 8 channel dwords
-  const int ltid = tid - (64 * WAVES - NLOAD);
+#ifndef MSF_S32_LOADERS_FIRST
+  const int ltid = tid - (64 * WAVES - NLOAD);     // (r05: in the stage-A waves instead -- no stores there, see k_strip8x -- 362 -> 654 us:
+                                                   // those waves carry two M-tile jobs each, the loader on top makes them the step)
+#else
+  const int ltid = tid < NLOAD ? tid : -1;
+#endif
   const bool ld = ltid >= 0;
   const int lcb = ld ? ltid / (2 * XW) : 0, lrm = ld ? ltid - lcb * 2 * XW : 0;
   const int lr = lrm / XW, lc = lrm - lr * XW;
   const int lgx = X0 - 2 + lc;
   const bool colok = ld && lgx >= 0 && lgx < W;
-  const uint32_t lofs = colok ? (uint32_t)(8 * lcb * HW + lgx) : 0u;
+  const uint32_t lofs = colok ? (uint32_t)lgx : 0u;
+#ifndef MSF_S32_LOADERS_FIRST
   const bool ldwave = wave >= (64 * WAVES - NLOAD) / 64;
+#else
+  const bool ldwave = wave <= (NLOAD - 1) / 64;
+#endif
 #define MSF_S32_ISSUE(q_, n_)                                                                     \
   {                                                                                               \
     const int gy = 2 * (n_) + lr;                                                                 \
-    const uint32_t so = (colok && gy < H) ? 4u * (lofs + (uint32_t)(gy * W)) : 0u;                \
-    _Pragma("unroll") for (int c = 0; c < 8; c++)                                                 \
-      q_[c] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(inf) + (so + 4u * (uint32_t)(c * HW))); \
+    const uint32_t so = (colok && gy < H) ? sx_off(gy, 0, lcb, (int)lofs, W, 4) : 0u;             \
+    q_[0] = sx_ld(inf, so);                                                                       \
+    q_[1] = sx_ld(inf, so + 64u * (uint32_t)W);                                                   \
   }
 #define MSF_S32_COMMIT(q_, n_)                                                                    \
   if (ld) {                                                                                       \
     const bool ok = colok && 2 * (n_) + lr < H;                                                   \
-    bf16x4 h0, l0, h1, l1;                                                                        \
-    split4(ok ? f32x4{q_[0], q_[1], q_[2], q_[3]} : f32x4{0.f, 0.f, 0.f, 0.f}, h0, l0);           \
-    split4(ok ? f32x4{q_[4], q_[5], q_[6], q_[7]} : f32x4{0.f, 0.f, 0.f, 0.f}, h1, l1);           \
-    bf16x4* dst = reinterpret_cast<bf16x4*>(xr + (lcb * XCB + crow + lr * XPX + lc));             \
-    dst[0] = h0; dst[1] = h1; dst[8 * XCB] = l0; dst[8 * XCB + 1] = l1;                           \
+    const u32x4v z4 = u32x4v{0u, 0u, 0u, 0u};                                                     \
+    u32x4v* dst = reinterpret_cast<u32x4v*>(xr + (lcb * XCB + crow + lr * XPX + lc));             \
+    dst[0] = ok ? q_[0] : z4; dst[4 * XCB] = ok ? q_[1] : z4;                                     \
   }
   int crow = 0;                                    // loader cursor: (2n mod 12) * XPX
   constexpr int XWRAP = XROWS * XPX;
@@ -1813,7 +1885,7 @@ __global__ __launch_bounds__(64 * strip32::WAVES) MSF_STRIP32_ATTR void k_strip3
   const int nsteps = ((npairs + 4 + kQDepth - 1) / kQDepth) * kQDepth;
   auto run = [&](auto is_loader) {
     constexpr bool kLd = decltype(is_loader)::value;
-    float q0[8]; float q1[8];
+    u32x4v q0[2]; u32x4v q1[2];
     if (kLd) {
       MSF_S32_ISSUE(q0, 0)
       MSF_S32_ISSUE(q1, 1)
@@ -1900,24 +1972,22 @@ __global__ __launch_bounds__(64 * down32::WAVES) void k_down32x(const float* __r
   const int r4 = lrm / INW, lc = lrm - r4 * INW;
   const int lgx = 2 * X0 - 3 + lc;
   const bool colok = ld && lgx >= 0 && lgx < Win;
-  const uint32_t lofs = colok ? (uint32_t)(8 * lcb * HWin + lgx) : 0u;
+  const uint32_t lofs = colok ? (uint32_t)lgx : 0u;
   const int lslot = (lc & 1) ? IODD + (lc >> 1) : (lc >> 1);
   const bool ldwave = wave <= (NLOAD - 1) / 64;
 #define MSF_D32_ISSUE(q_, n_)                                                                     \
   {                                                                                               \
     const int gy = 4 * (n_) + r4;                                                                 \
-    const uint32_t so = (colok && gy < Hin) ? 4u * (lofs + (uint32_t)(gy * Win)) : 0u;            \
-    _Pragma("unroll") for (int c = 0; c < 8; c++)                                                 \
-      q_[c] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(inf) + (so + 4u * (uint32_t)(c * HWin))); \
+    const uint32_t so = (colok && gy < Hin) ? sx_off(gy, 0, lcb, (int)lofs, Win, 2) : 0u;         \
+    q_[0] = sx_ld(inf, so);                                                                       \
+    q_[1] = sx_ld(inf, so + 32u * (uint32_t)Win);                                                 \
   }
 #define MSF_D32_COMMIT(q_, n_)                                                                    \
   if (ld) {                                                                                       \
     const bool ok = colok && 4 * (n_) + r4 < Hin;                                                 \
-    bf16x4 h0, l0, h1, l1;                                                                        \
-    split4(ok ? f32x4{q_[0], q_[1], q_[2], q_[3]} : f32x4{0.f, 0.f, 0.f, 0.f}, h0, l0);           \
-    split4(ok ? f32x4{q_[4], q_[5], q_[6], q_[7]} : f32x4{0.f, 0.f, 0.f, 0.f}, h1, l1);           \
-    bf16x4* dst = reinterpret_cast<bf16x4*>(xr + (lcb * ICB + irow + r4 * IPX + lslot));          \
-    dst[0] = h0; dst[1] = h1; dst[4 * ICB] = l0; dst[4 * ICB + 1] = l1;                           \
+    const u32x4v z4 = u32x4v{0u, 0u, 0u, 0u};                                                     \
+    u32x4v* dst = reinterpret_cast<u32x4v*>(xr + (lcb * ICB + irow + r4 * IPX + lslot));          \
+    dst[0] = ok ? q_[0] : z4; dst[2 * ICB] = ok ? q_[1] : z4;                                     \
   }
   int irow = 0;                                    // loader cursor: (4n mod 12) * IPX
   constexpr int IWRAP = IROWS * IPX;
@@ -2010,14 +2080,7 @@ __global__ __launch_bounds__(64 * down32::WAVES) void k_down32x(const float* __r
     v.x += (float)a[0] + (float)b[0]; v.y += (float)a[1] + (float)b[1];
     v.z += (float)a[2] + (float)b[2]; v.w += (float)a[3] + (float)b[3];
     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-    if (X0 + i < W) {
-      const uint32_t oo = 4u * (uint32_t)(((16 * nt + 4 * kq) * H + Y) * W + X0 + i);
-      char* ob = reinterpret_cast<char*>(outf);
-      *reinterpret_cast<float*>(ob + oo) = v.x;
-      *reinterpret_cast<float*>(ob + (oo + 4u * (uint32_t)HW)) = v.y;
-      *reinterpret_cast<float*>(ob + (oo + 8u * (uint32_t)HW)) = v.z;
-      *reinterpret_cast<float*>(ob + (oo + 12u * (uint32_t)HW)) = v.w;
-    }
+    if (X0 + i < W) sx_st4(outf, Y, cbp, X0 + i, kq & 1, W, 4, v);   // channels 16 nt + 4 kq .. +3: block cbp, half kq & 1
   };
 #define MSF_D32_STEP(q_, n_)                                                                      \
   {                                                                                               \
@@ -2041,9 +2104,9 @@ __global__ __launch_bounds__(64 * down32::WAVES) void k_down32x(const float* __r
   const int nsteps = ((npairs + 3 + kQDepth - 1) / kQDepth) * kQDepth;
   auto run = [&](auto is_loader) {
     constexpr bool kLd = decltype(is_loader)::value;
-    float q0[8]; float q1[8];
-    float q2[8];
-    float q3[8];
+    u32x4v q0[2]; u32x4v q1[2];
+    u32x4v q2[2];
+    u32x4v q3[2];
     if (kLd) {
       MSF_D32_ISSUE(q0, 0)
       MSF_D32_ISSUE(q1, 1)
@@ -4009,6 +4072,7 @@ struct LoftrPipeline::Impl {
   float* conf_dbg = nullptr; // [1200][1200]
   float* feat_dbg = nullptr; // [2][1200][32]
   float* act_dbg[4] = {nullptr, nullptr, nullptr, nullptr};   // frame A of pair 0 after layer1..4: [8][240][320], [16][120][160], [32][60][80], [32][30][40]
+  bool act_split[4] = {false, false, false, false};           // ... kept in the streaming kernels' split-pixel format (debug_get converts)
   int dbg_pair = 0;
   bool have_dbg = false;
   // Stage events (start, backbone done, transformer done, head done) as a ring of sets: a call records into the next free
@@ -4493,7 +4557,10 @@ void launch_block8x(const ConvDesc& ca, const ConvDesc& cb, const float* in, flo
 // one 8-channel BasicBlock as a streaming pass (k_strip8x<1>): convolutions cv[0], cv[1]
 void launch_strip8x(const ConvDesc* cv, const float* in, float* out, int n_img, hipStream_t st) {
   constexpr int NB = 1, WVW = strip8::WAVES;
-  auto kern = k_strip8x<NB, WVW, strip8::S>;
+#ifndef MSF_STRIP8_S
+#define MSF_STRIP8_S strip8::S
+#endif
+  auto kern = k_strip8x<NB, WVW, MSF_STRIP8_S>;
   constexpr int lds = strip8::lds_bytes<NB>();
   static std::once_flag attr_once;     // handles on several host threads (msf_multi) may arrive here together
   std::call_once(attr_once, [&] {
@@ -4501,7 +4568,7 @@ void launch_strip8x(const ConvDesc* cv, const float* in, float* out, int n_img, 
   });
   StripW sw{};
   for (int c = 0; c < 2 * NB; c++) { sw.wx[c] = cv[c].d_wx; sw.b[c] = cv[c].d_b; }
-  const int Wd = cv[0].wout, Sd = strip8::S;
+  const int Wd = cv[0].wout, Sd = MSF_STRIP8_S;
   const int n_strips = (Wd - Sd + Sd - 1) / Sd + 1;
   hipLaunchKernelGGL(kern, dim3(n_strips * n_img), dim3(64 * WVW), lds, st, in, sw, out, cv[0].hout, Wd, n_strips);
 }
@@ -4721,10 +4788,14 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
     launch_conv<8, 8, 3, 1, 64, true, false, false, 2>(c[3], cc, s8, 0, nullptr, b, ni, st);
     launch_conv<8, 8, 3, 1, 64, true, true, false, 2>(c[4], b, s8, 0, cc, a, ni, st);                 // a = 196
   }
-  auto keep = [&](int l, const float* src, size_t elems) {   // MSF_FLAG_KEEP_DEBUG: the first image's activation
-    if (P.act_dbg[l]) hipMemcpyAsync(P.act_dbg[l], src, elems * sizeof(float), hipMemcpyDeviceToDevice, st);
+  // MSF_FLAG_KEEP_DEBUG: the first image's activation (raw bytes; `split`: in the streaming kernels' split-pixel format)
+  auto keep = [&](int l, const float* src, size_t elems, bool split) {
+    if (P.act_dbg[l]) {
+      hipMemcpyAsync(P.act_dbg[l], src, elems * sizeof(float), hipMemcpyDeviceToDevice, st);
+      P.act_split[l] = split;
+    }
   };
-  keep(0, a, 8u * 240 * 320);
+  keep(0, a, 8u * 240 * 320, P.fuse_blocks && stem_fused);
   // layer2 @120x160, 16 ch
   const long long s16 = 16LL * 120 * 160;
   if (P.fuse_blocks && P.split_bf16 && strip_mode != 0 && P.down_stream) {
@@ -4741,7 +4812,7 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
     launch_conv<16, 16, 3, 1, 32, true, false, false>(c[8], cc, s16, 0, nullptr, b, ni, st);
     launch_conv<16, 16, 3, 1, 32, true, true, false>(c[9], b, s16, 0, cc, a, ni, st);              // a = 212
   }
-  keep(1, a, 16u * 120 * 160);
+  keep(1, a, 16u * 120 * 160, P.fuse_blocks && P.split_bf16 && strip_mode != 0 && P.down_stream);
   // layer3 @60x80, 32 ch
   const long long s32 = 32LL * 60 * 80;
   const bool down3 = P.split_bf16 && P.fuse_blocks && strip_mode != 0 && P.down_stream;
@@ -4761,7 +4832,7 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
     launch_conv<32, 32, 3, 1, 16, true, false, false>(c[13], cc, s32, 0, nullptr, b, ni, st);
     launch_conv<32, 32, 3, 1, 16, true, true, false>(c[14], b, s32, 0, cc, a, ni, st);             // a = 228
   }
-  keep(2, a, 32u * 60 * 80);
+  keep(2, a, 32u * 60 * 80, false);
   // layer4 @30x40, 32 ch
   const long long s40 = 32LL * 30 * 40;
   if (P.split_bf16) launch_convx2<32>(c[15], c[17], a, b, d, ni, st);
@@ -4776,7 +4847,7 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
     launch_conv<32, 32, 3, 1, 16, true, false, false>(c[18], cc, s40, 0, nullptr, b, ni, st);
     launch_conv<32, 32, 3, 1, 16, true, true, false>(c[19], b, s40, 0, cc, a, ni, st);             // a = 244
   }
-  keep(3, a, 32u * 30 * 40);
+  keep(3, a, 32u * 30 * 40, false);
   launch_conv<32, 32, 1, 1, 16, false, false, false>(c[20], a, s40, 0, nullptr, b, ni, st);      // b = 245
   const int tok_tiles = (NTOK + kTokTile - 1) / kTokTile;
   if (nA) hipLaunchKernelGGL(k_tokens, dim3(tok_tiles, nA), dim3(256), 0, st, b, P.d_pe, tokA, nA);
@@ -4919,6 +4990,23 @@ int LoftrPipeline::debug_get(int what, int slot, int level, void* host_out, size
   else { *err = "unknown debug item for LoFTR"; return MSF_ERR_INVALID_ARG; }
   *n_bytes = bytes;
   const size_t n = bytes < cap ? bytes : cap;
+  if (what == MSF_DBG_LOFTR_ACT && p_->act_split[level]) {
+    // kept in split pixels ([y][hi | lo][channel block][x] x 8 bf16): back to the graph's NCHW f32, v = hi + lo
+    const int C = level == 0 ? 8 : 16, H = level == 0 ? 240 : 120, W = level == 0 ? 320 : 160, CB = C / 8;
+    std::vector<uint16_t> raw(bytes / 2);
+    if (hipMemcpy(raw.data(), src, bytes, hipMemcpyDeviceToHost) != hipSuccess) { *err = "hipMemcpy failed"; return MSF_ERR_HIP; }
+    std::vector<float> nchw(bytes / 4);
+    auto bf = [](uint16_t b) { const uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
+    for (int y = 0; y < H; y++)
+      for (int cb = 0; cb < CB; cb++)
+        for (int x = 0; x < W; x++)
+          for (int k = 0; k < 8; k++) {
+            const size_t hi = ((((size_t)y * 2 + 0) * CB + cb) * W + x) * 8 + k, lo = ((((size_t)y * 2 + 1) * CB + cb) * W + x) * 8 + k;
+            nchw[((size_t)(8 * cb + k) * H + y) * W + x] = bf(raw[hi]) + bf(raw[lo]);
+          }
+    memcpy(host_out, nchw.data(), n);
+    return 0;
+  }
   if (n && hipMemcpy(host_out, src, n, hipMemcpyDeviceToHost) != hipSuccess) { *err = "hipMemcpy failed"; return MSF_ERR_HIP; }
   return 0;
 }
