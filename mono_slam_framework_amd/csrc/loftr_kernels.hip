@@ -778,13 +778,7 @@ constexpr int S = 64;                              // output columns per strip
 // multiple of 256 B apart, so that the 16 slots a ds_read_b128 lane group takes from two ring rows meet no bank twice)
 // changed nothing: 642 vs 617 us -- the conflicts are not in the fragment reads, and they are not what bounds the step.
 constexpr int XP = 72;
-// MSF_LOFTR_DEFER = 1: a stage runs a pair's epilogue one step after its sums (see k_strip8x); rings then hold seven pairs
-// (pair p of x is still read -- as the residual -- at step p + 6, while pair p + 6 arrives) instead of six
-#ifndef MSF_LOFTR_DEFER
-#define MSF_LOFTR_DEFER 0
-#endif
-constexpr bool kDefer = MSF_LOFTR_DEFER != 0;
-constexpr int RROWS = kDefer ? 14 : 12;
+constexpr int RROWS = 12;                          // six row pairs per ring (five are live in a step)
 constexpr int RING = RROWS * XP;                   // pixel slots per plane
 constexpr int TAIL = 16;                           // the fifth M tile of a stage reads up to 10 slots past a ring row
 constexpr int WAVES = 8;
@@ -799,7 +793,7 @@ constexpr int WAVES = 8;
 // the memory system gives, and the step time is the prefetch distance (4 steps) into the loaded-memory latency.
 template <int NB>
 constexpr int lds_bytes() { return 16 * (2 * NB * 2 * RING + TAIL); }
-__device__ __forceinline__ int ring_row(int r) {   // r mod RROWS for r >= -4 RROWS (used when the cursors are set up; they are carried afterwards)
+__device__ __forceinline__ int ring_row(int r) {   // r mod RROWS for r >= -4 RROWS (only when the cursors are set up: they are carried afterwards)
   return (r + 4 * RROWS) % RROWS;
 }
 }  // namespace strip8
@@ -892,13 +886,8 @@ __global__ __launch_bounds__(64 * WV) void k_strip8x(const float* __restrict__ i
   const bool edge = X0 == 0 || X0 + S == W;        // wave-uniform: only the outer strips have columns outside the image
   constexpr int kQDepth = MSF_LOFTR_STRIP8_DEPTH;  // load queue: steps ahead, each step's registers named statically, loop unrolled by it
   static_assert(kQDepth >= 2 && kQDepth <= 4, "load queue depth");
-  // stage c lags LAG(c) steps behind the loader (which writes pair n at step n): it makes pair n - LAG at step n.
-  //   plain (kDefer = 0): LAG = 2c, the whole pair in its step.
-  //   deferred: LAG = 3c - 1 for the sums (fragment reads + MFMAs); the EPILOGUE of a pair (bias, residual, ReLU, split,
-  //   ring write or store) runs one step later, between the next pair's fragment reads and its MFMAs, so that it executes
-  //   while those reads are in flight and nothing waits for an MFMA in the step that issued it; sums cross the barrier in
-  //   registers.  Results are identical either way.
-  const int nsteps = ((npairs + (kDefer ? 3 : 2) * NS + kQDepth - 1) / kQDepth) * kQDepth;
+  // stage c makes pair n - 2c at step n (the loader writes pair n at step n); its last pair at step npairs - 1 + 2 NS
+  const int nsteps = ((npairs + 2 * NS + kQDepth - 1) / kQDepth) * kQDepth;
   // r05: ONE COPY OF THE STEP LOOP PER (loader?, stage), everything a stage decides -- last stage / residual / number of M
   // tiles / ring addresses -- a compile-time constant, and the steps in which every pair index is inside the image (all
   // but the first and last few) without a single range check.  r04's loop was one body for all stages: its uniform
@@ -910,16 +899,14 @@ __global__ __launch_bounds__(64 * WV) void k_strip8x(const float* __restrict__ i
     constexpr bool last = CST == NS, has_res = (CST & 1) == 0;
     constexpr int MT = (S + 2 * (NS - CST) + 15) / 16;   // M tiles: S (+ 2 (NS - c) halo) columns
     static_assert(MT >= WPS && MT <= 2 * WPS, "one or two M tiles per wave");
-    constexpr int LAG = kDefer ? 3 * CST - 1 : 2 * CST;
+    constexpr int LAG = 2 * CST;
     const bool two = ws + WPS < MT;                      // wave-uniform: this wave also makes the stage's extra tile
     const bf16x8* inh = ring + (CST - 1) * 2 * RING;
     const bf16x4* resh = reinterpret_cast<const bf16x4*>(ring + (has_res ? CST - 2 : 0) * 2 * RING);
     bf16x4* outh = reinterpret_cast<bf16x4*>(ring + (last ? 0 : CST) * 2 * RING);
     int crow = ring_row(lr) * XP;                        // loader: row 2n + lr
     int rin = ring_row(-2 * LAG - 1 + kq) * XP;          // sums: fragment row 2p - 1 + kq, p = n - LAG
-    // epilogue: row 2pe + (kq >> 1) of the output / residual ring, pe = p (plain) or p - 1 (deferred)
-    int ror = ring_row(-2 * LAG - (kDefer ? 2 : 0) + (kq >> 1)) * XP;
-    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;   // deferred: the sums made in the previous step
+    int ror = ring_row(-2 * LAG + (kq >> 1)) * XP;       // epilogue: row 2p + (kq >> 1) of the output / residual ring
     // epilogue of M tile q of pair pe (sums v) -- or, for pe == npairs (CHK only), the zero rows below the image
     auto epilogue = [&](auto chk, int pe, int q, f32x4 v) {
       constexpr bool CHK = decltype(chk)::value;
@@ -957,9 +944,8 @@ __global__ __launch_bounds__(64 * WV) void k_strip8x(const float* __restrict__ i
         }
       }
     };
-    // M tile q of this wave at a step whose sums pair is p: fragment reads of pair p, [deferred: epilogue of pair p - 1],
-    // MFMAs of pair p, [plain: epilogue of pair p]
-    auto tile = [&](auto chk, int q, int p, f32x4& accp) {
+    // M tile q of this wave, pair p: fragment reads, MFMAs, epilogue
+    auto tile = [&](auto chk, int q, int p) {
       constexpr bool CHK = decltype(chk)::value;
       const bool sums = !CHK || (p >= 0 && p < npairs);     // wave-uniform
       bf16x8 fh[3], fl[3];
@@ -968,18 +954,16 @@ __global__ __launch_bounds__(64 * WV) void k_strip8x(const float* __restrict__ i
 #pragma unroll
         for (int g = 0; g < 3; g++) { fh[g] = src[g]; fl[g] = src[RING + g]; }
       }
-      if (kDefer && (!CHK || (p >= 1 && p <= npairs + 1))) epilogue(chk, p - 1, q, accp);
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
       if (sums) {
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < 3; g++) {
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[g], fh[g], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g], fl[g], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g], fh[g], acc, 0, 0, 0);
         }
-        accp = acc;
       }
-      if (!kDefer && (!CHK || (p >= 0 && p <= npairs))) epilogue(chk, p, q, accp);
+      if (!CHK || (p >= 0 && p <= npairs)) epilogue(chk, p, q, acc);
     };
     // one step: barrier (everything written in the previous step is visible; nothing read in it is overwritten before),
     // pair n of x into its ring, the queue slot refilled with pair n + depth, this wave's stage
@@ -990,8 +974,8 @@ __global__ __launch_bounds__(64 * WV) void k_strip8x(const float* __restrict__ i
       MSF_ST_COMMIT(q_, n_)                                                                       \
       MSF_ST_ISSUE(q_, (n_) + kQDepth)                                                            \
     }                                                                                             \
-    tile(chk_, ws, (n_) - LAG, acc0);                                                             \
-    if (two) tile(chk_, ws + WPS, (n_) - LAG, acc1);                                              \
+    tile(chk_, ws, (n_) - LAG);                                                                   \
+    if (two) tile(chk_, ws + WPS, (n_) - LAG);                                                    \
     crow += 2 * XP; crow = crow >= RWRAP ? crow - RWRAP : crow;                                   \
     rin += 2 * XP; rin = rin >= RWRAP ? rin - RWRAP : rin;                                        \
     ror += 2 * XP; ror = ror >= RWRAP ? ror - RWRAP : ror;                                        \
@@ -1003,8 +987,8 @@ __global__ __launch_bounds__(64 * WV) void k_strip8x(const float* __restrict__ i
       MSF_ST_ISSUE(q1, 1)
       MSF_ST_ISSUE(q2, 2)
     }
-    // steps n with 1 <= n - LAG and n - LAG <= npairs - 1 need no range check on the stage's pairs
-    const int n_lo = ((LAG + 1 + kQDepth - 1) / kQDepth) * kQDepth, n_hi = ((npairs + LAG) / kQDepth) * kQDepth;
+    // steps n with 0 <= n - LAG <= npairs - 1 need no range check on the stage's pairs
+    const int n_lo = ((LAG + kQDepth - 1) / kQDepth) * kQDepth, n_hi = ((npairs + LAG) / kQDepth) * kQDepth;
     for (int n = 0; n < nsteps; n += kQDepth) {
       if (n >= n_lo && n < n_hi) {
         MSF_ST_STEP(std::false_type{}, q0, n)
@@ -1122,24 +1106,22 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8
   const bool edge = X0 == 0 || X0 + S == W;
   constexpr int kQDepth = MSF_LOFTR_STEM_DEPTH;    // load queue: steps ahead, statically named registers, loop unrolled by it
   static_assert(kQDepth == 4, "the step macro is written out for a four-step queue");
-  // Lags behind the image loader (rows 4n .. 4n + 3 arrive at step n; the stem's sums of pair p need rows up to 4p + 5,
-  // arrived at step p + 1): plain: stage s makes pair n - 2 - 2s in its step; deferred (k_strip8x): sums of pair
-  // n - 2 - 3s, that pair's epilogue one step later.
-  const int nsteps = ((npairs + (kDefer ? 3 * NS + 4 : 2 * NS + 2) + kQDepth - 1) / kQDepth) * kQDepth;
+  // Lags behind the image loader (rows 4n .. 4n + 3 arrive at step n; the stem's pair p needs rows up to 4p + 5, arrived
+  // at step p + 1): stage s makes pair n - 2 - 2s at step n
+  const int nsteps = ((npairs + 2 * NS + 2 + kQDepth - 1) / kQDepth) * kQDepth;
   // one copy of the step loop per stage (the loader lives in the stem waves), see k_strip8x
   auto run = [&](auto is_loader, auto stage_c) {
     constexpr bool kLd = decltype(is_loader)::value;
     constexpr int SID = decltype(stage_c)::value;
     constexpr bool last = SID == NS, has_res = SID == 2;
     constexpr int MT = last ? 4 : 5, wps = SID == 2 ? 2 : 3;
-    constexpr int LAG = kDefer ? 2 + 3 * SID : 2 + 2 * SID;
+    constexpr int LAG = 2 + 2 * SID;
     const bool two = ws + wps < MT;                      // wave-uniform
     const bf16x8* inh = ring + (SID > 0 ? SID - 1 : 0) * 2 * RING;
     const bf16x4* resh = reinterpret_cast<const bf16x4*>(ring);
     bf16x4* outh = reinterpret_cast<bf16x4*>(ring + (last ? 0 : SID) * 2 * RING);
     int rin = ring_row(-2 * LAG - 1 + kq) * XP;          // sums: fragment row 2p - 1 + kq of ring SID - 1
-    int ror = ring_row(-2 * LAG - (kDefer ? 2 : 0) + (kq >> 1)) * XP;   // epilogue: row 2pe + (kq >> 1)
-    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    int ror = ring_row(-2 * LAG + (kq >> 1)) * XP;       // epilogue: row 2p + (kq >> 1)
     auto epilogue = [&](auto chk, int pe, int q, f32x4 v) {
       constexpr bool CHK = decltype(chk)::value;
       const int j = 16 * q + i;
@@ -1175,7 +1157,7 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8
         }
       }
     };
-    auto tile = [&](auto chk, int q, int p, f32x4& accp) {
+    auto tile = [&](auto chk, int q, int p) {
       constexpr bool CHK = decltype(chk)::value;
       const bool sums = !CHK || (p >= 0 && p < npairs);     // wave-uniform
       typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -1194,9 +1176,8 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8
           for (int g = 0; g < 3; g++) { fh[g] = src[g]; fl[g] = src[RING + g]; }
         }
       }
-      if (kDefer && (!CHK || (p >= 1 && p <= npairs + 1))) epilogue(chk, p - 1, q, accp);
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
       if (sums) {
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
         if (SID == 0) {
 #pragma unroll
           for (int g = 0; g < 3; g++) {
@@ -1211,9 +1192,8 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g], fh[g], acc, 0, 0, 0);
           }
         }
-        accp = acc;
       }
-      if (!kDefer && (!CHK || (p >= 0 && p <= npairs))) epilogue(chk, p, q, accp);
+      if (!CHK || (p >= 0 && p <= npairs)) epilogue(chk, p, q, acc);
     };
 #define MSF_SS_STEP(chk_, q_, n_)                                                                 \
   {                                                                                               \
@@ -1222,8 +1202,8 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8
       MSF_SS_COMMIT(q_, n_)                                                                       \
       MSF_SS_ISSUE(q_, (n_) + kQDepth)                                                            \
     }                                                                                             \
-    tile(chk_, ws, (n_) - LAG, acc0);                                                             \
-    if (two) tile(chk_, ws + wps, (n_) - LAG, acc1);                                              \
+    tile(chk_, ws, (n_) - LAG);                                                                   \
+    if (two) tile(chk_, ws + wps, (n_) - LAG);                                                    \
     rin += 2 * XP; rin = rin >= RWRAP ? rin - RWRAP : rin;                                        \
     ror += 2 * XP; ror = ror >= RWRAP ? ror - RWRAP : ror;                                        \
   }
