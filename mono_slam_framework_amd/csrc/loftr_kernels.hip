@@ -3058,12 +3058,21 @@ __device__ __forceinline__ f32x4 mfma3x(bf16x8 wh, bf16x8 wl, bf16x8 xh, bf16x8 
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, c, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(64 * kKvWaves) void k_attn_kv_x(const float* __restrict__ src, long long seq_stride, BlockW w,
-                                                             float* __restrict__ kv /*[n][1056]: KV in PD order | Ksum*/) {
+// r05: a launch may carry TWO independent encoder blocks (the two self-attention blocks of a layer pair: feat0 <- feat0 and
+// feat1 <- feat1): workgroups [0, n_first) work on (src, w, kv), the rest on (src2, w2, kv2); n_first = gridDim.x: one block.
+__global__ __launch_bounds__(64 * kKvWaves) void k_attn_kv_x(const float* __restrict__ src_a, long long seq_stride, BlockW w_a,
+                                                             float* __restrict__ kv_a /*[n][1056]: KV in PD order | Ksum*/,
+                                                             int n_first, const float* __restrict__ src_b, BlockW w_b,
+                                                             float* __restrict__ kv_b) {
   __shared__ bf16x8 sWk[2 * 2 * 64], sWv[2 * 2 * 64];           // fragments [cout tile][hi | lo][lane]
   __shared__ float red[kKvWaves][DM * DM + DM];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tl = lane & 15, g = lane >> 4;
-  const float* s = src + (long long)blockIdx.x * seq_stride;
+  const bool second = (int)blockIdx.x >= n_first;                // workgroup-uniform
+  const int seq_i = second ? (int)blockIdx.x - n_first : (int)blockIdx.x;
+  const float* src = second ? src_b : src_a;
+  float* kv = second ? kv_b : kv_a;
+  const BlockW w = second ? w_b : w_a;
+  const float* s = src + (long long)seq_i * seq_stride;
   constexpr int NT16 = NTOK / 16;                                // 75 token tiles: 37 pairs + one single
   // (the first pair goes out together with the weight loads below)
   // the token rows of the next pair of tiles are requested before the current pair is processed (a sequence is walked
@@ -3156,7 +3165,7 @@ __global__ __launch_bounds__(64 * kKvWaves) void k_attn_kv_x(const float* __rest
     red[0][i] = t;
   }
   __syncthreads();
-  float* o = kv + (long long)blockIdx.x * (DM * DM + DM);
+  float* o = kv + (long long)seq_i * (DM * DM + DM);
   for (int i = tid; i < DM * DM; i += 64 * kKvWaves) {     // KV as the A operand of msg = KV^T Q, PD slot order over d
     const int ln = i & 63, sl = (i >> 6) & 7, me = i >> 9;
     const int d = 16 * (sl >> 2) + 4 * (ln >> 4) + (sl & 3), e = 16 * me + (ln & 15);
@@ -3165,10 +3174,19 @@ __global__ __launch_bounds__(64 * kKvWaves) void k_attn_kv_x(const float* __rest
   if (tid < DM) o[DM * DM + tid] = red[0][DM * DM + tid];
 }
 
-__global__ __launch_bounds__(256) void k_attn_update_x(const float* __restrict__ xsrc, long long x_stride,
-                                                       const float* __restrict__ kv, BlockW w, float* __restrict__ dst,
+// (r05: as k_attn_kv_x, a launch may carry two independent blocks: workgroups [0, wg_first) take the first argument set)
+__global__ __launch_bounds__(256) void k_attn_update_x(const float* __restrict__ xsrc_a, long long x_stride,
+                                                       const float* __restrict__ kv_a, BlockW w_a, float* __restrict__ dst_a,
                                                        long long d_stride, int n_items, int items_per_wg,
-                                                       float* __restrict__ fs_out, __bf16* __restrict__ pl_out) {
+                                                       float* __restrict__ fs_out, __bf16* __restrict__ pl_out, int wg_first,
+                                                       const float* __restrict__ xsrc_b, const float* __restrict__ kv_b,
+                                                       BlockW w_b, float* __restrict__ dst_b) {
+  const bool second = (int)blockIdx.x >= wg_first;               // workgroup-uniform
+  const int wg_i = second ? (int)blockIdx.x - wg_first : (int)blockIdx.x;
+  const float* xsrc = second ? xsrc_b : xsrc_a;
+  const float* kv = second ? kv_b : kv_a;
+  float* dst = second ? dst_b : dst_a;
+  const BlockW w = second ? w_b : w_a;
   // fragments: [mtile][K group][hi | lo][lane]
   __shared__ bf16x8 sWq[2 * 2 * 64], sKV[2 * 2 * 64], sWm[2 * 2 * 64], sW0[4 * 2 * 2 * 64], sW1[2 * 2 * 2 * 64];
   __shared__ float sLN[4 * DM], sKs[DM];
@@ -3187,7 +3205,7 @@ __global__ __launch_bounds__(256) void k_attn_update_x(const float* __restrict__
     sLN[tid] = w.n1w[tid]; sLN[DM + tid] = w.n1b[tid]; sLN[2 * DM + tid] = w.n2w[tid]; sLN[3 * DM + tid] = w.n2b[tid];
   }
   constexpr int kUpdBlocks = (NTOK / 16 + 4 * kUpdTilesPerWave - 1) / (4 * kUpdTilesPerWave);
-  const int item_lo = blockIdx.x * items_per_wg, item_hi = min(item_lo + items_per_wg, n_items);
+  const int item_lo = wg_i * items_per_wg, item_hi = min(item_lo + items_per_wg, n_items);
   int cur_seq = -1;
   for (int item = item_lo; item < item_hi; item++) {
   const int seq = item / kUpdBlocks, xblk = item - seq * kUpdBlocks;
@@ -4039,6 +4057,7 @@ struct LoftrPipeline::Impl {
   float* cpart = nullptr;    // [max_pairs][25][1200] column-sum partials
   float* rpart = nullptr;    // [max_pairs][3][1200] row-sum partials (one per third of the columns)
   uint32_t* sim_redo = nullptr;   // [max_pairs] pairs whose single-pass sums left the f32 range
+  bool attn_pair = true;     // MSF_LOFTR_ATTN_PAIR=0: one launch per encoder block (tests compare: identical results)
   bool sim_single = true;    // MSF_LOFTR_SIM_SINGLE=0: the two running-maximum passes always
   bool sim_force_redo = false;    // MSF_LOFTR_SIM_FORCE_REDO=1 (tests): every pair takes the fallback
   bool dense_head = false;
@@ -4127,6 +4146,7 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
   {
     if (const char* d = getenv("MSF_LOFTR_DENSE_HEAD")) P.dense_head = atoi(d) != 0;   // tests: force the dense head
     if (const char* d = getenv("MSF_LOFTR_SIM_SINGLE")) P.sim_single = atoi(d) != 0;
+    if (const char* d = getenv("MSF_LOFTR_ATTN_PAIR")) P.attn_pair = atoi(d) != 0;
     if (const char* d = getenv("MSF_LOFTR_SIM_FORCE_REDO")) P.sim_force_redo = atoi(d) != 0;
     if (const char* d = getenv("MSF_LOFTR_UNFUSED")) P.fuse_blocks = atoi(d) == 0;
     P.split_bf16 = !f32_convs;
@@ -4450,7 +4470,7 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
     LF_TRY(dalloc(&m, (size_t)3 * max_pairs * NTOK * DM));   // 2 x 3 bf16 planes = 3 floats per feature
     P.fsp = reinterpret_cast<__bf16*>(m);
   }
-  LF_TRY(dalloc(&P.kv, (size_t)max_pairs * (DM * DM + DM)));
+  LF_TRY(dalloc(&P.kv, (size_t)2 * max_pairs * (DM * DM + DM)));     // two halves: a launch may carry two encoder blocks
   LF_TRY(dalloc(&P.rstats, (size_t)max_pairs * 2 * NTOK));
   LF_TRY(dalloc(&P.cstats, (size_t)max_pairs * 2 * NTOK));
   {
@@ -4848,18 +4868,27 @@ hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf
       {f0, f0, t0}, {f1, f1, t1}, {t0, t1, f0}, {t1, f0, f1}, {f0, f0, t0}, {f1, f1, t1}, {t0, t1, f0}, {t1, f0, f1}};
   const int upd_blocks = (NTOK / 16 + 4 * kUpdTilesPerWave - 1) / (4 * kUpdTilesPerWave);
   for (int bi = 0; bi < 8; bi++) {
-    if (P.split_bf16) hipLaunchKernelGGL(k_attn_kv_x, dim3(n), dim3(64 * kKvWaves), 0, st, seq[bi].s, ts, P.blk[bi], P.kv);
-    else hipLaunchKernelGGL(k_attn_kv, dim3(n), dim3(64 * kKvWaves), 0, st, seq[bi].s, ts, P.blk[bi], P.kv);
     if (P.split_bf16) {
+      // the two self-attention blocks of a layer pair (0 | 1, 4 | 5) read and write disjoint sequences: ONE launch of each
+      // kernel for both (12 launches per call instead of 16; the second block's KV goes to the second half of P.kv)
+      const bool pairup = (bi & 3) == 0 && P.attn_pair;
+      const int bj = pairup ? bi + 1 : bi;
+      float* kv2 = P.kv + (long long)P.max_pairs * (DM * DM + DM);
+      hipLaunchKernelGGL(k_attn_kv_x, dim3(pairup ? 2 * n : n), dim3(64 * kKvWaves), 0, st, seq[bi].s, ts, P.blk[bi], P.kv, n,
+                         seq[bj].s, P.blk[bj], kv2);
       const int n_items = n * upd_blocks;
       const int per_wg = 1;     // one item per workgroup (runs of 3 / 5 items with the weights staged once: 0.52 / 0.54 vs 0.49 ms)
+      const int wgs = (n_items + per_wg - 1) / per_wg;
       // blocks 6 and 7 write the final f0 and f1: they also write the head's scaled features and bf16 planes
       float* fs_o = bi == 6 ? P.fsc : bi == 7 ? P.fsc + (long long)P.max_pairs * ts : nullptr;
       __bf16* pl_o = bi == 6 ? P.fsp : bi == 7 ? P.fsp + (long long)P.max_pairs * 3 * ts : nullptr;
-      hipLaunchKernelGGL(k_attn_update_x, dim3((n_items + per_wg - 1) / per_wg), dim3(256), 0, st, seq[bi].x, ts, P.kv, P.blk[bi],
-                         seq[bi].o, ts, n_items, per_wg, fs_o, pl_o);
+      hipLaunchKernelGGL(k_attn_update_x, dim3(pairup ? 2 * wgs : wgs), dim3(256), 0, st, seq[bi].x, ts, P.kv, P.blk[bi],
+                         seq[bi].o, ts, n_items, per_wg, fs_o, pl_o, wgs, seq[bj].x, kv2, P.blk[bj], seq[bj].o);
+      if (pairup) bi++;
+      continue;
     }
-    else hipLaunchKernelGGL(k_attn_update, dim3(upd_blocks, n), dim3(256), 0, st, seq[bi].x, ts, P.kv, P.blk[bi], seq[bi].o, ts);
+    hipLaunchKernelGGL(k_attn_kv, dim3(n), dim3(64 * kKvWaves), 0, st, seq[bi].s, ts, P.blk[bi], P.kv);
+    hipLaunchKernelGGL(k_attn_update, dim3(upd_blocks, n), dim3(256), 0, st, seq[bi].x, ts, P.kv, P.blk[bi], seq[bi].o, ts);
   }
   if (ev) hipEventRecord(ev[2], st);
   // ---- matching head on (f0, f1)

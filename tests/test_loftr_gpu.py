@@ -337,3 +337,14 @@ def test_single_pass_statistics_equal_the_running_maximum_passes(monkeypatch):
         differing = sum(1 for k in range(n) if len(l1[k]) != len(l2[k]) or not np.array_equal(l1[k], l2[k]))
         assert differing <= 1, differing
     assert total > 3000
+
+
+def test_paired_attention_launches_equal_one_launch_per_block():
+    """r05: the two self-attention blocks of a layer pair (feat0 <- feat0, feat1 <- feat1) run as ONE launch of each
+    attention kernel (12 launches per call instead of 16).  Same arithmetic, other grid: confidences, features and the
+    match list are bit-identical to one launch per block (MSF_LOFTR_ATTN_PAIR=0)."""
+    outs = [_run_child({"MSF_LOFTR_ATTN_PAIR": u}) for u in ("1", "0")]
+    assert len(outs[0]["m"]) > 20
+    np.testing.assert_array_equal(outs[0]["m"], outs[1]["m"])
+    np.testing.assert_array_equal(outs[0]["feat"].view(np.uint32), outs[1]["feat"].view(np.uint32))
+    np.testing.assert_array_equal(outs[0]["conf"].view(np.uint32), outs[1]["conf"].view(np.uint32))
