@@ -87,10 +87,14 @@ typedef struct msf_config {
   int32_t image_height;
   int32_t max_batch_pairs;   /* P: device workspace is sized for this many pairs per call.  ORB keeps the per-CALL arrays
                                 (pyramid, FAST candidate lists, stage-1 lists, walker state) once per frame of a call --
-                                2 P rows of about 4.8 MB at 1280x720 -- and key points + descriptors (128 KB) per feature
+                                2 P rows of about 3.5 MB at 1280x720 -- and key points + descriptors (128 KB) per feature
                                 slot, of which there are 4 P + 64 (2 P caller-visible, 2 P scratch of the stateless calls,
-                                64 of the frame cache): about 10.4 GB at P = 1024 (round 3 kept everything per slot:
-                                20 GB); LoFTR about 20 MB of activations per pair of a backbone chunk (<= 256) */
+                                64 of the frame cache): 7.8 GB at P = 1024 (measured, tests/test_orb_gpu.py; round 4: 10.4,
+                                round 3: 20).  A level's candidate list holds w h / 64 entries (what the output-sensitive
+                                FAST pass lists); a level that needs more -- a dense second pass over a frame of noise --
+                                takes a full-size list from a pool shared by the call, and a call that exhausts the pool
+                                returns MSF_ERR_CAPACITY for the frames concerned (n_out = -1), never a short list.
+                                LoFTR: about 20 MB of activations per pair of a backbone chunk (<= 256) */
   uint32_t flags;
   const char* weights_path;  /* LoFTR: the model file, as DNNFeatureMatcher's model_file_path (dnnfeaturematcher.cpp:11-21):
                                 the reference's model/LoFTR_teacher.onnx is read directly (its initializers and constants);

@@ -292,6 +292,28 @@ struct FastSmem {
   uint32_t nbd, lcount, gbase;   // nbd: brighter count (low 16) | darker count (high 16)
 };
 
+// ---- where the candidate list of (frame, level) lives (r05): cmap[slot * 8 + level] = (first entry, capacity) in the
+// candidate arrays -- the level's primary list inside the frame's work row, or a block of the pool (orb_pipeline.h)
+__global__ __launch_bounds__(256) void k_cand_reset(OrbGeometry g, uint2* cmap_rows, uint32_t* pool_cnt, int n_frames, int dense) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) *pool_cnt = 0u;
+  if (i >= n_frames * kOrbLevels) return;
+  const int row = i / kOrbLevels, l = i - row * kOrbLevels;
+  if (l >= g.nlevels) { cmap_rows[i] = make_uint2(0u, 0u); return; }
+  const OrbLevelInfo& L = g.lv[l];
+  // a dense call (every level at fastThreshold): frame `row` gets a full-capacity region of the pool (host-checked: it fits)
+  cmap_rows[i] = dense ? make_uint2((uint32_t)(g.pool_base + (long long)row * g.cand_total + L.cand_off), (uint32_t)L.cand_cap)
+                       : make_uint2((uint32_t)((long long)row * g.prim_total + L.prim_off), (uint32_t)L.prim_cap);
+}
+// one lane: (slot, level) moves to a pool region of its full capacity (before its dense pass); false: the pool is exhausted
+__device__ __forceinline__ bool cand_take_block(const OrbGeometry& g, uint2* cmap, uint32_t* pool_cnt, int idx, int l) {
+  const uint32_t cap = (uint32_t)g.lv[l].cand_cap;              // (a multiple of 16: regions stay 16-byte aligned)
+  const uint32_t at = atomicAdd(pool_cnt, cap);
+  if (at > g.pool_entries || cap > g.pool_entries - at) return false;
+  cmap[idx] = make_uint2((uint32_t)(g.pool_base + (long long)at), cap);
+  return true;
+}
+
 // One tile of level l of frame fi with score threshold tau (even, >= kFastT): emits exactly the strict 3x3 maxima whose
 // score is >= tau.  With tau = kFastT that is FAST_t<16> + NMS; with a larger tau it is the subset retainBest(2N) can
 // still keep: a pixel whose score is below tau gets 0 in the score tile, which is what a maximum with score >= tau
@@ -299,7 +321,7 @@ struct FastSmem {
 // All threads of the workgroup must call this together; the LDS block may be reused after the call returns.
 __device__ __forceinline__ void fast_tile(const OrbGeometry& g, const FrameSrc& src, const uint8_t* pyr, int fi, int l,
                                           int t, int tau, uint32_t* cand_cnt, uint32_t* cand_key, uint8_t* cand_sc,
-                                          FastSmem& S_) {
+                                          const uint2* cmap, FastSmem& S_) {
   uint8_t* px = S_.px;
   uint8_t* sc = S_.sc;
   uint16_t* list1 = S_.list1;
@@ -450,10 +472,11 @@ __device__ __forceinline__ void fast_tile(const OrbGeometry& g, const FrameSrc& 
       __syncthreads();
       const uint32_t base = S_.gbase;
       // structure of arrays: the retainBest threshold pass reads every score (1 byte) but only a few hundred keys
-      uint32_t* outk = cand_key + (long long)slot * g.cand_total + L.cand_off;
-      uint8_t* outs = cand_sc + (long long)slot * g.cand_total + L.cand_off;
+      const uint2 cm = cmap[slot * kOrbLevels + l];
+      uint32_t* outk = cand_key + cm.x;
+      uint8_t* outs = cand_sc + cm.x;
       for (uint32_t i = tid; i < n; i += kFastThreads)
-        if (base + i < (uint32_t)L.cand_cap) {
+        if (base + i < cm.y) {
           const uint2 e = llist[i];
           outk[base + i] = e.x;
           outs[base + i] = (uint8_t)e.y;
@@ -464,7 +487,8 @@ __device__ __forceinline__ void fast_tile(const OrbGeometry& g, const FrameSrc& 
 
 // K3+K4 over every tile of every level of every frame of the batch at fastThreshold (MSF_FLAG_FAST_DENSE).
 __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
-                                                       uint32_t* cand_cnt, uint32_t* cand_key, uint8_t* cand_sc) {
+                                                       uint32_t* cand_cnt, uint32_t* cand_key, uint8_t* cand_sc,
+                                                       const uint2* cmap) {
   __shared__ FastSmem sm;
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so workgroup b
   // takes tile start(b % 8) + b / 8 of the flattened (frame, tile) list: one XCD walks one contiguous run of tiles and
@@ -480,7 +504,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(OrbGeometry g, FrameSrc s
 #pragma unroll
   for (int i = 1; i < kOrbLevels; i++)
     if (i < g.nlevels && bt >= g.lv[i].tile_base) l = i;
-  fast_tile(g, src, pyr, fi, l, bt - g.lv[l].tile_base, kFastT, cand_cnt, cand_key, cand_sc, sm);
+  fast_tile(g, src, pyr, fi, l, bt - g.lv[l].tile_base, kFastT, cand_cnt, cand_key, cand_sc, cmap, sm);
 }
 
 // ------------------------------------------------------------------ K2+K3+K4, streaming form: one wave walks a column strip
@@ -623,8 +647,9 @@ __device__ __forceinline__ void unit_stall(uint32_t* status, int slot, uint32_t*
 template <bool RESIZE>
 __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g, const FrameSrc& src, uint8_t* pyr,
                                            const uint32_t* __restrict__ tab, uint32_t* qstat, uint32_t* cand_cnt,
-                                           uint32_t* cand_key, uint8_t* cand_sc, uint32_t* status, uint32_t* abort_word,
-                                           int margin_pct, int dyn, int chain, const int l, const int fi, const int ts) {
+                                           uint32_t* cand_key, uint8_t* cand_sc, const uint2* cmap, uint32_t* status,
+                                           uint32_t* abort_word, int margin_pct, int dyn, int chain, const int l, const int fi,
+                                           const int ts) {
   const int lane = threadIdx.x;
   const bool quarter = (ts & 3) == 0;
   const OrbLevelInfo L = g.lv[l];
@@ -742,9 +767,10 @@ __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g,
   const uint32_t lerp_bright = 0x01010101u * (uint32_t)(128 - tv / 2);
   const uint32_t lerp_not_dark = 0x01010101u * (uint32_t)(255 - (254 - tv) / 2);
   uint32_t* const out_cnt = cand_cnt + idx;
-  uint32_t* const outk = cand_key + (long long)slot * g.cand_total + L.cand_off;
-  uint8_t* const outs = cand_sc + (long long)slot * g.cand_total + L.cand_off;
-  const uint32_t out_cap = (uint32_t)L.cand_cap;
+  const uint2 cm = cmap[idx];                     // (read behind the wait for the level's threshold: tau_unit may have moved the list)
+  uint32_t* const outk = cand_key + cm.x;
+  uint8_t* const outs = cand_sc + cm.x;
+  const uint32_t out_cap = cm.y;
   uint32_t* pxw = reinterpret_cast<uint32_t*>(sm.px);
   uint32_t* scw = reinterpret_cast<uint32_t*>(sm.sc);
   uint8_t* pxb = sm.px;
@@ -1382,7 +1408,8 @@ __device__ __forceinline__ void tau_unit(TauSmem& T, const OrbGeometry& g, const
 // level l + 1.  One wave per workgroup, one unit per workgroup.
 __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_t* pyr, const uint32_t* __restrict__ tab,
                                              uint32_t* tau, uint32_t* tau_first, uint32_t* qstat, uint32_t* cand_cnt,
-                                             uint32_t* cand_key, uint8_t* cand_sc, uint32_t* redo_cnt, uint32_t* redo_list,
+                                             uint32_t* cand_key, uint8_t* cand_sc, const uint2* cmap,
+                                             uint32_t* redo_cnt, uint32_t* redo_list,
                                              uint32_t* status, uint32_t* abort_word, int l_lo, int l_hi, int n_frames,
                                              int margin_pct, int dyn, int force_tau, int predict_pct, int chain,
                                              int resize_mask, int test_stall_frame) {
@@ -1420,9 +1447,9 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
     ts = 4 * (ip / 3) + ip % 3 + 1;
   }
   if ((resize_mask >> l) & 1)
-    walk_strip<true>(sm, g, src, pyr, tab, qstat, cand_cnt, cand_key, cand_sc, status, abort_word, margin_pct, dyn, chain, l, fi, ts);
+    walk_strip<true>(sm, g, src, pyr, tab, qstat, cand_cnt, cand_key, cand_sc, cmap, status, abort_word, margin_pct, dyn, chain, l, fi, ts);
   else
-    walk_strip<false>(sm, g, src, pyr, tab, qstat, cand_cnt, cand_key, cand_sc, status, abort_word, margin_pct, dyn, chain, l, fi, ts);
+    walk_strip<false>(sm, g, src, pyr, tab, qstat, cand_cnt, cand_key, cand_sc, cmap, status, abort_word, margin_pct, dyn, chain, l, fi, ts);
 }
 
 // After the walker: tau[idx] is the largest threshold any strip of the (frame, level) ran at, and every strict maximum
@@ -1430,16 +1457,20 @@ __global__ __launch_bounds__(64) void k_walk(OrbGeometry g, FrameSrc src, uint8_
 // reach it, retainBest(2N) would cut below what was searched completely: the level is queued for the dense pass (its
 // candidate list restarts from empty).  One wave per (frame, level).
 __global__ __launch_bounds__(64) void k_fast_check(OrbGeometry g, int slot0, int n_frames, uint32_t* tau, uint32_t* tau_first,
-                                                   uint32_t* cand_cnt, const uint8_t* cand_sc, uint32_t* redo_cnt,
-                                                   uint32_t* redo_list, const uint32_t* qstat) {
+                                                   uint32_t* cand_cnt, const uint8_t* cand_sc, const uint2* cmap,
+                                                   uint32_t* redo_cnt, uint32_t* redo_list, const uint32_t* qstat) {
   const int fi = blockIdx.x / kOrbLevels, l = blockIdx.x - fi * kOrbLevels, lane = threadIdx.x;
   if (fi >= n_frames || l >= g.nlevels) return;
   const int idx = (slot0 + fi) * kOrbLevels + l;
   if (tau[idx] <= (uint32_t)kFastT) return;
   const uint32_t T = max(tau[idx], qstat[(size_t)idx * kQStat + kQTau]);   // the largest threshold any strip ran at
   const OrbLevelInfo L = g.lv[l];
-  const uint32_t n = min(cand_cnt[idx], (uint32_t)L.cand_cap);   // an overflowed list is flagged by k_thr_harris
-  const uint8_t* scs = cand_sc + (long long)(slot0 + fi) * g.cand_total + L.cand_off;
+  const uint2 cm = cmap[idx];
+  // a primary list that overflowed is incomplete: the level takes the dense pass (with a full-capacity block) like one
+  // that holds too few strong corners
+  const bool over = cand_cnt[idx] > cm.y;
+  const uint32_t n = min(cand_cnt[idx], cm.y);
+  const uint8_t* scs = cand_sc + cm.x;
   uint32_t found = 0;
   for (uint32_t i = 16u * lane; i < n; i += 16u * 64u) {
     const uint4 v = *reinterpret_cast<const uint4*>(scs + i);
@@ -1451,7 +1482,7 @@ __global__ __launch_bounds__(64) void k_fast_check(OrbGeometry g, int slot0, int
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) found += __shfl_xor(found, o);
   if (lane == 0) {
-    if (found < 2u * (uint32_t)L.quota) {
+    if (over || found < 2u * (uint32_t)L.quota) {
       tau[idx] = kFastT;
       cand_cnt[idx] = 0;
       redo_list[atomicAdd(redo_cnt, 1u)] = (uint32_t)(fi * kOrbLevels + l);
@@ -1467,7 +1498,8 @@ __global__ __launch_bounds__(64) void k_fast_check(OrbGeometry g, int slot0, int
 __global__ __launch_bounds__(kFastThreads) void k_fast_redo(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
                                                             const uint32_t* __restrict__ redo_cnt,
                                                             const uint32_t* __restrict__ redo_list, int max_tiles,
-                                                            uint32_t* cand_cnt, uint32_t* cand_key, uint8_t* cand_sc) {
+                                                            uint32_t* cand_cnt, uint32_t* cand_key, uint8_t* cand_sc,
+                                                            const uint2* cmap) {
   __shared__ FastSmem sm;
   const uint32_t n = *redo_cnt;
   const unsigned long long units = (unsigned long long)n * (unsigned)max_tiles;
@@ -1480,8 +1512,28 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_redo(OrbGeometry g, Frame
     const int t = (int)(u % (unsigned)max_tiles);
     const int fi = (int)(item / kOrbLevels), l = (int)(item % kOrbLevels);
     if (t >= g.lv[l].tiles_x * g.lv[l].tiles_y) continue;   // uniform
-    fast_tile(g, src, pyr, fi, l, t, kFastT, cand_cnt, cand_key, cand_sc, sm);
+    fast_tile(g, src, pyr, fi, l, t, kFastT, cand_cnt, cand_key, cand_sc, cmap, sm);
     __syncthreads();
+  }
+}
+
+// After the dense second pass: a redone level whose candidates did not fit its primary list (a frame of noise: tens of
+// thousands of maxima; a smooth frame's dense list is short) moves to a pool region of full capacity and is queued once
+// more.  One thread per entry of the first queue.  Pool exhausted: the frame is flagged (MSF_ERR_CAPACITY), never a short list.
+__global__ __launch_bounds__(256) void k_redo_overflow(OrbGeometry g, int slot0, uint32_t* cand_cnt, uint2* cmap,
+                                                       uint32_t* pool_cnt, uint32_t* status, const uint32_t* redo_cnt,
+                                                       const uint32_t* redo_list, uint32_t* redo2_cnt, uint32_t* redo2_list) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= *redo_cnt) return;
+  const uint32_t item = redo_list[i];
+  const int fi = (int)(item / kOrbLevels), l = (int)(item % kOrbLevels);
+  const int idx = (slot0 + fi) * kOrbLevels + l;
+  if (cand_cnt[idx] <= cmap[idx].y) return;
+  if ((uint32_t)g.lv[l].cand_cap > cmap[idx].y && cand_take_block(g, cmap, pool_cnt, idx, l)) {
+    cand_cnt[idx] = 0;
+    redo2_list[atomicAdd(redo2_cnt, 1u)] = item;
+  } else {
+    atomicOr(&status[slot0 + fi], kStatusOverflow);
   }
 }
 
@@ -1538,7 +1590,7 @@ __device__ __forceinline__ float harris_at(const uint8_t* img, int step, int x0,
 
 __global__ __launch_bounds__(256) void k_thr_harris(OrbGeometry g, FrameSrc src, const uint8_t* pyr,
                                                     const uint32_t* cand_cnt, const uint32_t* cand_key,
-                                                    const uint8_t* cand_sc,
+                                                    const uint8_t* cand_sc, const uint2* cmap,
                                                     uint32_t* s1_cnt, uint4* s1, uint32_t* status, int do_harris) {
   __shared__ uint32_t hist[256];
   __shared__ uint32_t thr_s, lcount;
@@ -1550,12 +1602,13 @@ __global__ __launch_bounds__(256) void k_thr_harris(OrbGeometry g, FrameSrc src,
   if (l >= g.nlevels) return;
   const OrbLevelInfo L = g.lv[l];
   uint32_t n = cand_cnt[slot * kOrbLevels + l];
-  if (n > (uint32_t)L.cand_cap) {
+  const uint2 cm = cmap[slot * kOrbLevels + l];
+  if (n > cm.y) {
     if (tid == 0) atomicOr(&status[slot], kStatusOverflow);
-    n = L.cand_cap;
+    n = cm.y;
   }
-  const uint32_t* keys = cand_key + (long long)slot * g.cand_total + L.cand_off;
-  const uint8_t* scs = cand_sc + (long long)slot * g.cand_total + L.cand_off;   // 16-byte aligned (cand_off % 16 == 0)
+  const uint32_t* keys = cand_key + cm.x;
+  const uint8_t* scs = cand_sc + cm.x;   // 16-byte aligned (every region starts at a multiple of 16 entries)
   uint4* out = s1 + (long long)slot * g.s1_total + L.s1_off;
   for (uint32_t b = tid; b < 256u; b += nt) hist[b] = 0;
   if (tid == 0) lcount = 0;
@@ -2232,9 +2285,9 @@ void OrbPipeline::destroy() {
   hipFree(d_tau_); hipFree(d_redo_); hipFree(d_qstat_); hipFree(d_walk_abort_);
   if (h_walk_abort_) hipHostFree(h_walk_abort_);
   d_tau_ = nullptr; d_redo_ = nullptr; d_qstat_ = nullptr; d_walk_abort_ = nullptr; h_walk_abort_ = nullptr;
-  hipFree(d_pyr_); hipFree(d_tab_); hipFree(d_cand_cnt_); hipFree(d_cand_); hipFree(d_cand_sc_); hipFree(d_qres_); hipFree(d_done_); hipFree(d_s1_cnt_); hipFree(d_s1_);
+  hipFree(d_pyr_); hipFree(d_tab_); hipFree(d_cand_cnt_); hipFree(d_cand_); hipFree(d_cand_sc_); hipFree(d_cmap_); hipFree(d_pool_cnt_); hipFree(d_qres_); hipFree(d_done_); hipFree(d_s1_cnt_); hipFree(d_s1_);
   hipFree(d_kp_); hipFree(d_desc_); hipFree(d_kp_cnt_); hipFree(d_status_);
-  d_pyr_ = nullptr; d_tab_ = nullptr; d_cand_cnt_ = nullptr; d_cand_ = nullptr; d_cand_sc_ = nullptr; d_qres_ = nullptr; d_done_ = nullptr; d_s1_cnt_ = nullptr;
+  d_pyr_ = nullptr; d_tab_ = nullptr; d_cand_cnt_ = nullptr; d_cand_ = nullptr; d_cand_sc_ = nullptr; d_cmap_ = nullptr; d_pool_cnt_ = nullptr; d_qres_ = nullptr; d_done_ = nullptr; d_s1_cnt_ = nullptr;
   d_s1_ = nullptr; d_kp_ = nullptr; d_desc_ = nullptr; d_kp_cnt_ = nullptr; d_status_ = nullptr;
   if (ev_ok_) {
     for (auto& set : evr_)
@@ -2328,7 +2381,7 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     for (int v = 0; v < 16; v++) g.umax[v] = umax[v];
   }
   long long pix = 0;
-  int cand = 0, tiles = 0, strips = 0, tab = 0, s1 = 0;
+  int cand = 0, prim = 0, tiles = 0, strips = 0, tab = 0, s1 = 0;
   g.max_level_tiles = 0;
   for (int l = 0; l < g.nlevels; l++) {
     OrbLevelInfo& L = g.lv[l];
@@ -2350,6 +2403,18 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     L.cand_cap = cap;
     L.cand_off = cand;
     cand += cap;
+    // the output-sensitive pass lists the maxima at or above the level's threshold -- about a thousand at 1280 x 720
+    // against ~20 000 maxima in all --: the primary list is an eighth of the full one (a list that overflows all the same
+    // sends its level to the dense pass, k_fast_check)
+    int pcap = (int)((long long)L.w * L.h / 64);
+    if (pcap < 4096) pcap = 4096;
+    pcap = (pcap + 15) & ~15;
+    // small levels keep their full capacity (little memory, and small levels are the ones that take the dense pass:
+    // their thresholds rest on few corners): only lists above 16 K entries are cut
+    if (pcap > cap || cap <= 16384) pcap = cap;
+    L.prim_cap = pcap;
+    L.prim_off = prim;
+    prim += pcap;
     L.s1_off = s1;
     s1 += kS1Cap;
     // FAST tiles cover only the pixels runByImageBorder(31) can keep, [31, w-31) x [31, h-31) (17 % fewer tiles on
@@ -2401,6 +2466,7 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   }
   g.pyr_bytes = (pix + 255) & ~255ll;
   g.cand_total = cand;
+  g.prim_total = prim;
   g.s1_total = s1;
   g.total_tiles = tiles;
   g.total_strips = strips;
@@ -2471,11 +2537,35 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
   MSF_HIP_TRY(hipMalloc(&d_cand_cnt_, Wk * kOrbLevels * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMalloc(&d_tau_, 2 * Wk * kOrbLevels * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMemset(d_tau_, 0, 2 * Wk * kOrbLevels * sizeof(uint32_t)));
-  MSF_HIP_TRY(hipMalloc(&d_redo_, (1 + Wk * kOrbLevels) * sizeof(uint32_t)));
+  MSF_HIP_TRY(hipMalloc(&d_redo_, 2 * (1 + Wk * kOrbLevels) * sizeof(uint32_t)));   // two queues: dense pass, dense pass again from the pool
   MSF_HIP_TRY(hipMalloc(&d_qstat_, Wk * kOrbLevels * kQStat * sizeof(uint32_t)));
   MSF_HIP_TRY(hipMemset(d_qstat_, 0, Wk * kOrbLevels * kQStat * sizeof(uint32_t)));
-  MSF_HIP_TRY(hipMalloc(&d_cand_, Wk * g.cand_total * sizeof(uint32_t)));
-  MSF_HIP_TRY(hipMalloc(&d_cand_sc_, Wk * g.cand_total));
+  {
+    // candidate arrays: a primary region per work row + the pool.  The pool serves (a) the (frame, level)s that take the
+    // dense second pass -- 0 to 8 of 2 048 in the measured batches; sized for an eighth of all of them at full capacity,
+    // at least 64 level-0 lists -- and (b) dense CALLS, whose frames lay their full-capacity regions over it: every row
+    // with MSF_FLAG_FAST_DENSE, at most stream_min_frames - 1 frames otherwise.
+    const long long dense_rows = force_tau_ == kFastT ? (long long)Wk : std::min<long long>((long long)Wk, std::max(stream_min_frames_ - 1, 0));
+    long long redo_entries = std::max<long long>((long long)Wk * g.cand_total / 8, 64ll * g.lv[0].cand_cap);
+    redo_entries = std::min<long long>(redo_entries, (long long)Wk * g.cand_total);
+    // (MSF_ORB_POOL_ENTRIES, tests: a pool too small for what a batch needs must end in MSF_ERR_CAPACITY, never in a
+    // short list; batches that force most levels through the dense pass ask for more)
+    if (const char* e = getenv("MSF_ORB_POOL_ENTRIES")) {
+      const long long v = atoll(e);
+      if (v >= 0) redo_entries = std::min<long long>(v, (long long)Wk * g.cand_total);
+    }
+    const long long pool_entries_ = std::max(std::max<long long>(redo_entries, 16), dense_rows * g.cand_total);
+    g.pool_base = (long long)Wk * g.prim_total;
+    const long long total = g.pool_base + pool_entries_;
+    if (total >= (1ll << 32)) return "ORB candidate arrays exceed 2^32 entries: reduce max_batch_pairs";
+    g.pool_entries = (unsigned)pool_entries_;
+    MSF_HIP_TRY(hipMalloc(&d_cand_, (size_t)total * sizeof(uint32_t)));
+    MSF_HIP_TRY(hipMalloc(&d_cand_sc_, (size_t)total));
+    MSF_HIP_TRY(hipMalloc(&d_cmap_, Wk * kOrbLevels * sizeof(uint2)));
+    MSF_HIP_TRY(hipMemset(d_cmap_, 0, Wk * kOrbLevels * sizeof(uint2)));
+    MSF_HIP_TRY(hipMalloc(&d_pool_cnt_, 16));
+    MSF_HIP_TRY(hipMemset(d_pool_cnt_, 0, 16));
+  }
   MSF_HIP_TRY(hipMalloc(&d_walk_abort_, 16));
   MSF_HIP_TRY(hipMemset(d_walk_abort_, 0, 16));
   MSF_HIP_TRY(hipHostMalloc(&h_walk_abort_, 16, hipHostMallocDefault));
@@ -2557,14 +2647,14 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
   const ptrdiff_t back = (ptrdiff_t)src.slot0;
   uint8_t* const d_pyr_ = this->d_pyr_ - back * g.pyr_bytes;
   uint32_t* const d_cand_cnt_ = this->d_cand_cnt_ - back * kOrbLevels;
-  uint32_t* const d_cand_ = this->d_cand_ - back * g.cand_total;
-  uint8_t* const d_cand_sc_ = this->d_cand_sc_ - back * g.cand_total;
+  uint2* const d_cmap_ = this->d_cmap_ - back * kOrbLevels;     // (its entries are absolute offsets into d_cand_ / d_cand_sc_)
   uint32_t* const d_qstat_ = this->d_qstat_ - back * kOrbLevels * kQStat;
   uint32_t* const d_s1_cnt_ = this->d_s1_cnt_ - back * kOrbLevels;
   uint4* const d_s1_ = this->d_s1_ - back * g.s1_total;
   if ((e = hipMemsetAsync(this->d_cand_cnt_, 0, (size_t)n * kOrbLevels * 4, st))) return e;
   if ((e = hipMemsetAsync(d_status_ + src.slot0, 0, (size_t)n * 4, st))) return e;
   if ((e = hipMemsetAsync(d_redo_, 0, 4, st))) return e;
+  if ((e = hipMemsetAsync(d_redo_ + 1 + (size_t)work_frames_ * kOrbLevels, 0, 4, st))) return e;
   if (evs) hipEventRecord(evs[0], st);
   uint32_t* tau = d_tau_ - back * kOrbLevels;
   uint32_t* tau_first = d_tau_ + (ptrdiff_t)work_frames_ * kOrbLevels - back * kOrbLevels;
@@ -2573,6 +2663,10 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
   // tile.  Such calls take k_resize + the dense kernel directly; the result is the same either way.
   const int force_tau = (force_tau_ == 0 && n < stream_min_frames_) ? kFastT : force_tau_;
   const bool dense = force_tau == kFastT;
+  // where each (frame, level)'s candidate list lives in this call (k_cand_reset): its primary list, or -- a dense call --
+  // the frame's full-capacity region in the pool
+  if (dense && (long long)n * g.cand_total > (long long)g.pool_entries) return hipErrorInvalidValue;   // (cannot happen: see init)
+  hipLaunchKernelGGL(k_cand_reset, dim3((n * kOrbLevels + 255) / 256), dim3(256), 0, st, g, this->d_cmap_, d_pool_cnt_, n, dense ? 1 : 0);
   const int dyn = (fast_two_part_ && force_tau == 0) ? 1 : 0;
   bool fused = fused_ && !dense && g.total_tiles > 0;
   for (int l = 1; l < g.nlevels; l++) fused = fused && g.lv[l].wk_fused != 0;
@@ -2600,7 +2694,7 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
     for (int l = l_lo; l <= l_hi; l++) per_frame += 1 + g.lv[l].wk_nx * g.lv[l].wk_ny;
     const long long wgs = 8ll * ((n + 7) / 8) * per_frame;
     hipLaunchKernelGGL(k_walk, dim3((unsigned)wgs), dim3(64), 0, st, g, src, d_pyr_, d_tab_, tau, tau_first, d_qstat_,
-                       d_cand_cnt_, d_cand_, d_cand_sc_, d_redo_, d_redo_ + 1, d_status_, d_walk_abort_, l_lo, l_hi, n,
+                       d_cand_cnt_, d_cand_, d_cand_sc_, d_cmap_, d_redo_, d_redo_ + 1, d_status_, d_walk_abort_, l_lo, l_hi, n,
                        tau2_margin_pct_, dyn, force_tau, predict_pct, chain, resize_mask, test_stall_frame_);
   };
   last_fused_ = fused;
@@ -2633,7 +2727,7 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
         hipLaunchKernelGGL(k_fill_u32, dim3((n * kOrbLevels + 255) / 256), dim3(256), 0, st, tau + (size_t)src.slot0 * kOrbLevels,
                            tau_first + (size_t)src.slot0 * kOrbLevels, (uint32_t)kFastT, n * kOrbLevels);
         hipLaunchKernelGGL(k_fast, dim3((unsigned)g.total_tiles * (unsigned)n), dim3(kFastThreads), 0, st, g, src, d_pyr_,
-                           d_cand_cnt_, d_cand_, d_cand_sc_);
+                           d_cand_cnt_, d_cand_, d_cand_sc_, d_cmap_);
       } else {
         // every level exists: FAST-only strips, every level's first threshold from its own sample
         launch_walk(0, g.nlevels - 1, 0, 0, 0);
@@ -2642,17 +2736,24 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
   }
   if (g.total_tiles > 0 && !dense) {
     hipLaunchKernelGGL(k_fast_check, dim3((unsigned)n * kOrbLevels), dim3(64), 0, st, g, src.slot0, n, tau, tau_first,
-                       d_cand_cnt_, d_cand_sc_, d_redo_, d_redo_ + 1, d_qstat_);
+                       d_cand_cnt_, d_cand_sc_, d_cmap_, d_redo_, d_redo_ + 1, d_qstat_);
     // fixed grid (a multiple of 8: see the XCD-contiguous unit order), sized to what the batch could need
     long long units = (long long)n * kOrbLevels * g.max_level_tiles;
     unsigned grid = (unsigned)(units < 2048 ? units : 2048);
     grid = (grid + 7u) & ~7u;
     hipLaunchKernelGGL(k_fast_redo, dim3(grid), dim3(kFastThreads), 0, st, g, src, d_pyr_, d_redo_, d_redo_ + 1,
-                       g.max_level_tiles, d_cand_cnt_, d_cand_, d_cand_sc_);
+                       g.max_level_tiles, d_cand_cnt_, d_cand_, d_cand_sc_, d_cmap_);
+    // a redone level that overflowed its primary list: once more, into a full-capacity region of the pool (both launches
+    // find an empty queue in nearly every call)
+    uint32_t* const redo2 = d_redo_ + 1 + (size_t)work_frames_ * kOrbLevels;
+    hipLaunchKernelGGL(k_redo_overflow, dim3((n * kOrbLevels + 255) / 256), dim3(256), 0, st, g, src.slot0, d_cand_cnt_, d_cmap_,
+                       d_pool_cnt_, d_status_, d_redo_, d_redo_ + 1, redo2, redo2 + 1);
+    hipLaunchKernelGGL(k_fast_redo, dim3(grid), dim3(kFastThreads), 0, st, g, src, d_pyr_, redo2, redo2 + 1,
+                       g.max_level_tiles, d_cand_cnt_, d_cand_, d_cand_sc_, d_cmap_);
   }
   if (evs) hipEventRecord(evs[2], st);
   hipLaunchKernelGGL(k_thr_harris, dim3(g.nlevels, n), dim3(dense ? 256 : 64), 0, st, g, src, d_pyr_,
-                     d_cand_cnt_, d_cand_, d_cand_sc_, d_s1_cnt_, d_s1_, d_status_, dense ? 1 : 0);
+                     d_cand_cnt_, d_cand_, d_cand_sc_, d_cmap_, d_s1_cnt_, d_s1_, d_status_, dense ? 1 : 0);
   if (!dense) {
     HarrisUnits hw;
     int nu = 0;
@@ -2797,13 +2898,15 @@ int OrbPipeline::debug_get(int what, int slot, int level, void* host_out, size_t
     case MSF_DBG_FAST_CANDS: {
       if (level < 0 || level >= g.nlevels) return fail("bad level");
       uint32_t n = 0;
+      uint2 cm = make_uint2(0u, 0u);        // where the list lives: its primary region or a pool block
       hipMemcpy(&n, d_cand_cnt_ + (size_t)row * kOrbLevels + level, 4, hipMemcpyDeviceToHost);
-      if (n > (uint32_t)g.lv[level].cand_cap) n = g.lv[level].cand_cap;
+      hipMemcpy(&cm, d_cmap_ + (size_t)row * kOrbLevels + level, sizeof(cm), hipMemcpyDeviceToHost);
+      if (n > cm.y) n = cm.y;
       std::vector<uint32_t> tk(n);
       std::vector<uint8_t> ts(n);
       if (n) {
-        hipMemcpy(tk.data(), d_cand_ + (size_t)row * g.cand_total + g.lv[level].cand_off, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
-        hipMemcpy(ts.data(), d_cand_sc_ + (size_t)row * g.cand_total + g.lv[level].cand_off, n, hipMemcpyDeviceToHost);
+        hipMemcpy(tk.data(), d_cand_ + (size_t)cm.x, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        hipMemcpy(ts.data(), d_cand_sc_ + (size_t)cm.x, n, hipMemcpyDeviceToHost);
       }
       // the sampled quarter of a two-part streaming pass also lists corners below the level's final threshold
       uint32_t tfin = 0;

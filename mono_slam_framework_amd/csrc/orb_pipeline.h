@@ -25,8 +25,10 @@ struct OrbLevelInfo {
   int w, h, pitch;     // level size, row pitch in bytes (multiple of 16)
   int quota;           // nfeaturesPerLevel
   float scale;         // getScale(level)
-  int cand_cap;        // capacity of the FAST candidate list of this level
-  int cand_off;        // offset (entries) of this level inside a slot's candidate array
+  int cand_cap;        // FULL capacity of the FAST candidate list of this level (the dense detector: w h / 8)
+  int cand_off;        // offset (entries) of this level inside a frame's full-capacity region (dense calls)
+  int prim_cap;        // capacity of the level's PRIMARY list (the output-sensitive pass: w h / 64, at least 4096)
+  int prim_off;        // offset (entries) of it inside a work row's primary region
   int s1_off;          // offset (entries) of this level inside a slot's stage-1 array
   int tiles_x, tiles_y, tile_base;  // FAST tiling (128 x 32 tiles, dense kernel)
   // column strips of the streaming walker (one wave each) over the WHOLE level: strip (sx, sy) holds the 256-px window
@@ -48,7 +50,15 @@ struct OrbGeometry {
   int total_tiles;
   int total_strips;        // walker strips of all levels
   int max_level_tiles;     // largest tile count of one level
-  int cand_total;          // candidate entries per slot
+  int cand_total;          // candidate entries of a frame at full capacity (dense calls: one such region per frame in the pool)
+  int prim_total;          // candidate entries per work row (primary lists)
+  // r05: the candidate arrays are [work rows][prim_total] followed by a POOL of pool_entries entries.  The dense second
+  // pass of a (frame, level) first writes into the level's primary list (a smooth frame's dense list is short); only a
+  // level that overflows it takes a region of its full capacity from the pool (a bump allocation per call) and is redone
+  // once more.  A call that is dense altogether (MSF_FLAG_FAST_DENSE, fewer than eight frames) lays its frames'
+  // full-capacity regions over the pool.  Exhausted pool: MSF_ERR_CAPACITY for that frame, never a short list.
+  long long pool_base;     // first pool entry
+  unsigned pool_entries;
   int s1_total;            // stage-1 entries per slot
   long long pyr_bytes;     // pyramid blob bytes per slot (levels 1..)
   OrbLevelInfo lv[kOrbLevels];
@@ -121,8 +131,10 @@ class OrbPipeline {
   uint32_t* d_cand_cnt_ = nullptr; // [slots][8]
   uint32_t* d_tau_ = nullptr;      // [2][slots][8] FAST score threshold used per (slot, level) | first estimate
   uint32_t* d_redo_ = nullptr;     // [1 + slots * 8] dense-pass queue: count, entries (frame * 8 + level)
-  uint32_t* d_cand_ = nullptr;     // [slots][cand_total] key = y << 16 | x
-  uint8_t* d_cand_sc_ = nullptr;   // [slots][cand_total] FAST score
+  uint32_t* d_cand_ = nullptr;     // [work rows][prim_total] + pool: key = y << 16 | x
+  uint8_t* d_cand_sc_ = nullptr;   // the same shape: FAST score
+  uint2* d_cmap_ = nullptr;        // [work rows][8] where the list of (frame, level) lives: (first entry, capacity); reset per call
+  uint32_t* d_pool_cnt_ = nullptr; // pool entries handed out in the current call
   uint32_t* d_s1_cnt_ = nullptr;   // [slots][8]
   uint4* d_s1_ = nullptr;          // [slots][s1_total] (key, response bits, score, 0)
   // per feature SLOT (max_slots_): what a later match reads

@@ -485,6 +485,9 @@ def test_refined_fast_threshold_equals_unrefined_and_survives_an_overshooting_es
     assert (tau_two[:, :3, 0] > tau_one[:, :3, 0]).mean() > 0.5
     assert (tau_two[:, :, 0] == tau_two[:, :, 1]).all()                    # nothing redone
     # an absurd prediction margin (5 % of the needed density: thresholds far too high) only costs dense passes
+    # (these two settings send most levels of the batch through the dense pass: the pool of full-capacity candidate
+    # lists, sized for an eighth of them, is made large enough for all -- r05, orb_pipeline.h)
+    monkeypatch.setenv("MSF_ORB_POOL_ENTRIES", str(1 << 30))
     monkeypatch.setenv("MSF_ORB_TAU_PREDICT", "5")
     wildp = FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=fl)
     got_p = wildp.match_batch(list(A), list(B), cap=1024)
@@ -505,6 +508,7 @@ def test_refined_fast_threshold_equals_unrefined_and_survives_an_overshooting_es
     for r, g in zip(ref, got2):
         np.testing.assert_array_equal(r, g)
     monkeypatch.delenv("MSF_ORB_TAU2_MARGIN_PCT")
+    monkeypatch.delenv("MSF_ORB_POOL_ENTRIES")
     for env in ({"MSF_ORB_WALK_PER_LEVEL": "1"}, {"MSF_ORB_UNFUSED": "1"},
                 {"MSF_ORB_WALK_PER_LEVEL": "1", "MSF_ORB_TAU_PREDICT": "0"}):
         for k, v in env.items():
@@ -674,3 +678,39 @@ def test_two_walker_grids_at_once():
             np.testing.assert_array_equal(got[i], alone[0][i], err_msg="shard 0 pair %d" % i)
             np.testing.assert_array_equal(got[n + i], alone[1][i], err_msg="shard 1 pair %d" % i)
     multi.close()
+
+
+@pytest.mark.gpu
+def test_candidate_pool_exhaustion_is_loud_and_the_footprint_is_what_the_header_says(monkeypatch):
+    """r05: a (frame, level) keeps a small primary candidate list (w h / 64 entries) and takes a full-capacity region of a
+    shared pool only when it goes through the dense second pass (orb_pipeline.h).  (1) With the pool cut to nothing
+    (MSF_ORB_POOL_ENTRIES=0) and a first threshold no level can satisfy (MSF_ORB_FAST_TAU=254: every level needs the dense
+    pass) every pair reports n_out = -1 / MSF_ERR_CAPACITY -- never a short list; with the default pool the same batch is
+    the oracle's (test_fast_threshold_fallback_path).  (2) A handle for 1024 pairs of 1280 x 720 takes less than the 8 GB
+    include/msf_abi.h states (r04: 10.4 GB, r03: 20 GB)."""
+    import torch
+    from mono_slam_framework_amd import _lib
+    from mono_slam_framework_amd.matcher import FeatureMatcher
+    n, w, h = 8, 640, 480
+    A, B = synth.synth_batch(12500, n, w, h, mode=0)
+    monkeypatch.setenv("MSF_ORB_FAST_TAU", "254")
+    monkeypatch.setenv("MSF_ORB_POOL_ENTRIES", "0")
+    fm = FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=_lib.MSF_FLAG_NO_FRAME_CACHE)
+    num, _ = fm.match_batch_raw(list(A), list(B), cap=1024)
+    assert (num == -1).all(), num
+    fm.close()
+    monkeypatch.delenv("MSF_ORB_POOL_ENTRIES")
+    fm = FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=_lib.MSF_FLAG_NO_FRAME_CACHE)
+    num, lists = fm.match_batch_raw(list(A), list(B), cap=1024)
+    assert (num >= 0).all()
+    np.testing.assert_array_equal(lists[3], oracle_orb.FeatureMatcherOracle(0.7).MatchFrames(A[3], B[3]))
+    fm.close()
+    monkeypatch.delenv("MSF_ORB_FAST_TAU")
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    big = FeatureMatcher(0.6, 1280, 720, max_batch_pairs=1024)
+    free1, _ = torch.cuda.mem_get_info()
+    used = (free0 - free1) / 1e9
+    print("ORB handle, 1024 pairs of 1280x720: %.2f GB of device memory" % used)
+    assert 5.0 < used < 8.0, used
+    big.close()
