@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MSF_ABI_VERSION 3 /* 3: MSF_FLAG_BLUR_SUM256, msf_gather_*; 2: msf_weights_info, msf_convert_weights, msf_frame_cache_stats, flags FAST_DENSE / NO_FRAME_CACHE / LEVEL_SIZE_MUL_INV */
+#define MSF_ABI_VERSION 4 /* 4: MSF_DBG_WALK_MODE, the ORB candidate pool (MSF_ERR_CAPACITY when a call exhausts it); 3: MSF_FLAG_BLUR_SUM256, msf_gather_*; 2: msf_weights_info, msf_convert_weights, msf_frame_cache_stats, flags FAST_DENSE / NO_FRAME_CACHE / LEVEL_SIZE_MUL_INV */
 
 typedef struct msf_handle msf_handle;
 

@@ -294,7 +294,8 @@ struct FastSmem {
 
 // ---- where the candidate list of (frame, level) lives (r05): cmap[slot * 8 + level] = (first entry, capacity) in the
 // candidate arrays -- the level's primary list inside the frame's work row, or a block of the pool (orb_pipeline.h)
-__global__ __launch_bounds__(256) void k_cand_reset(OrbGeometry g, uint2* cmap_rows, uint32_t* pool_cnt, int n_frames, int dense) {
+__global__ __launch_bounds__(256) void k_cand_reset(OrbGeometry g, OrbPrimLists prim, uint2* cmap_rows, uint32_t* pool_cnt,
+                                                    int n_frames, int dense) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0) *pool_cnt = 0u;
   if (i >= n_frames * kOrbLevels) return;
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(256) void k_cand_reset(OrbGeometry g, uint2* cmap_r
   const OrbLevelInfo& L = g.lv[l];
   // a dense call (every level at fastThreshold): frame `row` gets a full-capacity region of the pool (host-checked: it fits)
   cmap_rows[i] = dense ? make_uint2((uint32_t)(g.pool_base + (long long)row * g.cand_total + L.cand_off), (uint32_t)L.cand_cap)
-                       : make_uint2((uint32_t)((long long)row * g.prim_total + L.prim_off), (uint32_t)L.prim_cap);
+                       : make_uint2((uint32_t)((long long)row * g.prim_total + prim.off[l]), (uint32_t)prim.cap[l]);
 }
 // one lane: (slot, level) moves to a pool region of its full capacity (before its dense pass); false: the pool is exhausted
 __device__ __forceinline__ bool cand_take_block(const OrbGeometry& g, uint2* cmap, uint32_t* pool_cnt, int idx, int l) {
@@ -767,10 +768,11 @@ __device__ __forceinline__ void walk_strip(StreamSmem& sm, const OrbGeometry& g,
   const uint32_t lerp_bright = 0x01010101u * (uint32_t)(128 - tv / 2);
   const uint32_t lerp_not_dark = 0x01010101u * (uint32_t)(255 - (254 - tv) / 2);
   uint32_t* const out_cnt = cand_cnt + idx;
-  const uint2 cm = cmap[idx];                     // (read behind the wait for the level's threshold: tau_unit may have moved the list)
+  // where this (frame, level)'s list lives (read behind the wait for the level's threshold)
+  const uint2 cm = cmap[idx];
   uint32_t* const outk = cand_key + cm.x;
   uint8_t* const outs = cand_sc + cm.x;
-  const uint32_t out_cap = cm.y;
+  const uint32_t out_cap = min(cm.y, (uint32_t)L.cand_cap);   // (a list never has more than the level's full capacity)
   uint32_t* pxw = reinterpret_cast<uint32_t*>(sm.px);
   uint32_t* scw = reinterpret_cast<uint32_t*>(sm.sc);
   uint8_t* pxb = sm.px;
@@ -2412,8 +2414,8 @@ std::string OrbPipeline::init(int width, int height, int max_slots, bool blur_ha
     // small levels keep their full capacity (little memory, and small levels are the ones that take the dense pass:
     // their thresholds rest on few corners): only lists above 16 K entries are cut
     if (pcap > cap || cap <= 16384) pcap = cap;
-    L.prim_cap = pcap;
-    L.prim_off = prim;
+    prim_.cap[l] = pcap;
+    prim_.off[l] = prim;
     prim += pcap;
     L.s1_off = s1;
     s1 += kS1Cap;
@@ -2666,7 +2668,7 @@ hipError_t OrbPipeline::extract_range(const FrameSrc& src, int n, hipStream_t st
   // where each (frame, level)'s candidate list lives in this call (k_cand_reset): its primary list, or -- a dense call --
   // the frame's full-capacity region in the pool
   if (dense && (long long)n * g.cand_total > (long long)g.pool_entries) return hipErrorInvalidValue;   // (cannot happen: see init)
-  hipLaunchKernelGGL(k_cand_reset, dim3((n * kOrbLevels + 255) / 256), dim3(256), 0, st, g, this->d_cmap_, d_pool_cnt_, n, dense ? 1 : 0);
+  hipLaunchKernelGGL(k_cand_reset, dim3((n * kOrbLevels + 255) / 256), dim3(256), 0, st, g, prim_, this->d_cmap_, d_pool_cnt_, n, dense ? 1 : 0);
   const int dyn = (fast_two_part_ && force_tau == 0) ? 1 : 0;
   bool fused = fused_ && !dense && g.total_tiles > 0;
   for (int l = 1; l < g.nlevels; l++) fused = fused && g.lv[l].wk_fused != 0;

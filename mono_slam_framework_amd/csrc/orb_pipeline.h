@@ -27,8 +27,6 @@ struct OrbLevelInfo {
   float scale;         // getScale(level)
   int cand_cap;        // FULL capacity of the FAST candidate list of this level (the dense detector: w h / 8)
   int cand_off;        // offset (entries) of this level inside a frame's full-capacity region (dense calls)
-  int prim_cap;        // capacity of the level's PRIMARY list (the output-sensitive pass: w h / 64, at least 4096)
-  int prim_off;        // offset (entries) of it inside a work row's primary region
   int s1_off;          // offset (entries) of this level inside a slot's stage-1 array
   int tiles_x, tiles_y, tile_base;  // FAST tiling (128 x 32 tiles, dense kernel)
   // column strips of the streaming walker (one wave each) over the WHOLE level: strip (sx, sy) holds the 256-px window
@@ -42,6 +40,13 @@ struct OrbLevelInfo {
   int tab_off;         // offset (entries) of this level's resize tables
   int samp_sx, samp_sy, samp_rows, samp_cols;   // tau_unit's sample lattice over [31, w-31) x [31, h-31); rows 0 = none
   long long pix_off;   // byte offset of this level inside a slot's pyramid blob (levels >= 1)
+};
+
+// per level: capacity of the PRIMARY candidate list (the output-sensitive pass: w h / 64, at least 4096; small levels keep
+// their full capacity) and its offset (entries) inside a work row's primary region.  (A struct of its own, passed to the
+// one kernel that needs it: inside OrbGeometry or OrbLevelInfo the extra members put the walker's copies into scratch.)
+struct OrbPrimLists {
+  int cap[kOrbLevels], off[kOrbLevels];
 };
 
 struct OrbGeometry {
@@ -103,6 +108,7 @@ class OrbPipeline {
 
  private:
   OrbGeometry g_{};
+  OrbPrimLists prim_{};
   int max_slots_ = 0;
   int work_frames_ = 0;            // frames one extraction may hold = rows of the per-call arrays (0 at init: max_slots)
   int last_n_ = 0;                 // frames of the last extraction (debug_get maps a slot to its work row)

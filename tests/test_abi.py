@@ -22,7 +22,7 @@ def test_header_symbols_are_exported():
     for n in names:
         assert hasattr(L, n), n
     assert sorted(_lib.ABI_SYMBOLS) == names
-    assert L.msf_abi_version() == 3
+    assert L.msf_abi_version() == 4
 
 
 def test_header_is_plain_c(tmp_path):

@@ -42,13 +42,13 @@ def audit(src):
         m = re.match(r"^(_ZN3msf\w+):", ln)
         if m:
             cur = m.group(1)
-            stats[cur] = {"vm0": 0, "vm0_loop": 0, "loads": 0, "lines": 0}
+            stats[cur] = {"vm0": 0, "vm0_loop": 0, "loads": 0, "lines": 0, "scratch_ops": 0}
             inloop = False
             continue
         m = re.match(r"\s*\.amdhsa_kernel (\S+)", ln)
         if m:
             cur = m.group(1)
-            stats.setdefault(cur, {"vm0": 0, "vm0_loop": 0, "loads": 0, "lines": 0})
+            stats.setdefault(cur, {"vm0": 0, "vm0_loop": 0, "loads": 0, "lines": 0, "scratch_ops": 0})
             continue
         if cur is None:
             continue
@@ -72,6 +72,10 @@ def audit(src):
             st["vm0_loop"] += 1 if inloop else 0
         if "global_load" in ln or "buffer_load" in ln:
             st["loads"] += 1
+        # scratch-memory instructions actually emitted (the descriptor's private-segment size also counts the frame the
+        # compiler reserves behind scalar-register spills to vector lanes, which no instruction ever touches)
+        if re.match(r"^\s*scratch_(load|store)", ln):
+            st["scratch_ops"] += 1
     return stats
 
 
