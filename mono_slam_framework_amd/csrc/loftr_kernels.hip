@@ -958,8 +958,10 @@ __global__ __launch_bounds__(64 * WV) void k_strip8x(const float* __restrict__ i
       if (sums) {
 #pragma unroll
         for (int g = 0; g < 3; g++) {
+#ifndef MSF_ABL_ONEMFMA   // timing-only build (results invalid): one product per fragment instead of three
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[g], fh[g], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g], fl[g], acc, 0, 0, 0);
+#endif
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[g], fh[g], acc, 0, 0, 0);
         }
       }
