@@ -10,7 +10,9 @@
 //                                  encoder blocks), k_sim_stats / k_conf_mask (similarity + dual softmax)
 //   '> threshold' + findNonZero + decode (:75-99) -> k_conf_mask (bit mask, conf never written to HBM) + k_decode
 //
-// Activations are NCHW f32 (the graph's own layout) so MFMA results store as float4 runs along W.
+// Activations in HBM: NCHW f32 (the graph's own layout: MFMA results store as float4 runs along W) everywhere except
+// BETWEEN the six streaming kernels of the default path, which hand each other "split pixels" -- channels-last 16-byte
+// pixels in [hi | lo] bf16 planes, the operand format of their LDS rings (see sx_off) -- so that the producer splits once.
 #include "loftr_pipeline.h"
 #include "weights_io.h"
 
@@ -762,15 +764,16 @@ __global__ __launch_bounds__(256, 2) void k_block8x(const float* __restrict__ in
 // step, and every convolution stage keeps its last six row pairs in an LDS ring ([hi | lo] planes of 16-byte pixels
 // as in k_block8x).  The 2 NB convolutions are a software pipeline over the steps with ONE barrier per step: stage c
 // (waves 8 / NS * (c - 1) ...) works on pair n - 2c at step n, reading only what stage c-1 wrote in earlier steps:
-//   step n:  pair n of x -> ring 0 (fetched four steps ahead into a statically named register queue, one pixel = 8
-//            channel dwords per loader thread)
+//   step n:  pair n of x -> ring 0 (fetched three steps ahead into a statically named register queue, one split pixel =
+//            16 bytes hi + 16 bytes lo per loader thread: two 16-byte loads, two 16-byte LDS writes)
 //            stage 1: pair n-2 of t1 from pairs n-3 .. n-1 of x
 //            stage 2: pair n-4 of y1 from pairs n-5 .. n-3 of t1, + residual pair n-4 of x (still in ring 0, hi + lo)
 //            stage 3: pair n-6 of t2 from y1,  stage 4: pair n-8 of y2 from t2 + residual y1 -> global memory
 // No row is fetched or computed twice, no intermediate leaves LDS; only the strip's halo columns (2 NB each side) are
 // recomputed.  All stages run transposed (A = weights, B = pixels): a lane holds 4 consecutive channels of one pixel,
-// i.e. one 8-byte LDS access per plane for ring writes and residual reads; the last stage stores dwords (16 lanes = 64
-// contiguous bytes per channel row).  A wave holds only its own stage's weight fragments (24 VGPRs).
+// i.e. one 8-byte LDS access per plane for ring writes and residual reads; the last stage splits its sums and stores the
+// two 8-byte halves (16 lanes x 2 halves = 256 contiguous bytes per row and plane).  A wave holds only its own stage's
+// weight fragments (24 VGPRs).
 namespace strip8 {
 constexpr int S = 64;                              // output columns per strip
 // ring row pitch in pixels (widest ring: 64 + 2 * 4 columns).  r03 counters for k_strip8x: waves wait 52 % of their
@@ -811,7 +814,6 @@ __global__ __launch_bounds__(64 * WV) void k_strip8x(const float* __restrict__ i
   constexpr int S = SB;                            // output columns per strip (hides strip8::S, the stem kernel's 64)
   constexpr int NS = 2 * NB;                       // convolution stages
   constexpr int WPS = WAVES / NS;                  // waves per stage
-  constexpr int MAXJOBS = (5 + WPS - 1) / WPS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   bf16x8* ring = reinterpret_cast<bf16x8*>(lds);   // ring c (c = 0: x): hi plane at c * 2 RING, lo plane RING behind it
   const int nwg = gridDim.x, per = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7;
@@ -1087,7 +1089,6 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8
   const int cx = 2 * (X0 - NS) - 4 + 4 * dd;                      // image column of the dword (a multiple of 4)
   const bool colok = ld && cx >= 0 && cx < Win;
   const uint32_t lofs = colok ? (uint32_t)cx : 0u;
-  const bool ldwave = wave <= (NLOAD - 1) / 64;
 #define MSF_SS_ISSUE(q_, n_)                                                                      \
   {                                                                                               \
     const int gy = 4 * (n_) + r4;                                                                 \
