@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8
     uint32_t* z = reinterpret_cast<uint32_t*>(lds);
     for (int idx = tid; idx < LDS_BYTES / 4; idx += 64 * WAVES) z[idx] = 0u;
   }
-  // image loader (the last NLOAD threads): thread (row r4 of the step's four, aligned dword d) fetches 4 pixels.  The
+  // image loader: thread (row r4 of the step's four, aligned dword d) fetches 4 pixels.  The
   // tile's pixel 0 is image column CB = 2 (X0 - NS) - 3 == 1 (mod 4): the dword at CB - 1 + 4d holds tile pixels 4d-1 .. 4d+2.
   // (r05: the FIRST NLOAD threads, i.e. the stem waves, which never store to global memory -- see k_strip8x)
   const int ltid = tid < NLOAD ? tid : -1;
@@ -1253,7 +1253,7 @@ __global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8
 //           the ky = 1 group, so it costs three more MFMAs and no LDS read.  K = 32 of an MFMA = the 3 kx of one ky x 8
 //           channels (+ one zero block).  Both results go to rings (16 channels = 2 channel-block planes, hi | lo);
 //   stage 2 (waves 6-7, two jobs each): u = relu(conv3x3(t) + sc) with k_block16x's K grouping (two taps x two channel
-//           blocks per MFMA, five groups), stored to global memory (dwords, 64 contiguous bytes per channel row).
+//           blocks per MFMA, five groups), stored to global memory as split pixels (sx_st4: 256 contiguous bytes per row and plane).
 // Pipeline: input rows 4n .. 4n+3 arrive at step n (fetched four steps ahead), stage 1 makes row pair n - 1, stage 2
 // pair n - 3; one barrier per step.  Moves x once and u once instead of x, t, sc twice and u (4.9 -> 1.9 GB per step).
 namespace down16 {
@@ -1267,7 +1267,7 @@ constexpr int TCB = TROWS * TPX;                   // 288 = 18 x 16 slots per ch
 constexpr int TRING = 4 * TCB;                     // [hi | lo][channel block]
 static_assert(TCB % 16 == 0, "channel-block planes must be multiples of 16 pixel slots");
 constexpr int WAVES = 8;
-constexpr int NLOAD = 4 * INW;                     // loader threads: one input pixel (8 channel dwords) each per step
+constexpr int NLOAD = 4 * INW;                     // loader threads: one input pixel (16 bytes hi + 16 bytes lo) each per step
 constexpr int LDS_BYTES = 16 * (2 * IPLANE + 2 * TRING + 16);
 constexpr int W1FRAG = 2 * 3 * 64 * 8;             // conv3x3 stride 2: [hi | lo][ky][lane][8]
 constexpr int WSFRAG = 2 * 64 * 8;                 // shortcut: [hi | lo][lane][8]
@@ -1325,7 +1325,7 @@ __global__ __launch_bounds__(64 * down16::WAVES) void k_down16x(const float* __r
     uint32_t* z = reinterpret_cast<uint32_t*>(lds);
     for (int idx = tid; idx < LDS_BYTES / 4; idx += 64 * WAVES) z[idx] = 0u;
   }
-  // loader (threads 0 .. NLOAD-1): thread (row r4 of the step's four, tile column lc) fetches one pixel = 8 channel dwords
+  // loader (threads 0 .. NLOAD-1): thread (row r4 of the step's four, tile column lc) fetches one split pixel (2 x 16 bytes)
   const bool ld = tid < NLOAD;
   const int r4 = ld ? tid / INW : 0, lc = ld ? tid - r4 * INW : 0;
   const int lgx = 2 * X0 - 3 + lc;
@@ -1528,7 +1528,7 @@ __global__ __launch_bounds__(64 * strip16::WAVES) void k_strip16x(const float* _
     uint32_t* z = reinterpret_cast<uint32_t*>(lds);
     for (int idx = tid; idx < LDS_BYTES / 4; idx += 64 * WAVES) z[idx] = 0u;
   }
-  // loader (threads 0 .. NLOAD-1): thread (channel block lcb, row lr of the pair, ring column lc) fetches 8 channel dwords
+  // loader (threads 0 .. NLOAD-1): thread (channel block lcb, row lr of the pair, ring column lc) fetches one split pixel block (2 x 16 bytes)
   const bool ld = tid < NLOAD;
   const int lcb = ld ? tid / (2 * XW) : 0, lrm = ld ? tid - lcb * 2 * XW : 0;
   const int lr = lrm / XW, lc = lrm - lr * XW;
@@ -1728,7 +1728,7 @@ __global__ __launch_bounds__(64 * strip32::WAVES) MSF_STRIP32_ATTR void k_strip3
     uint32_t* z = reinterpret_cast<uint32_t*>(lds);
     for (int idx = tid; idx < LDS_BYTES / 4; idx += 64 * WAVES) z[idx] = 0u;
   }
-  // loader (the last NLOAD threads): thread (channel block lcb, row lr of the pair, ring column lc) fetches 8 channel dwords
+  // loader (the last NLOAD threads): thread (channel block lcb, row lr of the pair, ring column lc) fetches one split pixel block (2 x 16 bytes)
 #ifndef MSF_S32_LOADERS_FIRST
   const int ltid = tid - (64 * WAVES - NLOAD);     // (r05: in the stage-A waves instead -- no stores there, see k_strip8x -- 362 -> 654 us:
                                                    // those waves carry two M-tile jobs each, the loader on top makes them the step)
@@ -1949,7 +1949,7 @@ __global__ __launch_bounds__(64 * down32::WAVES) void k_down32x(const float* __r
     uint32_t* z = reinterpret_cast<uint32_t*>(lds);
     for (int idx = tid; idx < LDS_BYTES / 4; idx += 64 * WAVES) z[idx] = 0u;
   }
-  // loader (threads 0 .. NLOAD-1): thread (channel block lcb, row r4 of the step's four, tile column lc) fetches 8 channel dwords
+  // loader (threads 0 .. NLOAD-1): thread (channel block lcb, row r4 of the step's four, tile column lc) fetches one split pixel block (2 x 16 bytes)
   const bool ld = tid < NLOAD;
   const int lcb = ld ? tid / (4 * INW) : 0, lrm = ld ? tid - lcb * 4 * INW : 0;
   const int r4 = lrm / INW, lc = lrm - r4 * INW;
