@@ -761,7 +761,7 @@ __global__ __launch_bounds__(256, 2) void k_block8x(const float* __restrict__ in
 // k_block8x runs at memory speed, and what it moves is 1.5 x its input (row halos of 8-row bands) + the residual
 // operand + the output, once per block.  This kernel removes all of that but one read and one write for BOTH blocks of
 // layer1: a workgroup owns a 64-column strip of one image and walks it top to bottom two rows (one MFMA row pair) per
-// step, and every convolution stage keeps its last six row pairs in an LDS ring ([hi | lo] planes of 16-byte pixels
+// step, and every convolution stage keeps its last five row pairs in an LDS ring ([hi | lo] planes of 16-byte pixels
 // as in k_block8x).  The 2 NB convolutions are a software pipeline over the steps with ONE barrier per step: stage c
 // (waves 8 / NS * (c - 1) ...) works on pair n - 2c at step n, reading only what stage c-1 wrote in earlier steps:
 //   step n:  pair n of x -> ring 0 (fetched three steps ahead into a statically named register queue, one split pixel =
@@ -781,7 +781,10 @@ constexpr int S = 64;                              // output columns per strip
 // multiple of 256 B apart, so that the 16 slots a ds_read_b128 lane group takes from two ring rows meet no bank twice)
 // changed nothing: 642 vs 617 us -- the conflicts are not in the fragment reads, and they are not what bounds the step.
 constexpr int XP = 72;
-constexpr int RROWS = 12;                          // six row pairs per ring (five are live in a step)
+// five row pairs per ring: exactly what is live in a step (x: the pair being written, the three pairs stage 1 reads, the
+// pair stage 2 takes its residual from; a pair is overwritten in the step after its last read, behind the step's
+// barrier).  r04 kept a sixth; without it k_stem_strip8x's LDS is 51 KB: THREE workgroups per CU (below)
+constexpr int RROWS = 10;
 constexpr int RING = RROWS * XP;                   // pixel slots per plane
 constexpr int TAIL = 16;                           // the fifth M tile of a stage reads up to 10 slots past a ring row
 constexpr int WAVES = 8;
@@ -1042,7 +1045,14 @@ constexpr int LDS_BYTES = 16 * (NS * 2 * RING + TAIL) + 2 * IROWS * IP + 64;
 constexpr int WFRAG = 2 * 3 * 64 * 8;              // stem fragments [hi | lo][row group][lane][8]
 }  // namespace stem8
 
-__global__ __launch_bounds__(64 * strip8::WAVES) void k_stem_strip8x(const uint8_t* __restrict__ framesA, int nA,
+// r05: three workgroups per CU -- 51 KB of LDS (five-pair rings) and six waves per SIMD = 80 registers (86 uncapped: five
+// registers are spilled, 20 B of scratch).  711-723 -> 683 us per 512 images; the grid (2 560 workgroups) is 3.3 rounds of
+// the 768 resident ones, the last one a third full.
+#ifndef MSF_STEM_WPE
+#define MSF_STEM_WPE 6
+#endif
+#define MSF_STEM_ATTR __attribute__((amdgpu_waves_per_eu(MSF_STEM_WPE, MSF_STEM_WPE)))
+__global__ __launch_bounds__(64 * strip8::WAVES) MSF_STEM_ATTR void k_stem_strip8x(const uint8_t* __restrict__ framesA, int nA,
                                                                      const uint8_t* __restrict__ framesB, long long frame_stride,
                                                                      int row_stride, const uint16_t* __restrict__ wx0,
                                                                      const float* __restrict__ b0, StripW sw,

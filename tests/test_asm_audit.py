@@ -47,9 +47,10 @@ def test_orb_kernels_keep_their_occupancy_and_waits():
 def test_loftr_streaming_kernels_fit_two_workgroups_per_cu():
     raw = _audit("loftr")
     for name, max_vgpr, max_scratch in (("k_down16x", 128, 0), ("k_strip32x", 128, 64), ("k_strip16x", 128, 0),
-                                        ("k_stem_strip8x", 128, 0), ("k_sim_single", 128, 0), ("k_sim_cand3", 128, 0)):
+                                        ("k_stem_strip8x", 80, 32), ("k_sim_single", 128, 0), ("k_sim_cand3", 128, 0)):
         sts = _by_prefix(raw, name)
         assert sts, name
         for st in sts:
-            assert st["vgpr"] <= max_vgpr, "%s: %d registers (more than 128 = one 8-wave workgroup per CU)" % (name, st["vgpr"])
+            # (128 registers = two 8-wave workgroups per CU; k_stem_strip8x runs three: 80 registers, 20 B of spills)
+            assert st["vgpr"] <= max_vgpr, "%s: %d registers (fewer workgroups per CU than it is built for)" % (name, st["vgpr"])
             assert st["scratch"] <= max_scratch, "%s spills %d B" % (name, st["scratch"])
