@@ -36,7 +36,8 @@
 #define MSF_LOFTR_STEM_DEPTH 4   // k_stem_strip8x: 858 / 867 / 898 us
 #define MSF_LOFTR_STRIP16_DEPTH 2   // k_strip16x: 452 / 435 / 419 us
 #define MSF_LOFTR_STRIP32_DEPTH 2   // k_strip32x: 484 / 492 us at one workgroup per CU (164 / 145 registers); 2 steps + the 128-register cap below: two workgroups, 368-375 us
-#define MSF_LOFTR_DOWN32_DEPTH 4   // k_down32x: 479 / 484 / 505 us (232 / 200 / 164 registers: one workgroup per CU at any depth)
+#define MSF_LOFTR_DOWN32_DEPTH 2   // k_down32x (r04, one loop for both stages: 4 / 3 / 2 steps = 479 / 484 / 505 us at 232 / 200 / 164 registers, one
+                                   // workgroup per CU at any depth; r05: per-stage loops + 2 steps fit two workgroups)
 #define MSF_LOFTR_DOWN16_DEPTH 3   // 110 registers, two workgroups per CU, no spills (4: 164 registers, one workgroup): 584 -> 475 us
 
 namespace msf {
@@ -1917,8 +1918,10 @@ constexpr int NLOAD = 2 * 4 * INW;                 // loader threads: (channel b
 constexpr int LDS_BYTES = 16 * (IRING + 2 * TRING + 16);
 }  // namespace down32
 
-#define MSF_LOFTR_DOWN32_WPE 0     // > 0: cap k_down32x's registers for this many waves per SIMD
-__global__ __launch_bounds__(64 * down32::WAVES) void k_down32x(const float* __restrict__ in, DownW dw, float* __restrict__ out,
+#ifndef MSF_LOFTR_DOWN32_WPE
+#define MSF_LOFTR_DOWN32_WPE 4     // registers capped for this many waves per SIMD (4 = 128 registers = two workgroups per CU)
+#endif
+__global__ __launch_bounds__(64 * down32::WAVES) __attribute__((amdgpu_waves_per_eu(MSF_LOFTR_DOWN32_WPE, MSF_LOFTR_DOWN32_WPE))) void k_down32x(const float* __restrict__ in, DownW dw, float* __restrict__ out,
                                                                 int H, int W, int n_strips) {
   using namespace down32;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1938,23 +1941,6 @@ __global__ __launch_bounds__(64 * down32::WAVES) void k_down32x(const float* __r
   const bool st1 = wave < 4;
   const int nt = wave & 1, jr = (wave >> 1) & 1;   // output-channel tile, row of the pair
   const int cbp = 2 * nt + (kq >> 1);              // channel-block plane of this lane's channels 16 nt + 4 kq .. +3 (half kq & 1)
-
-  bf16x8 wa[9], wb[9], wsh, wsl;                   // stage 1 uses 5 groups (+ the shortcut), stage 2 all 9
-  {
-    const bf16x8* pw = reinterpret_cast<const bf16x8*>(st1 ? dw.w1 : dw.w2);
-    const int ng = st1 ? 5 : 9;
-#pragma unroll
-    for (int g = 0; g < 9; g++) {
-      const int gg = g < ng ? g : ng - 1;
-      wa[g] = pw[((gg * 2 + nt) * 2 + 0) * 64 + lane];
-      wb[g] = pw[((gg * 2 + nt) * 2 + 1) * 64 + lane];
-    }
-    const bf16x8* ps = reinterpret_cast<const bf16x8*>(dw.wsc);
-    wsh = ps[(nt * 2 + 0) * 64 + lane];
-    wsl = ps[(nt * 2 + 1) * 64 + lane];
-  }
-  const f32x4 bias = *reinterpret_cast<const f32x4*>((st1 ? dw.b1 : dw.b2) + 16 * nt + 4 * kq);
-  const f32x4 bias_sc = *reinterpret_cast<const f32x4*>(dw.bsc + 16 * nt + 4 * kq);
   {
     uint32_t* z = reinterpret_cast<uint32_t*>(lds);
     for (int idx = tid; idx < LDS_BYTES / 4; idx += 64 * WAVES) z[idx] = 0u;
@@ -1968,6 +1954,7 @@ __global__ __launch_bounds__(64 * down32::WAVES) void k_down32x(const float* __r
   const uint32_t lofs = colok ? (uint32_t)lgx : 0u;
   const int lslot = (lc & 1) ? IODD + (lc >> 1) : (lc >> 1);
   const bool ldwave = wave <= (NLOAD - 1) / 64;
+  static_assert((NLOAD - 1) / 64 == 4, "waves 0-3 (stage 1) are loader waves, wave 4 (stage 2) partly");
 #define MSF_D32_ISSUE(q_, n_)                                                                     \
   {                                                                                               \
     const int gy = 4 * (n_) + r4;                                                                 \
@@ -1982,107 +1969,130 @@ __global__ __launch_bounds__(64 * down32::WAVES) void k_down32x(const float* __r
     u32x4v* dst = reinterpret_cast<u32x4v*>(xr + (lcb * ICB + irow + r4 * IPX + lslot));          \
     dst[0] = ok ? q_[0] : z4; dst[2 * ICB] = ok ? q_[1] : z4;                                     \
   }
-  int irow = 0;                                    // loader cursor: (4n mod 12) * IPX
   constexpr int IWRAP = IROWS * IPX;
   const bool edge = X0 == 0 || X0 + S >= W;
-  // stage 1: this lane's K block of group g: tap 2g + (kq >> 1) (the tenth has zero weights), channel block kq & 1
-  int s1off[5];
+  constexpr int kQDepth = MSF_LOFTR_DOWN32_DEPTH;
+  static_assert(kQDepth == 2, "the step macro is written out for a two-step queue");
+  const int nsteps = ((npairs + 3 + kQDepth - 1) / kQDepth) * kQDepth;
+  // r05: one copy of the step loop per (loader?, stage) -- a wave then holds only ITS stage's weight fragments (stage 1:
+  // five groups + the shortcut = 48 registers, stage 2: nine groups = 72; r04: 80 in every wave) and, with a two-step
+  // queue, the kernel fits 128 registers: two workgroups per CU instead of one (226 registers)
+  auto run = [&](auto is_loader, auto is_st1) {
+    constexpr bool kLd = decltype(is_loader)::value, ST1 = decltype(is_st1)::value;
+    constexpr int NG = ST1 ? 5 : 9;
+    bf16x8 wa[NG], wb[NG], wsh, wsl;
+    {
+      const bf16x8* pw = reinterpret_cast<const bf16x8*>(ST1 ? dw.w1 : dw.w2);
 #pragma unroll
-  for (int g = 0; g < 5; g++) {
-    int t = 2 * g + (kq >> 1);
-    t = t < 9 ? t : 8;
-    const int ky = t / 3, kx = t - 3 * ky;
-    s1off[g] = ky * 256 + (kx == 1 ? IODD : kx == 0 ? 0 : 1);     // ky in bits 8.., column offset below
-  }
-  auto stage1 = [&](int p) {
-    const int Y = 2 * p + jr;
-    bf16x4* th4 = reinterpret_cast<bf16x4*>(tr);
-    bf16x4* sh4 = reinterpret_cast<bf16x4*>(sr);
-    if (p >= npairs) {
-      bf16x4 z;
-      z[0] = z[1] = z[2] = z[3] = (__bf16)0.f;
-#pragma unroll
-      for (int q = 0; q < 2; q++) {
-        const int jt = 16 * q + i;
-        if (jt < TW) {
-          const int os = 2 * (cbp * TCB + (Y & (TROWS - 1)) * TPX + jt) + (kq & 1);
-          th4[os] = z; th4[os + 8 * TCB] = z;
-        }
+      for (int g = 0; g < NG; g++) {
+        wa[g] = pw[((g * 2 + nt) * 2 + 0) * 64 + lane];
+        wb[g] = pw[((g * 2 + nt) * 2 + 1) * 64 + lane];
       }
-      return;
+      const bf16x8* ps = reinterpret_cast<const bf16x8*>(dw.wsc);
+      wsh = ps[(nt * 2 + 0) * 64 + lane];            // (stage 1 only: dead in the stage-2 copies)
+      wsl = ps[(nt * 2 + 1) * 64 + lane];
     }
-    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    f32x4 asc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const f32x4 bias = *reinterpret_cast<const f32x4*>((ST1 ? dw.b1 : dw.b2) + 16 * nt + 4 * kq);
+    const f32x4 bias_sc = *reinterpret_cast<const f32x4*>(dw.bsc + 16 * nt + 4 * kq);
+    int irow = 0;                                    // loader cursor: (4n mod 12) * IPX
+    // stage 1: this lane's K block of group g: tap 2g + (kq >> 1) (the tenth has zero weights), channel block kq & 1
+    int s1off[5];
 #pragma unroll
     for (int g = 0; g < 5; g++) {
-      const int ky = s1off[g] >> 8, co = s1off[g] & 255;
-      int rr = 4 * p + 2 * jr - 1 + ky + IROWS;    // input row 2Y - 1 + ky, ring rows modulo 12
-      rr = rr - IROWS * ((rr * 2731) >> 15);
-      const bf16x8* row = xr + ((kq & 1) * ICB + rr * IPX + co);
+      int t = 2 * g + (kq >> 1);
+      t = t < 9 ? t : 8;
+      const int ky = t / 3, kx = t - 3 * ky;
+      s1off[g] = ky * 256 + (kx == 1 ? IODD : kx == 0 ? 0 : 1);     // ky in bits 8.., column offset below
+    }
+    auto stage1 = [&](int p) {
+      const int Y = 2 * p + jr;
+      bf16x4* th4 = reinterpret_cast<bf16x4*>(tr);
+      bf16x4* sh4 = reinterpret_cast<bf16x4*>(sr);
+      if (p >= npairs) {
+        bf16x4 z;
+        z[0] = z[1] = z[2] = z[3] = (__bf16)0.f;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const int jt = 16 * q + i;
+          if (jt < TW) {
+            const int os = 2 * (cbp * TCB + (Y & (TROWS - 1)) * TPX + jt) + (kq & 1);
+            th4[os] = z; th4[os + 8 * TCB] = z;
+          }
+        }
+        return;
+      }
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      f32x4 asc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int g = 0; g < 5; g++) {
+        const int ky = s1off[g] >> 8, co = s1off[g] & 255;
+        int rr = 4 * p + 2 * jr - 1 + ky + IROWS;    // input row 2Y - 1 + ky, ring rows modulo 12
+        rr = rr - IROWS * ((rr * 2731) >> 15);
+        const bf16x8* row = xr + ((kq & 1) * ICB + rr * IPX + co);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const int jt = 16 * q + i;
+          const bf16x8* src = row + (jt < TW ? jt : TW);           // lanes past the strip's columns stay inside the row
+          const bf16x8 ph = src[0], pl = src[2 * ICB];
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[g < NG ? g : 0], ph, acc[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g < NG ? g : 0], pl, acc[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g < NG ? g : 0], ph, acc[q], 0, 0, 0);
+          if (g == 2) {                                             // the centre tap: K blocks 0, 1 of this group
+            asc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsl, ph, asc[q], 0, 0, 0);
+            asc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsh, pl, asc[q], 0, 0, 0);
+            asc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsh, ph, asc[q], 0, 0, 0);
+          }
+        }
+      }
 #pragma unroll
       for (int q = 0; q < 2; q++) {
         const int jt = 16 * q + i;
-        const bf16x8* src = row + (jt < TW ? jt : TW);           // lanes past the strip's columns stay inside the row
-        const bf16x8 ph = src[0], pl = src[2 * ICB];
-        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[g], ph, acc[q], 0, 0, 0);
-        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], pl, acc[q], 0, 0, 0);
-        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], ph, acc[q], 0, 0, 0);
-        if (g == 2) {                                             // the centre tap: K blocks 0, 1 of this group
-          asc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsl, ph, asc[q], 0, 0, 0);
-          asc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsh, pl, asc[q], 0, 0, 0);
-          asc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsh, ph, asc[q], 0, 0, 0);
+        f32x4 v = acc[q] + bias, vs = asc[q] + bias_sc;
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        if (edge) {
+          const int gx = X0 - 1 + jt;
+          if (gx < 0 || gx >= W) v = f32x4{0.f, 0.f, 0.f, 0.f};    // stage 2 pads t with zeros
+        }
+        if (jt < TW) {
+          bf16x4 vh, vl;
+          const int os = 2 * (cbp * TCB + (Y & (TROWS - 1)) * TPX + jt) + (kq & 1);
+          split4(v, vh, vl);
+          th4[os] = vh; th4[os + 8 * TCB] = vl;
+          split4(vs, vh, vl);
+          sh4[os] = vh; sh4[os + 8 * TCB] = vl;
         }
       }
-    }
+    };
+    auto stage2 = [&](int p) {
+      if (p >= npairs) return;
+      const int Y = 2 * p + jr;
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-      const int jt = 16 * q + i;
-      f32x4 v = acc[q] + bias, vs = asc[q] + bias_sc;
+      for (int g = 0; g < 9; g++) {
+        const int ky = g / 3, kx = g - 3 * ky;
+        const bf16x8* src = tr + (kq * TCB + ((Y - 1 + ky) & (TROWS - 1)) * TPX + i + kx);
+        const bf16x8 ah = src[0], al = src[4 * TCB];
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[g < NG ? g : 0], ah, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g < NG ? g : 0], al, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g < NG ? g : 0], ah, acc, 0, 0, 0);
+      }
+      const bf16x4* sh4 = reinterpret_cast<const bf16x4*>(sr);
+      const int rs = 2 * (cbp * TCB + (Y & (TROWS - 1)) * TPX + i + 1) + (kq & 1);
+      const bf16x4 a = sh4[rs], b = sh4[rs + 8 * TCB];
+      f32x4 v = acc + bias;
+      v.x += (float)a[0] + (float)b[0]; v.y += (float)a[1] + (float)b[1];
+      v.z += (float)a[2] + (float)b[2]; v.w += (float)a[3] + (float)b[3];
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-      if (edge) {
-        const int gx = X0 - 1 + jt;
-        if (gx < 0 || gx >= W) v = f32x4{0.f, 0.f, 0.f, 0.f};    // stage 2 pads t with zeros
-      }
-      if (jt < TW) {
-        bf16x4 vh, vl;
-        const int os = 2 * (cbp * TCB + (Y & (TROWS - 1)) * TPX + jt) + (kq & 1);
-        split4(v, vh, vl);
-        th4[os] = vh; th4[os + 8 * TCB] = vl;
-        split4(vs, vh, vl);
-        sh4[os] = vh; sh4[os + 8 * TCB] = vl;
-      }
-    }
-  };
-  auto stage2 = [&](int p) {
-    if (p >= npairs) return;
-    const int Y = 2 * p + jr;
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int g = 0; g < 9; g++) {
-      const int ky = g / 3, kx = g - 3 * ky;
-      const bf16x8* src = tr + (kq * TCB + ((Y - 1 + ky) & (TROWS - 1)) * TPX + i + kx);
-      const bf16x8 ah = src[0], al = src[4 * TCB];
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[g], ah, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], al, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[g], ah, acc, 0, 0, 0);
-    }
-    const bf16x4* sh4 = reinterpret_cast<const bf16x4*>(sr);
-    const int rs = 2 * (cbp * TCB + (Y & (TROWS - 1)) * TPX + i + 1) + (kq & 1);
-    const bf16x4 a = sh4[rs], b = sh4[rs + 8 * TCB];
-    f32x4 v = acc + bias;
-    v.x += (float)a[0] + (float)b[0]; v.y += (float)a[1] + (float)b[1];
-    v.z += (float)a[2] + (float)b[2]; v.w += (float)a[3] + (float)b[3];
-    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-    if (X0 + i < W) sx_st4(outf, Y, cbp, X0 + i, kq & 1, W, 4, v);   // channels 16 nt + 4 kq .. +3: block cbp, half kq & 1
-  };
+      if (X0 + i < W) sx_st4(outf, Y, cbp, X0 + i, kq & 1, W, 4, v);   // channels 16 nt + 4 kq .. +3: block cbp, half kq & 1
+    };
 #define MSF_D32_STEP(q_, n_)                                                                      \
   {                                                                                               \
     __syncthreads();                                                                              \
     if (kLd) {                                                                                    \
       MSF_D32_COMMIT(q_, n_)                                                                      \
-      MSF_D32_ISSUE(q_, (n_) + MSF_LOFTR_DOWN32_DEPTH)                                                                 \
+      MSF_D32_ISSUE(q_, (n_) + kQDepth)                                                           \
     }                                                                                             \
-    if (st1) {                                                                                    \
+    if (ST1) {                                                                                    \
       const int p_ = (n_) - 1;                                                                    \
       if (p_ >= 0 && p_ <= npairs) stage1(p_);                                                    \
     } else {                                                                                      \
@@ -2091,33 +2101,22 @@ __global__ __launch_bounds__(64 * down32::WAVES) void k_down32x(const float* __r
     }                                                                                             \
     irow += 4 * IPX; irow = irow >= IWRAP ? irow - IWRAP : irow;                                  \
   }
-  // the load queue is MSF_LOFTR_DOWN32_DEPTH steps deep (2, 3 or 4), each step's registers named statically; the loop is unrolled by the depth
-  constexpr int kQDepth = MSF_LOFTR_DOWN32_DEPTH;
-  static_assert(kQDepth >= 2 && kQDepth <= 4, "load queue depth");
-  const int nsteps = ((npairs + 3 + kQDepth - 1) / kQDepth) * kQDepth;
-  auto run = [&](auto is_loader) {
-    constexpr bool kLd = decltype(is_loader)::value;
     u32x4v q0[2]; u32x4v q1[2];
-    u32x4v q2[2];
-    u32x4v q3[2];
     if (kLd) {
       MSF_D32_ISSUE(q0, 0)
       MSF_D32_ISSUE(q1, 1)
-      MSF_D32_ISSUE(q2, 2)
-      MSF_D32_ISSUE(q3, 3)
     }
     for (int n = 0; n < nsteps; n += kQDepth) {
       MSF_D32_STEP(q0, n)
       MSF_D32_STEP(q1, n + 1)
-      MSF_D32_STEP(q2, n + 2)
-      MSF_D32_STEP(q3, n + 3)
     }
+#undef MSF_D32_STEP
   };
-  if (ldwave) run(std::true_type{});
-  else run(std::false_type{});
+  if (st1) run(std::true_type{}, std::true_type{});                  // waves 0-3: stage 1, all of them loaders
+  else if (ldwave) run(std::true_type{}, std::false_type{});         // wave 4: stage 2 + the loader's last 40 threads
+  else run(std::false_type{}, std::false_type{});
 #undef MSF_D32_ISSUE
 #undef MSF_D32_COMMIT
-#undef MSF_D32_STEP
 }
 
 // ------------------------------------------------------------------ fused BasicBlock, 16 channels, split-bf16 MFMA
