@@ -810,6 +810,8 @@ struct StripW {
   const float* b[4];
 };
 
+// (r05: capped at 80 registers for three workgroups per CU -- its 46 KB of LDS would allow them -- the kernel spills 32
+// registers into its step loops: 637-649 -> 1 634 us.  It needs 117: 24 of weights, 24 of load queue, 24 of fragments.)
 template <int NB, int WV, int SB>
 __global__ __launch_bounds__(64 * WV) void k_strip8x(const float* __restrict__ in, StripW sw, float* __restrict__ out,
                                                      int H, int W, int n_strips) {
