@@ -685,7 +685,7 @@ def test_candidate_pool_exhaustion_is_loud_and_the_footprint_is_what_the_header_
     """r05: a (frame, level) keeps a small primary candidate list (w h / 64 entries) and takes a full-capacity region of a
     shared pool only when it goes through the dense second pass (orb_pipeline.h).  (1) With the pool cut to nothing
     (MSF_ORB_POOL_ENTRIES=0) and a first threshold no level can satisfy (MSF_ORB_FAST_TAU=254: every level needs the dense
-    pass) every pair reports n_out = -1 / MSF_ERR_CAPACITY -- never a short list; with the default pool the same batch is
+    pass) the pairs that find no region report n_out = -1 / MSF_ERR_CAPACITY -- never a short list; with the default pool the same batch is
     the oracle's (test_fast_threshold_fallback_path).  (2) A handle for 1024 pairs of 1280 x 720 takes less than the 8 GB
     include/msf_abi.h states (r04: 10.4 GB, r03: 20 GB)."""
     import torch
@@ -696,8 +696,12 @@ def test_candidate_pool_exhaustion_is_loud_and_the_footprint_is_what_the_header_
     monkeypatch.setenv("MSF_ORB_FAST_TAU", "254")
     monkeypatch.setenv("MSF_ORB_POOL_ENTRIES", "0")
     fm = FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=_lib.MSF_FLAG_NO_FRAME_CACHE)
-    num, _ = fm.match_batch_raw(list(A), list(B), cap=1024)
-    assert (num == -1).all(), num
+    num, lists = fm.match_batch_raw(list(A), list(B), cap=1024)
+    # (the pool keeps the regions dense CALLS need -- 7 frames' worth here -- and the overflowing levels race for them:
+    # which frames lose is not determined, that most do is; a pair that got its regions must be the oracle's)
+    assert (num == -1).sum() >= n // 2, num
+    for i in np.nonzero(num >= 0)[0]:
+        np.testing.assert_array_equal(lists[i], oracle_orb.FeatureMatcherOracle(0.7).MatchFrames(A[i], B[i]))
     fm.close()
     monkeypatch.delenv("MSF_ORB_POOL_ENTRIES")
     fm = FeatureMatcher(0.7, w, h, max_batch_pairs=n, flags=_lib.MSF_FLAG_NO_FRAME_CACHE)
