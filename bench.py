@@ -288,6 +288,45 @@ def opencv_probe(args, A, B, gpu_lists):
             "default_is_best": rank(default) == rank(best), "sweep": sweep}
 
 
+def two_handle_leg(args, matcher, fm, W, H, P, ratio_or_thr, local_rank, dev, dA, dB, out, cnt, packed, offs, side):
+    """NOT the headline: what a caller's double buffering adds.  A second handle with buffers and a stream of its own takes
+    every other step, so that the last round of workgroups of a step's kernels and its small tail kernels run beside the
+    other step's walker / strips (one handle's launches are a dependent chain on one stream: every kernel boundary drains
+    the chip).  Timed like the headline (same K, same barrier + synchronize bracket), in a region of its own after it;
+    stage times are not taken here -- a stage's HIP-event interval would contain the other handle's kernels -- which is
+    why `value`, `roofline` and the committed profiles stay with ONE handle."""
+    import torch
+    from mono_slam_framework_amd.matcher import DNNFeatureMatcher, FeatureMatcher
+    if matcher == "orb":
+        fm2 = FeatureMatcher(ratio_or_thr, W, H, device=local_rank, max_batch_pairs=P)
+    else:
+        fm2 = DNNFeatureMatcher(threshold=ratio_or_thr, device=local_rank, max_batch_pairs=P)
+    out2, cnt2, packed2, offs2 = torch.zeros_like(out), torch.zeros_like(cnt), torch.zeros_like(packed), torch.zeros_like(offs)
+    side2 = torch.cuda.Stream(device=dev)
+    lanes = ((fm, out, cnt, packed, offs, side), (fm2, out2, cnt2, packed2, offs2, side2))
+
+    def run(n):
+        for k in range(n):
+            h, o, c, pk, of, st = lanes[k & 1]
+            h.match_batch_device(dA, dB, o, c, stream=st.cuda_stream)
+            h.pack_matches_device(o, c, pk, of, stream=st.cuda_stream)
+
+    run(max(2, args.warmup))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    same = bool(torch.equal(cnt, cnt2) and torch.equal(offs, offs2) and torch.equal(packed, packed2))
+    fm.stage_times()
+    fm2.close()
+    del out2, cnt2, packed2, offs2
+    return {"value": round(P * args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 4), "steps": args.steps,
+            "handles": 2, "both_handles_identical_lists": same,
+            "note": "steps alternate between two handles on two streams (the caller's double buffering; nothing in the "
+                    "library); not the headline: `value` / `roofline` above are one handle, one stream"}
+
+
 def run_workload(args, matcher, W, H, P, ratio_or_thr, loftr_f32, rank, world, local_rank, dev, cdev, with_cpu):
     """One metric configuration: P synthetic pairs per GPU resident in HBM, `warmup` untimed + `steps` timed steps on a
     stream of its own.  Returns the result fields of one JSON line (rank 0) or None."""
@@ -471,6 +510,12 @@ def run_workload(args, matcher, W, H, P, ratio_or_thr, loftr_f32, rank, world, l
                                   ", pipelined: step k's gather on its own stream beside step k+1's kernels")},
             "roofline": roofline,
         }
+        if world == 1 and not args.no_two_handles and not loftr_f32:
+            try:
+                res["two_handles"] = two_handle_leg(args, matcher, fm, W, H, P, ratio_or_thr, local_rank, dev, dA, dB, out,
+                                                    cnt, packed, offs, side)
+            except Exception as e:      # an extra record: never at the price of the line
+                res["two_handles"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if with_cpu:
             cargs = argparse.Namespace(**vars(args))
             cargs.width, cargs.height, cargs.ratio, cargs.threshold = W, H, ratio_or_thr, ratio_or_thr
@@ -597,6 +642,8 @@ def main():
                     help="LoFTR: MSF_FLAG_LOFTR_F32 (every convolution on the f32 MFMA instead of split-bf16 products)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-two-handles", action="store_true",
+                    help="skip the extra `two_handles` record (steps alternating between two handles on two streams)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured configuration); gloo = rehearsal of the N > 1 code path "
                          "on a box with fewer GPUs than ranks (all ranks share cuda:0, results staged through host)")
@@ -659,6 +706,8 @@ def main():
                 "data": "synthetic", "config": r["config"], "roofline": r["roofline"]}
         if "cpu_baseline" in r:
             line["cpu_baseline"] = r["cpu_baseline"]
+        if "two_handles" in r:
+            line["two_handles"] = r["two_handles"]
         if secondary:
             # the two other configurations of BASELINE.json's metric, each run like the headline: same steps / warmup
             line["secondary"] = [dict(workload=x["config"]["workload"], unit="frame-pairs/sec", steps=args.steps,

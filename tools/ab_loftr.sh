@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of LoFTR bench variants on the GPU box: tools/ab_loftr.sh "NAME1:ENV=VAL ENV2=VAL" "NAME2:..." ...
 R=${GRAFT_REPO_ROOT:-/root/repo}
-ARGS=${AB_ARGS:---matcher loftr --steps 10 --warmup 3 --no-secondary --no-cpu-baseline}
+ARGS=${AB_ARGS:---matcher loftr --steps 10 --warmup 3 --no-secondary --no-cpu-baseline --no-two-handles}
 for spec in "$@"; do
   name=${spec%%:*}; envs=${spec#*:}
   out=$R/gpurun_out/abl_$name.json

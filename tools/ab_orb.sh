@@ -2,7 +2,7 @@
 # A/B of ORB bench variants on the GPU box: tools/ab_orb.sh "NAME1:ENV=VAL ENV2=VAL" "NAME2:..." ...
 # prints value, ms/step and the stage times of each variant (ORB 720p headline only, no CPU leg)
 R=${GRAFT_REPO_ROOT:-/root/repo}
-ARGS=${AB_ARGS:---steps 10 --warmup 3 --no-secondary --no-cpu-baseline}
+ARGS=${AB_ARGS:---steps 10 --warmup 3 --no-secondary --no-cpu-baseline --no-two-handles}
 for spec in "$@"; do
   name=${spec%%:*}; envs=${spec#*:}
   out=$R/gpurun_out/ab_$name.json

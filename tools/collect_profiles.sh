@@ -10,9 +10,9 @@ OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT
 mkdir -p $OUT
 cd /tmp
-ORB="--steps 5 --warmup 1 --no-cpu-baseline --no-secondary"
-VGA="--steps 5 --warmup 1 --no-cpu-baseline --no-secondary --width 640 --height 480 --pairs 4096"
-LOF="--matcher loftr --steps 5 --warmup 1 --no-cpu-baseline"
+ORB="--steps 5 --warmup 1 --no-cpu-baseline --no-two-handles --no-secondary"
+VGA="--steps 5 --warmup 1 --no-cpu-baseline --no-two-handles --no-secondary --width 640 --height 480 --pairs 4096"
+LOF="--matcher loftr --steps 5 --warmup 1 --no-cpu-baseline --no-two-handles"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/orb_stats -- python3 $R/bench.py $ORB > $OUT/orb_stats.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/loftr_stats -- python3 $R/bench.py $LOF > $OUT/loftr_stats.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/orb_fetch -- python3 $R/bench.py $ORB > $OUT/orb_fetch.log 2>&1 || exit 1

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/pmc_loftr
 rm -rf $OUT; mkdir -p $OUT
-ARGS="--matcher loftr --steps 2 --warmup 1 --no-cpu-baseline"
+ARGS="--matcher loftr --steps 2 --warmup 1 --no-cpu-baseline --no-two-handles"
 cd /tmp
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py $ARGS > $OUT/fetch.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py $ARGS > $OUT/write.log 2>&1 || exit 1

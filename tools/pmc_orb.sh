@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/pmc_orb
-ARGS="--steps 2 --warmup 1 --pairs ${PAIRS:-256} --no-cpu-baseline"
+ARGS="--steps 2 --warmup 1 --pairs ${PAIRS:-256} --no-cpu-baseline --no-two-handles"
 cd /tmp
 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/fetch -- python3 $R/bench.py $ARGS > $OUT.fetch.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/write -- python3 $R/bench.py $ARGS > $OUT.write.log 2>&1 || exit 1

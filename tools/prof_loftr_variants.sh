@@ -9,7 +9,7 @@ for spec in "$@"; do
   out=$R/gpurun_out/pv_$name
   rm -rf $out
   if [ "$lib" != "-" ]; then export MSF_LIB_PATH=$lib; else unset MSF_LIB_PATH; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $R/bench.py ${PROF_ARGS:---matcher loftr --steps 5 --warmup 1 --no-cpu-baseline} > $out.log 2>&1 || { echo "$name FAILED"; tail -3 $out.log; continue; }
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $R/bench.py ${PROF_ARGS:---matcher loftr --steps 5 --warmup 1 --no-cpu-baseline --no-two-handles} > $out.log 2>&1 || { echo "$name FAILED"; tail -3 $out.log; continue; }
   f=$(find $out -name '*kernel_stats.csv' | head -1)
   echo "== $name"
   python3 - "$f" "${PROF_FILTER:-strip|down|convx|k_conv}" <<'PY'

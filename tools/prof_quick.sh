@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/profq_$TAG
 rm -rf $OUT
 mkdir -p $OUT
 cd /tmp
-if [ "$LEG" = loftr ]; then ARGS="--matcher loftr --steps 5 --warmup 1 --no-cpu-baseline"; else ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-secondary"; fi
+if [ "$LEG" = loftr ]; then ARGS="--matcher loftr --steps 5 --warmup 1 --no-cpu-baseline --no-two-handles"; else ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-two-handles --no-secondary"; fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py $ARGS > $OUT/bench.log 2>&1 || exit 1
 F=$(find $OUT/stats -name '*kernel_stats.csv' | head -1)
 python3 - "$F" <<'PY' > $OUT/summary.txt

@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/proft_$TAG
 rm -rf $OUT; mkdir -p $OUT
 for kv in "$@"; do export "$kv"; done
 cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/tr -- python3 $R/bench.py ${PT_ARGS:---steps 4 --warmup 1 --no-cpu-baseline --no-secondary} > $OUT/bench.log 2>&1 || { tail -5 $OUT/bench.log; exit 1; }
+rocprofv3 --kernel-trace --output-format csv -d $OUT/tr -- python3 $R/bench.py ${PT_ARGS:---steps 4 --warmup 1 --no-cpu-baseline --no-two-handles --no-secondary} > $OUT/bench.log 2>&1 || { tail -5 $OUT/bench.log; exit 1; }
 F=$(find $OUT/tr -name '*kernel_trace.csv' | head -1)
 python3 - "$F" <<'PY' > $OUT/summary.txt
 import csv, sys, collections
