@@ -2844,6 +2844,53 @@ __global__ __launch_bounds__(256) void k_tokens(const float* __restrict__ bb, co
   }
 }
 
+// r05: the backbone's last convolution (1 x 1, 32 -> 32, no ReLU) + positional encoding + 'n c h w -> n (h w) c' in ONE pass:
+// k_conv<32, 32, 1, 1> wrote its result as NCHW and k_tokens read it back to transpose it (two launches per side, 0.16 GB
+// written and read per 512 images for 20 MFLOP per image).  A workgroup takes 64 tokens of one image -- 32 channels x 256
+// contiguous bytes in, as k_tokens did -- and runs the product TRANSPOSED (A = weights, B = tokens): a lane then holds four
+// consecutive output channels of one token, i.e. one 16-byte store into the token's 128-byte row.  Same f32 MFMA chain in
+// the same k order as k_conv (operands swapped, products and their order unchanged), then + bias, then + PE, as the two
+// kernels did: bit-identical (MSF_LOFTR_OUT_FUSED=0 keeps the two-kernel tail; tests compare).
+__global__ __launch_bounds__(256) void k_out_tokens(const float* __restrict__ act /*[img][32][NTOK]*/, const float* __restrict__ wB,
+                                                    const float* __restrict__ bias, const float* __restrict__ pe,
+                                                    float* __restrict__ tok_a, int n_a, float* __restrict__ tok_b, int n_img) {
+  __shared__ float xt[DM][kTokTile + 1], pt[DM][kTokTile + 1];
+  const int img = blockIdx.y, t0 = blockIdx.x * kTokTile, tid = threadIdx.x;
+  if (img >= n_img) return;
+  const int lane = tid & 63, wave = tid >> 6, i = lane & 15, kq = lane >> 4;
+  const float* src = act + (long long)img * DM * NTOK;
+  float wf[DM / 4][2];                         // weight fragments: k step s, output-channel tile mt
+#pragma unroll
+  for (int sI = 0; sI < DM / 4; sI++)
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) wf[sI][mt] = wB[(sI * 4 + kq) * DM + mt * 16 + i];
+#pragma unroll
+  for (int k = 0; k < DM * kTokTile / 256; k++) {
+    const int e = k * 256 + tid, c = e / kTokTile, t = e - c * kTokTile;
+    const bool ok = t0 + t < NTOK;
+    xt[c][t] = ok ? src[(long long)c * NTOK + t0 + t] : 0.f;
+    pt[c][t] = ok ? pe[c * NTOK + t0 + t] : 0.f;
+  }
+  __syncthreads();
+  const int tl = 16 * wave + i;                // this lane's token inside the tile
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int sI = 0; sI < DM / 4; sI++) {
+    const float b = xt[sI * 4 + kq][tl];
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[sI][mt], b, acc[mt], 0, 0, 0);
+  }
+  if (t0 + tl >= NTOK) return;
+  float* dst = (img < n_a ? tok_a + (long long)img * NTOK * DM : tok_b + (long long)(img - n_a) * NTOK * DM) + (long long)(t0 + tl) * DM;
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++) {
+    const int co = 16 * mt + 4 * kq;           // D[row = channel 4 kq + r of the tile][col = token i]
+    f32x4 v = acc[mt] + (bias ? *reinterpret_cast<const f32x4*>(bias + co) : f32x4{0.f, 0.f, 0.f, 0.f});
+    v += f32x4{pt[co][tl], pt[co + 1][tl], pt[co + 2][tl], pt[co + 3][tl]};
+    *reinterpret_cast<f32x4*>(dst + co) = v;
+  }
+}
+
 // ------------------------------------------------------------------ linear-attention encoder block (MFMA)
 // All products of a block are 16-wide tiles of v_mfma_f32_16x16x4_f32 (exact f32).  Two k-slot orders let every
 // operand be used where it already is, with no transposes and no LDS round trips for activations:
@@ -4071,6 +4118,7 @@ struct LoftrPipeline::Impl {
   float* cpart = nullptr;    // [max_pairs][25][1200] column-sum partials
   float* rpart = nullptr;    // [max_pairs][3][1200] row-sum partials (one per third of the columns)
   uint32_t* sim_redo = nullptr;   // [max_pairs] pairs whose single-pass sums left the f32 range
+  bool out_fused = true;     // MSF_LOFTR_OUT_FUSED=0: the 1 x 1 output convolution and the token kernel as two passes (tests compare: identical)
   bool attn_pair = true;     // MSF_LOFTR_ATTN_PAIR=0: one launch per encoder block (tests compare: identical results)
   bool sim_single = true;    // MSF_LOFTR_SIM_SINGLE=0: the two running-maximum passes always
   bool sim_force_redo = false;    // MSF_LOFTR_SIM_FORCE_REDO=1 (tests): every pair takes the fallback
@@ -4161,6 +4209,7 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
     if (const char* d = getenv("MSF_LOFTR_DENSE_HEAD")) P.dense_head = atoi(d) != 0;   // tests: force the dense head
     if (const char* d = getenv("MSF_LOFTR_SIM_SINGLE")) P.sim_single = atoi(d) != 0;
     if (const char* d = getenv("MSF_LOFTR_ATTN_PAIR")) P.attn_pair = atoi(d) != 0;
+    if (const char* d = getenv("MSF_LOFTR_OUT_FUSED")) P.out_fused = atoi(d) != 0;
     if (const char* d = getenv("MSF_LOFTR_SIM_FORCE_REDO")) P.sim_force_redo = atoi(d) != 0;
     if (const char* d = getenv("MSF_LOFTR_UNFUSED")) P.fuse_blocks = atoi(d) == 0;
     P.split_bf16 = !f32_convs;
@@ -4862,8 +4911,12 @@ void run_backbone(LoftrPipeline::Impl& P, const uint8_t* srcA, int nA, float* to
     launch_conv<32, 32, 3, 1, 16, true, true, false>(c[19], b, s40, 0, cc, a, ni, st);             // a = 244
   }
   keep(3, a, 32u * 30 * 40, false);
-  launch_conv<32, 32, 1, 1, 16, false, false, false>(c[20], a, s40, 0, nullptr, b, ni, st);      // b = 245
   const int tok_tiles = (NTOK + kTokTile - 1) / kTokTile;
+  if (P.out_fused) {
+    hipLaunchKernelGGL(k_out_tokens, dim3(tok_tiles, ni), dim3(256), 0, st, a, c[20].d_w, c[20].d_b, P.d_pe, tokA, nA, tokB, ni);
+    return;
+  }
+  launch_conv<32, 32, 1, 1, 16, false, false, false>(c[20], a, s40, 0, nullptr, b, ni, st);      // b = 245
   if (nA) hipLaunchKernelGGL(k_tokens, dim3(tok_tiles, nA), dim3(256), 0, st, b, P.d_pe, tokA, nA);
   if (nB) hipLaunchKernelGGL(k_tokens, dim3(tok_tiles, nB), dim3(256), 0, st, b + (long long)nA * 32LL * 30 * 40, P.d_pe, tokB, nB);
 }

@@ -339,6 +339,19 @@ def test_single_pass_statistics_equal_the_running_maximum_passes(monkeypatch):
     assert total > 3000
 
 
+def test_fused_output_convolution_and_tokens_equal_the_two_kernel_tail():
+    """r05: the backbone's 1 x 1 output convolution, the positional encoding and the n c h w -> n (h w) c transpose run as
+    one kernel (k_out_tokens) instead of k_conv<32, 32, 1, 1> + k_tokens: the same f32 MFMA chain in the same k order with
+    the operands swapped, the same two adds behind it.  Confidences, features and the list are bit-identical to the
+    two-kernel tail (MSF_LOFTR_OUT_FUSED=0) -- single pair (banded backbone) and the exact-f32 path alike."""
+    for extra in ({}, {"MSF_LOFTR_F32": "1"}):
+        outs = [_run_child(dict(extra, MSF_LOFTR_OUT_FUSED=u)) for u in ("1", "0")]
+        assert len(outs[0]["m"]) > 20
+        np.testing.assert_array_equal(outs[0]["m"], outs[1]["m"])
+        np.testing.assert_array_equal(outs[0]["feat"].view(np.uint32), outs[1]["feat"].view(np.uint32))
+        np.testing.assert_array_equal(outs[0]["conf"].view(np.uint32), outs[1]["conf"].view(np.uint32))
+
+
 def test_paired_attention_launches_equal_one_launch_per_block():
     """r05: the two self-attention blocks of a layer pair (feat0 <- feat0, feat1 <- feat1) run as ONE launch of each
     attention kernel (12 launches per call instead of 16).  Same arithmetic, other grid: confidences, features and the
