@@ -3119,6 +3119,48 @@ __device__ __forceinline__ f32x4 mfma3x(bf16x8 wh, bf16x8 wl, bf16x8 xh, bf16x8 
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, c, 0, 0, 0);
 }
 
+// The split-bf16 encoder kernels are bound by vector issue (0.74 VALU-busy), and a third of their vector instructions were
+// IEEE divisions and libm's expf: a LayerNorm divided each of its 8 values per lane by the standard deviation (ten
+// instructions per correctly rounded division), V was divided by 1200 value by value, ELU went through expf's range
+// reduction.  The fast forms below multiply by ONE correctly rounded reciprocal and take the exponential as v_exp_f32 of
+// x log2(e): each result within 1-2 ulp of the exact form's (the exact-f32 kernels k_attn_kv / k_attn_update keep the
+// graph's operations one for one); the conv stack's split products are the larger error by far.
+// features / sqrt(32) as a product with the rounded reciprocal (the split path's fused form in k_attn_update_x; the exact-f32
+// path's k_scale_feats divides)
+constexpr float kInvSqrtDM = 1.0f / 5.656854f;
+// quad_sum on v_permlane16_swap / v_permlane32_swap: the same two additions in the same order (bit-identical) without the
+// two LDS round trips of the shuffles, which sat in the dependent chain of every LayerNorm and normaliser
+__device__ __forceinline__ float quad_sum_pl(float v) {
+  const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);               // lanes l and l ^ 16
+  const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);            // ... and l ^ 32
+}
+__device__ __forceinline__ float elu1_fast(float x) {
+  return (x > 0.f ? x : __builtin_amdgcn_exp2f(x * 1.44269504089f) - 1.f) + 1.f;
+}
+__device__ __forceinline__ void layer_norm_cols_fast(f32x4* v, const float* w, const float* b, int g) {
+  float sum = 0.f;
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) sum += v[m][r];
+  const float mean = quad_sum_pl(sum) * (1.f / (float)DM);            // (a power of two: the same value as the division)
+  float var = 0.f;
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { v[m][r] -= mean; var += v[m][r] * v[m][r]; }
+  const float rden = 1.0f / sqrtf(quad_sum_pl(var) * (1.f / (float)DM) + 1.0000000116860974e-07f);
+#pragma unroll
+  for (int m = 0; m < 2; m++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int f = 16 * m + 4 * g + r;
+      v[m][r] = v[m][r] * rden * w[f] + b[f];
+    }
+}
+
 // r05: a launch may carry TWO independent encoder blocks (the two self-attention blocks of a layer pair: feat0 <- feat0 and
 // feat1 <- feat1): workgroups [0, n_first) work on (src, w, kv), the rest on (src2, w2, kv2); n_first = gridDim.x: one block.
 __global__ __launch_bounds__(64 * kKvWaves) void k_attn_kv_x(const float* __restrict__ src_a, long long seq_stride, BlockW w_a,
@@ -3187,8 +3229,8 @@ __global__ __launch_bounds__(64 * kKvWaves) void k_attn_kv_x(const float* __rest
           const f32x4 V = mfma3x(xh, xl, sWv[(n * 2 + 0) * 64 + lane], sWv[(n * 2 + 1) * 64 + lane], zero);
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            Kv[n][4 * h + r] = elu1(K[r]);
-            Vv[n][4 * h + r] = V[r] / 1200.0f;
+            Kv[n][4 * h + r] = elu1_fast(K[r]);
+            Vv[n][4 * h + r] = V[r] * (1.0f / 1200.0f);
             ksum[n] += Kv[n][4 * h + r];
           }
         }
@@ -3215,7 +3257,7 @@ __global__ __launch_bounds__(64 * kKvWaves) void k_attn_kv_x(const float* __rest
       for (int r = 0; r < 4; r++) red[wave][(16 * m + 4 * g + r) * DM + 16 * n + tl] = acc[m][n][r];
 #pragma unroll
   for (int n = 0; n < 2; n++) {
-    const float t = quad_sum(ksum[n]);
+    const float t = quad_sum_pl(ksum[n]);
     if (g == 0) red[wave][DM * DM + 16 * n + tl] = t;
   }
   __syncthreads();
@@ -3305,11 +3347,11 @@ __global__ __launch_bounds__(256) void k_attn_update_x(const float* __restrict__
       const f32x4 q = mfma3x(sWq[(m * 2 + 0) * 64 + lane], sWq[(m * 2 + 1) * 64 + lane], xh, xl, zero);
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        qv[4 * m + r] = elu1(q[r]);
+        qv[4 * m + r] = elu1_fast(q[r]);
         zp += qv[4 * m + r] * sKs[16 * m + 4 * g + r];
       }
     }
-    const float z = 1.0f / (quad_sum(zp) + 9.999999974752427e-07f);
+    const float z = 1.0f / (quad_sum_pl(zp) + 9.999999974752427e-07f);
     bf16x8 qh, ql;
     split8(qv, qh, ql);
     // msg = (KV^T Q) * Z * 1200
@@ -3326,7 +3368,7 @@ __global__ __launch_bounds__(256) void k_attn_update_x(const float* __restrict__
     f32x4 mg[2];
 #pragma unroll
     for (int m = 0; m < 2; m++) mg[m] = mfma3x(sWm[(m * 2 + 0) * 64 + lane], sWm[(m * 2 + 1) * 64 + lane], mh, ml, zero);
-    layer_norm_cols(mg, sLN, sLN + DM, g);
+    layer_norm_cols_fast(mg, sLN, sLN + DM, g);
     const float mgv[8] = {mg[0][0], mg[0][1], mg[0][2], mg[0][3], mg[1][0], mg[1][1], mg[1][2], mg[1][3]};
     bf16x8 gh, gl;
     split8(mgv, gh, gl);
@@ -3348,14 +3390,14 @@ __global__ __launch_bounds__(256) void k_attn_update_x(const float* __restrict__
       o[m] = mfma3x(sW1[((m * 2 + 0) * 2 + 0) * 64 + lane], sW1[((m * 2 + 0) * 2 + 1) * 64 + lane], h0h, h0l, zero);
       o[m] = mfma3x(sW1[((m * 2 + 1) * 2 + 0) * 64 + lane], sW1[((m * 2 + 1) * 2 + 1) * 64 + lane], h1h, h1l, o[m]);
     }
-    layer_norm_cols(o, sLN + 2 * DM, sLN + 3 * DM, g);
+    layer_norm_cols_fast(o, sLN + 2 * DM, sLN + 3 * DM, g);
     float* dr = dst + (long long)seq * d_stride + (long long)(tile * 16 + tl) * DM;
     const f32x4 r0 = xd0 + o[0], r1 = xd1 + o[1];
     *reinterpret_cast<f32x4*>(dr + 4 * g) = r0;
     *reinterpret_cast<f32x4*>(dr + 16 + 4 * g) = r1;
     if (fs_out) {
-      // the last block of a side: the matching head's inputs leave here as well (what k_scale_feats makes of dst: the
-      // features / sqrt(32) and their three bf16 planes, the same expressions on the same values)
+      // the last block of a side: the matching head's inputs leave here as well (what k_scale_feats makes of dst in the
+      // exact-f32 path: the features / sqrt(32) -- here times the rounded reciprocal -- and their three bf16 planes)
       const long long e0 = (long long)(tile * 16 + tl) * DM;
       float* fr = fs_out + (long long)seq * d_stride + e0;
       __bf16* pr = pl_out + (long long)seq * 3 * d_stride + e0;
@@ -3365,7 +3407,7 @@ __global__ __launch_bounds__(256) void k_attn_update_x(const float* __restrict__
       bf16x4_t ph[2], pm[2], pl[2];
 #pragma unroll
       for (int q = 0; q < 8; q++) {
-        const float v = rv[q] / 5.656854f;
+        const float v = rv[q] * kInvSqrtDM;
         sv[q] = v;
         const __bf16 h = (__bf16)v;
         const float e1 = v - (float)h;
