@@ -13,8 +13,11 @@ HIP_SOURCES = ["msf_abi.cpp", "msf_multi.cpp", "msf_gather.cpp", "weights_io.cpp
                "ransac_kernels.hip"]
 # -ffp-contract=off + correctly rounded f32 divide: the few f32 steps inside ORB
 # (Harris response, fastAtan2, pattern rotation) must round exactly like the CPU.
+# -mllvm -amdgpu-mfma-vgpr-form: MFMA results straight into VGPRs (the default put the accumulators of k_attn_update_x and
+# the similarity kernels into AGPRs and copied them out with 12-52 v_accvgpr_read_b32 per tile; no kernel is near 256 VGPRs).
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-             "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+             "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-mllvm", "-amdgpu-mfma-vgpr-form",
+             "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 
 def _stale(target, deps):

@@ -567,12 +567,14 @@ __device__ __forceinline__ u32x4v sx_ld(const void* base, uint32_t off) {      /
 }
 // a producer lane's four channels 4 half .. 4 half + 3 of pixel (y, x), channel block cb: hi and lo halves
 __device__ __forceinline__ void sx_st4(void* base, int y, int cb, int x, int half, int W, int CB, f32x4 v);
-__device__ __forceinline__ void split4(f32x4 v, bf16x4& vh, bf16x4& vl) {   // 12 instructions for four values
+__device__ __forceinline__ void split4(f32x4 v, bf16x4& vh, bf16x4& vl) {   // 10-12 instructions for four values
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
   const uint32_t h0 = cvt_pk_bf16(v.x, v.y), h1 = cvt_pk_bf16(v.z, v.w);
-  const float rx = v.x - __uint_as_float(h0 << 16), ry = v.y - __uint_as_float(h0 & 0xffff0000u);
-  const float rz = v.z - __uint_as_float(h1 << 16), rw = v.w - __uint_as_float(h1 & 0xffff0000u);
+  // the remainders as two-wide subtractions (v_pk_add_f32 with negated operands where the register pairs allow)
+  const f32x2v r0 = f32x2v{v.x, v.y} - f32x2v{__uint_as_float(h0 << 16), __uint_as_float(h0 & 0xffff0000u)};
+  const f32x2v r1 = f32x2v{v.z, v.w} - f32x2v{__uint_as_float(h1 << 16), __uint_as_float(h1 & 0xffff0000u)};
   vh = __builtin_bit_cast(bf16x4, u32x2v{h0, h1});
-  vl = __builtin_bit_cast(bf16x4, u32x2v{cvt_pk_bf16(rx, ry), cvt_pk_bf16(rz, rw)});
+  vl = __builtin_bit_cast(bf16x4, u32x2v{cvt_pk_bf16(r0.x, r0.y), cvt_pk_bf16(r1.x, r1.y)});
 }
 __device__ __forceinline__ void sx_st4(void* base, int y, int cb, int x, int half, int W, int CB, f32x4 v) {
   bf16x4 vh, vl;
@@ -3379,7 +3381,8 @@ __global__ __launch_bounds__(256) void k_attn_update_x(const float* __restrict__
       f32x4 t = mfma3x(sW0[((m * 2 + 0) * 2 + 0) * 64 + lane], sW0[((m * 2 + 0) * 2 + 1) * 64 + lane], xh, xl, zero);
       t = mfma3x(sW0[((m * 2 + 1) * 2 + 0) * 64 + lane], sW0[((m * 2 + 1) * 2 + 1) * 64 + lane], gh, gl, t);
 #pragma unroll
-      for (int r = 0; r < 4; r++) hv[4 * m + r] = fmaxf(t[r], 0.f);
+      for (int r = 0; r < 4; r++)      // ReLU as a signed-integer maximum: a float maximum of an MFMA result costs a second v_max_f32 (NaN quieting)
+        hv[4 * m + r] = __int_as_float(max(__float_as_int(t[r]), 0));
     }
     bf16x8 h0h, h0l, h1h, h1l;
     split8(hv, h0h, h0l);

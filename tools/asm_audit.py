@@ -18,7 +18,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "mono_slam_framework_amd", "csrc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
-         "-fno-fast-math", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "--cuda-device-only", "-S"]
+         "-fno-fast-math", "-mllvm", "-amdgpu-mfma-vgpr-form", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "--cuda-device-only", "-S"]
 
 
 def hipcc():
