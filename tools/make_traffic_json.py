@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 # check and the dense redo
 STAGE = {"k_resize": "pyramid", "k_fast": "fast_nms", "k_walk": "pyramid_fast",
          "k_fast_check": "fast_nms", "k_fast_redo": "fast_nms", "k_thr_harris": "select_harris", "k_select": "select_harris",
-         "k_describe": "orient_describe", "k_match": "match", "k_conv": "backbone_convs", "k_tokens": "backbone_convs",
+         "k_describe": "orient_describe", "k_match": "match", "k_conv": "backbone_convs", "k_tokens": "backbone_convs", "k_out_tokens": "backbone_convs",
          "k_block8": "backbone_convs", "k_block16": "backbone_convs", "k_block8x": "backbone_convs",
          "k_block16x": "backbone_convs", "k_convx": "backbone_convs", "k_down16x": "backbone_convs",
          "k_strip8x": "backbone_convs", "k_stem_strip8x": "backbone_convs", "k_convx2": "backbone_convs", "k_strip16x": "backbone_convs", "k_strip32x": "backbone_convs",
