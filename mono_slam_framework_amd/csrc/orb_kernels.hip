@@ -1920,20 +1920,30 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
     const msf_keypoint* Kp = kp + (long long)slot * kKpCap + k_;
     return make_uint3((uint32_t)Kp->octave, (uint32_t)Kp->lx, (uint32_t)Kp->ly);
   };
+  // A wave walks ONE key point at a time: level and position are the same in every lane (they come from one address), and
+  // as scalars the patch is  s[base] + 32-bit lane offset  per load -- row r = i / 12 by a multiply-shift (exact for
+  // i < 576: 43691 = ceil(2^19 / 12)), offset r (pitch - 48) + 4 i.  (r04 formed r, the column and a 64-bit address per
+  // lane and load: 105 of the ~510 vector instructions per key point of a kernel that is 0.82 VALU-busy.)
   auto issue = [&](uint3 m) {
-    const int pitch_ = lvl_pitch_s[m.x];
+    const uint32_t lv = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.x);
+    const int mx = __builtin_amdgcn_readfirstlane((int)m.y), my = __builtin_amdgcn_readfirstlane((int)m.z);
+    const uint32_t pitch_ = (uint32_t)__builtin_amdgcn_readfirstlane(lvl_pitch_s[lv]);
+    const unsigned long long b64 = lvl_base_s[lv];
+    const unsigned long long img_ = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b64 >> 32)) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64);
     typedef const __attribute__((address_space(1))) uint8_t* gptr_t;   // global, not generic: a flat load counts as an LDS op too
-    gptr_t img_ = (gptr_t)lvl_base_s[m.x];
     // raw patch, radius 22, fetched as aligned dwords: columns ax .. ax+47 hold x = cx-22 .. cx+22 at byte
     // offset xo (keypoints sit >= 31 px inside the level, so this never leaves the row)
-    const int ax = ((int)m.y - PR) & ~3;
-    xo_pre = ((int)m.y - PR) - ax;
-    gptr_t base = img_ + (long long)((int)m.z - PR) * pitch_ + ax;
+    const int ax = (mx - PR) & ~3;
+    xo_pre = (mx - PR) - ax;
+    gptr_t base = (gptr_t)(img_ + (unsigned long long)((long long)(my - PR) * (long long)pitch_ + ax));
+    const uint32_t pm = pitch_ - (uint32_t)PP;
 #pragma unroll
     for (int u = 0; u < NPL; u++) {
-      const int i = lane + 64 * u;
-      const int r = i / (PP / 4), c = i % (PP / 4);
-      pre[u] = i < PD * (PP / 4) ? *(const __attribute__((address_space(1))) uint32_t*)(base + (long long)r * pitch_ + 4 * c) : 0u;
+      const uint32_t i = (uint32_t)lane + 64u * (uint32_t)u;
+      const uint32_t r = (i * 43691u) >> 19;
+      const uint32_t off = mad_u24(r, pm, 4u * i);
+      pre[u] = i < (uint32_t)(PD * (PP / 4)) ? *(const __attribute__((address_space(1))) uint32_t*)(base + off) : 0u;
     }
   };
   // row blur: lane -> (row pair rl within a block of six, column group gq); dword offsets of its reads and writes
