@@ -1886,7 +1886,7 @@ __global__ __launch_bounds__(256) void k_describe(OrbGeometry g, FrameSrc src, c
   // memory latency (6 us per key point and wave; the kernel was bound by neither its bytes nor its instructions)
   __shared__ __attribute__((aligned(16))) int pat_s[256];
   const int fi = blockIdx.y, slot = src.slot0 + fi;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // (scalar: key-point indices and record addresses are then scalar too)
   for (int i = threadIdx.x; i < 2 * kDiscTasks; i += 256) disc_s[i] = c_disc[i];
   pat_s[threadIdx.x] = reinterpret_cast<const int*>(c_pattern)[threadIdx.x];
   // base pointer and pitch of this frame's levels: the level of a key point is a vector register to the compiler, and the
