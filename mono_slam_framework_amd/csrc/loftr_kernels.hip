@@ -3125,7 +3125,7 @@ __device__ __forceinline__ f32x4 mfma3x(bf16x8 wh, bf16x8 wl, bf16x8 xh, bf16x8 
 // IEEE divisions and libm's expf: a LayerNorm divided each of its 8 values per lane by the standard deviation (ten
 // instructions per correctly rounded division), V was divided by 1200 value by value, ELU went through expf's range
 // reduction.  The fast forms below multiply by ONE correctly rounded reciprocal and take the exponential as v_exp_f32 of
-// x log2(e): each result within 1-2 ulp of the exact form's (the exact-f32 kernels k_attn_kv / k_attn_update keep the
+// x log2(e), the normalisers as v_rsq_f32 / v_rcp_f32: each result within 1-2 ulp of the exact form's (the exact-f32 kernels k_attn_kv / k_attn_update keep the
 // graph's operations one for one); the conv stack's split products are the larger error by far.
 // features / sqrt(32) as a product with the rounded reciprocal (the split path's fused form in k_attn_update_x; the exact-f32
 // path's k_scale_feats divides)
@@ -3153,7 +3153,8 @@ __device__ __forceinline__ void layer_norm_cols_fast(f32x4* v, const float* w, c
   for (int m = 0; m < 2; m++)
 #pragma unroll
     for (int r = 0; r < 4; r++) { v[m][r] -= mean; var += v[m][r] * v[m][r]; }
-  const float rden = 1.0f / sqrtf(quad_sum_pl(var) * (1.f / (float)DM) + 1.0000000116860974e-07f);
+  // v_rsq_f32 (1 ulp) for the correctly rounded square root and division: twenty instructions fewer per LayerNorm
+  const float rden = __builtin_amdgcn_rsqf(quad_sum_pl(var) * (1.f / (float)DM) + 1.0000000116860974e-07f);
 #pragma unroll
   for (int m = 0; m < 2; m++)
 #pragma unroll
@@ -3353,7 +3354,7 @@ __global__ __launch_bounds__(256) void k_attn_update_x(const float* __restrict__
         zp += qv[4 * m + r] * sKs[16 * m + 4 * g + r];
       }
     }
-    const float z = 1.0f / (quad_sum_pl(zp) + 9.999999974752427e-07f);
+    const float z = __builtin_amdgcn_rcpf(quad_sum_pl(zp) + 9.999999974752427e-07f);      // v_rcp_f32 (1 ulp)
     bf16x8 qh, ql;
     split8(qv, qh, ql);
     // msg = (KV^T Q) * Z * 1200
