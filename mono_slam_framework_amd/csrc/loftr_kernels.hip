@@ -3724,6 +3724,25 @@ __global__ __launch_bounds__(64 * kSimWaves) void k_sim_stats3(const __bf16* __r
 // flagged pair is redone by the running-maximum passes (which skip every other pair).  Sums in a fixed order: a wave
 // owns three row tiles over a third of the column tiles, leaves its row sums in rpart[pair][third][1200] and its column
 // partials in cpart[pair][triple 0..24][1200]; k_sim_finish adds the 3 and the 25 in order.  Deterministic, no atomics.
+// r05: k_sim_single leaves, per item and column tile, the largest dot product d of the tile's 48 x 16 entries (as an
+// order-preserving integer key); k_sim_cand3 -- the same items over the same tiles -- then evaluates only the tiles whose
+// maximum can reach the smallest candidate limit of its rows.  A candidate needs d >= ld(row); the two kernels sum the same
+// six products in another order, so their d differ by a few ulp: a tile is skipped only if its maximum is more than 1e-5
+// below the smallest limit.  With ~100 matches per pair four tiles in five hold no candidate.
+__device__ __forceinline__ int f32_order_key(float v) {      // a < b  <=>  key(a) < key(b) as signed integers
+  const int b = __float_as_int(v);
+  return b ^ ((b >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));     // quad_perm [1,0,3,2]: lane ^ 1
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]: lane ^ 2
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));    // row_half_mirror: the other quad of the 8
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));    // row_mirror: the other 8 of the 16
+  const auto r16 = __builtin_amdgcn_permlane16_swap((uint32_t)v, (uint32_t)v, false, false);
+  v = max((int)r16[0], (int)r16[1]);
+  const auto r32 = __builtin_amdgcn_permlane32_swap((uint32_t)v, (uint32_t)v, false, false);
+  return max((int)r32[0], (int)r32[1]);
+}
 constexpr int kSimParts = NTOK / 16 / kSimRT;         // 25 row-tile triples per pair
 #define MSF_LOFTR_SIM_COLPARTS 3
 constexpr int kSimColParts = MSF_LOFTR_SIM_COLPARTS;  // an item covers 1 / kSimColParts of the column tiles (1, 3, 5 measured)
@@ -3767,7 +3786,7 @@ __global__ __launch_bounds__(256) void k_pair_bound(const float* __restrict__ f0
 __global__ __launch_bounds__(64 * kSimItemWaves) void k_sim_single(const __bf16* __restrict__ pa, const __bf16* __restrict__ pb,
                                                                long long pair_stride, const float* __restrict__ gbound,
                                                                float* __restrict__ rpart, float* __restrict__ cpart,
-                                                               int n_items) {
+                                                               int n_items, int* __restrict__ tmax) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tl = lane & 15, g = lane >> 4;
   const int item = blockIdx.x * kSimItemWaves + wave;
   if (item >= n_items) return;
@@ -3806,6 +3825,7 @@ __global__ __launch_bounds__(64 * kSimItemWaves) void k_sim_single(const __bf16*
 #pragma unroll
     for (int pl = 0; pl < 3; pl++) bn[pl] = PB[pl * kPlane + (jn * 16 + tl) * (DM / 8) + g];
     float col = 0.f;
+    float dmax = -INFINITY;
 #pragma unroll
     for (int t = 0; t < kSimRT; t++) {
       f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -3821,6 +3841,11 @@ __global__ __launch_bounds__(64 * kSimItemWaves) void k_sim_single(const __bf16*
         rs[t][r] += e;
         col += e;
       }
+      dmax = fmaxf(dmax, fmaxf(fmaxf(d[0], d[1]), fmaxf(d[2], d[3])));
+    }
+    if (tmax) {                                   // (uniform) the tile's largest d, for k_sim_cand3's skip
+      const int km = wave_max_i32(f32_order_key(dmax));
+      if (lane == 0) tmax[(long long)item * kSimColTiles + (jt - jt_lo)] = km;
     }
     // this lane's column jt * 16 + tl over the 12 rows it holds; the other three lane groups hold the other rows
     // (v_permlane16/32_swap: the cross-row sums stay in the VALU; as shuffles they are two LDS round trips per column
@@ -3886,7 +3911,8 @@ constexpr int kCandBuf = 512;                         // entries per wave; a ste
 __global__ __launch_bounds__(64 * kSimItemWaves) void k_sim_cand3(const __bf16* __restrict__ pa, const __bf16* __restrict__ pb,
                                                               long long pair_stride, const float* __restrict__ lim,
                                                               SimCand* __restrict__ cand, uint32_t* __restrict__ cand_cnt,
-                                                              const uint32_t* __restrict__ skip_if, int n_items) {
+                                                              const uint32_t* __restrict__ skip_if, int n_items,
+                                                              const int* __restrict__ tmax) {
   __shared__ SimCand buf_s[kSimItemWaves][kCandBuf];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tl = lane & 15, g = lane >> 4;
   const int item = blockIdx.x * kSimItemWaves + wave;
@@ -3925,13 +3951,30 @@ __global__ __launch_bounds__(64 * kSimItemWaves) void k_sim_cand3(const __bf16* 
   };
   bf16x8 bn[3];
   const int jt_lo = zpart * kSimColTiles, jt_hi = jt_lo + kSimColTiles;            // a third of the columns (see k_sim_single)
+  // the column tiles this item has to look at: all of them, or (tmax) those whose largest d can reach the smallest limit
+  // of the item's 48 rows
+  static_assert(kSimColTiles <= 64, "one mask bit per column tile");
+  unsigned long long todo = kSimColTiles == 64 ? ~0ull : ((1ull << kSimColTiles) - 1ull);
+  if (tmax) {
+    float lmin = INFINITY;
 #pragma unroll
-  for (int pl = 0; pl < 3; pl++) bn[pl] = PB[pl * kPlane + (jt_lo * 16 + tl) * (DM / 8) + g];
-  for (int jt = jt_lo; jt < jt_hi; jt++) {
+    for (int t = 0; t < kSimRT; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) lmin = fminf(lmin, ld[t][r]);
+    const int kmin = -wave_max_i32(-f32_order_key(lmin - 1e-5f));       // wave minimum of the keys
+    const int km = lane < kSimColTiles ? tmax[(long long)item * kSimColTiles + lane] : (int)0x80000000;
+    todo &= __ballot(km >= kmin);
+  }
+  if (todo == 0ull) return;                      // (nothing buffered yet)
+  int jt = jt_lo + (int)__builtin_ctzll(todo);
+  todo &= todo - 1ull;
+#pragma unroll
+  for (int pl = 0; pl < 3; pl++) bn[pl] = PB[pl * kPlane + (jt * 16 + tl) * (DM / 8) + g];
+  for (;;) {
     bf16x8 b3[3];
 #pragma unroll
     for (int pl = 0; pl < 3; pl++) b3[pl] = bn[pl];
-    const int jn = jt + 1 < jt_hi ? jt + 1 : jt;            // one tile ahead (see k_sim_single)
+    const int jn = todo ? jt_lo + (int)__builtin_ctzll(todo) : jt;      // the next tile to look at, requested one ahead
 #pragma unroll
     for (int pl = 0; pl < 3; pl++) bn[pl] = PB[pl * kPlane + (jn * 16 + tl) * (DM / 8) + g];
 #pragma unroll
@@ -3962,6 +4005,9 @@ __global__ __launch_bounds__(64 * kSimItemWaves) void k_sim_cand3(const __bf16* 
         if (nb > (uint32_t)(kCandBuf - 256)) flush();
       }
     }
+    if (todo == 0ull) break;
+    jt = jn;
+    todo &= todo - 1ull;
   }
   flush();
 }
@@ -4164,6 +4210,8 @@ struct LoftrPipeline::Impl {
   float* cpart = nullptr;    // [max_pairs][25][1200] column-sum partials
   float* rpart = nullptr;    // [max_pairs][3][1200] row-sum partials (one per third of the columns)
   uint32_t* sim_redo = nullptr;   // [max_pairs] pairs whose single-pass sums left the f32 range
+  int* sim_tmax = nullptr;        // [max_pairs][75 items][25 column tiles] largest d per tile (k_sim_single -> k_sim_cand3); null: MSF_LOFTR_SIM_SKIP=0
+  bool sim_skip = true;      // MSF_LOFTR_SIM_SKIP=0: the candidate pass evaluates every tile (tests compare: identical lists)
   bool out_fused = true;     // MSF_LOFTR_OUT_FUSED=0: the 1 x 1 output convolution and the token kernel as two passes (tests compare: identical)
   bool attn_pair = true;     // MSF_LOFTR_ATTN_PAIR=0: one launch per encoder block (tests compare: identical results)
   bool sim_single = true;    // MSF_LOFTR_SIM_SINGLE=0: the two running-maximum passes always
@@ -4256,6 +4304,7 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
     if (const char* d = getenv("MSF_LOFTR_SIM_SINGLE")) P.sim_single = atoi(d) != 0;
     if (const char* d = getenv("MSF_LOFTR_ATTN_PAIR")) P.attn_pair = atoi(d) != 0;
     if (const char* d = getenv("MSF_LOFTR_OUT_FUSED")) P.out_fused = atoi(d) != 0;
+    if (const char* d = getenv("MSF_LOFTR_SIM_SKIP")) P.sim_skip = atoi(d) != 0;
     if (const char* d = getenv("MSF_LOFTR_SIM_FORCE_REDO")) P.sim_force_redo = atoi(d) != 0;
     if (const char* d = getenv("MSF_LOFTR_UNFUSED")) P.fuse_blocks = atoi(d) == 0;
     P.split_bf16 = !f32_convs;
@@ -4597,6 +4646,10 @@ std::string LoftrPipeline::init(const char* weights_path, int max_pairs, bool pr
     float* m = nullptr;
     LF_TRY(dalloc(&m, (size_t)max_pairs));
     P.sim_redo = reinterpret_cast<uint32_t*>(m);
+    if (P.sim_skip) {
+      LF_TRY(dalloc(&m, (size_t)max_pairs * kSimItemsPerPair * kSimColTiles));
+      P.sim_tmax = reinterpret_cast<int*>(m);
+    }
   }
   {
     float* m = nullptr;
@@ -5026,7 +5079,8 @@ hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf
     hipLaunchKernelGGL(k_pair_bound, dim3(n), dim3(256), 0, st, f0s, f1s, ts, P.gbound);
     const int n_items = n * kSimItemsPerPair;
     const dim3 gridi((n_items + kSimItemWaves - 1) / kSimItemWaves), blocki(64 * kSimItemWaves);
-    hipLaunchKernelGGL(k_sim_single, gridi, blocki, 0, st, p0, p1, ts, P.gbound, P.rpart, P.cpart, n_items);
+    hipLaunchKernelGGL(k_sim_single, gridi, blocki, 0, st, p0, p1, ts, P.gbound, P.rpart, P.cpart, n_items,
+                       sparse ? P.sim_tmax : nullptr);
     hipLaunchKernelGGL(k_sim_finish, dim3((n * NTOK + 255) / 256), dim3(256), 0, st, P.gbound, P.rstats, P.rpart, P.cstats, 2LL * NTOK,
                        P.cpart, threshold, sparse ? P.lim : nullptr, P.sim_redo, n, P.sim_force_redo ? 1 : 0);
     redo = P.sim_redo;
@@ -5046,7 +5100,7 @@ hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf
     if (single) {
       const int n_items = n * kSimItemsPerPair;
       hipLaunchKernelGGL(k_sim_cand3, dim3((n_items + kSimItemWaves - 1) / kSimItemWaves), dim3(64 * kSimItemWaves), 0, st, p0, p1, ts,
-                         P.lim, P.cand, P.cand_cnt, redo, n_items);
+                         P.lim, P.cand, P.cand_cnt, redo, n_items, P.sim_tmax);
       hipLaunchKernelGGL((k_sim_stats<true, true>), dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats, 2LL * NTOK,
                          P.lim, P.cand, P.cand_cnt, p1, p0, redo);      // flagged pairs only
     } else if (p0) hipLaunchKernelGGL((k_sim_stats<true, true>), dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats, 2LL * NTOK,

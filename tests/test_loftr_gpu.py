@@ -352,6 +352,39 @@ def test_fused_output_convolution_and_tokens_equal_the_two_kernel_tail():
         np.testing.assert_array_equal(outs[0]["conf"].view(np.uint32), outs[1]["conf"].view(np.uint32))
 
 
+def test_candidate_pass_skips_tiles_without_changing_a_list(monkeypatch):
+    """r05: the statistics pass (k_sim_single) leaves the largest dot product of every (row-tile triple, column tile) and the
+    candidate pass (k_sim_cand3) evaluates only the tiles whose maximum can reach the smallest candidate limit of their rows.
+    A skipped tile holds no candidate, so the lists are those of the pass over every tile (MSF_LOFTR_SIM_SKIP=0), pair by
+    pair, at the default threshold and at the lowest one the sparse head takes; spot-checked against the oracle."""
+    from mono_slam_framework_amd import _lib
+    from mono_slam_framework_amd.matcher import DNNFeatureMatcher
+    n = 24                                           # >= 8 pairs: the batch form of the head (three row tiles per wave)
+    A, B = synth.synth_batch(8800, n, 640, 480, mode=1)
+    A[5], B[5] = G["img0_ii"], G["img1_ii"]
+    fl = _lib.MSF_FLAG_NO_FRAME_CACHE
+    monkeypatch.setenv("MSF_LOFTR_SIM_SKIP", "0")
+    every = DNNFeatureMatcher(threshold=0.15, max_batch_pairs=n, flags=fl)
+    monkeypatch.delenv("MSF_LOFTR_SIM_SKIP")
+    skip = DNNFeatureMatcher(threshold=0.15, max_batch_pairs=n, flags=fl)
+    total = 0
+    for thr in (0.15, 0.06):
+        every.SetThreshold(thr)
+        skip.SetThreshold(thr)
+        l1 = every.match_batch(list(A), list(B), cap=8192)
+        l2 = skip.match_batch(list(A), list(B), cap=8192)
+        for i in range(n):
+            np.testing.assert_array_equal(l1[i], l2[i], err_msg="thr %g pair %d" % (thr, i))
+            total += len(l2[i])
+    assert total > 2000
+    skip.SetThreshold(0.15)
+    got = skip.match_batch(list(A), list(B), cap=8192)
+    full_ref = oracle_loftr.DNNFeatureMatcherOracle(0.15).run(A[5], B[5])["conf"]
+    _check_lists(got[5], full_ref, 0.15)
+    every.close()
+    skip.close()
+
+
 def test_paired_attention_launches_equal_one_launch_per_block():
     """r05: the two self-attention blocks of a layer pair (feat0 <- feat0, feat1 <- feat1) run as ONE launch of each
     attention kernel (12 launches per call instead of 16).  Same arithmetic, other grid: confidences, features and the
