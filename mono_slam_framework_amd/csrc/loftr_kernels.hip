@@ -3724,15 +3724,12 @@ __global__ __launch_bounds__(64 * kSimWaves) void k_sim_stats3(const __bf16* __r
 // flagged pair is redone by the running-maximum passes (which skip every other pair).  Sums in a fixed order: a wave
 // owns three row tiles over a third of the column tiles, leaves its row sums in rpart[pair][third][1200] and its column
 // partials in cpart[pair][triple 0..24][1200]; k_sim_finish adds the 3 and the 25 in order.  Deterministic, no atomics.
-// r05: k_sim_single leaves, per item and column tile, the largest dot product d of the tile's 48 x 16 entries (as an
-// order-preserving integer key); k_sim_cand3 -- the same items over the same tiles -- then evaluates only the tiles whose
-// maximum can reach the smallest candidate limit of its rows.  A candidate needs d >= ld(row); the two kernels sum the same
-// six products in another order, so their d differ by a few ulp: a tile is skipped only if its maximum is more than 1e-5
-// below the smallest limit.  With ~100 matches per pair four tiles in five hold no candidate.
-__device__ __forceinline__ int f32_order_key(float v) {      // a < b  <=>  key(a) < key(b) as signed integers
-  const int b = __float_as_int(v);
-  return b ^ ((b >> 31) & 0x7fffffff);
-}
+// r05: k_sim_single leaves, per item and column tile, the largest entry of the tile's 48 x 16 -- as the exp(s - G) it forms
+// anyway: positive floats, so integer maxima on their bits --; k_sim_cand3 -- the same items over the same tiles -- then
+// evaluates only the tiles whose maximum can reach the smallest candidate limit of its rows.  A candidate needs
+// d >= ld(row); the two kernels sum the same six products in another order, so their d differ by a few ulp: a tile is
+// skipped only if its maximum is below what d = smallest limit - 1e-5 would give (1.4e-4 relative; v_exp_f32 is good to
+// 1e-7).  An exp that underflows to 0 makes every tile pass.  With ~100 matches per pair four tiles in five hold no candidate.
 __device__ __forceinline__ int wave_max_i32(int v) {
   v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));     // quad_perm [1,0,3,2]: lane ^ 1
   v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]: lane ^ 2
@@ -3825,7 +3822,7 @@ __global__ __launch_bounds__(64 * kSimItemWaves) void k_sim_single(const __bf16*
 #pragma unroll
     for (int pl = 0; pl < 3; pl++) bn[pl] = PB[pl * kPlane + (jn * 16 + tl) * (DM / 8) + g];
     float col = 0.f;
-    float dmax = -INFINITY;
+    int emax = 0;                                 // largest exp(s - G) of the tile: positive floats order like their bits
 #pragma unroll
     for (int t = 0; t < kSimRT; t++) {
       f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -3840,11 +3837,11 @@ __global__ __launch_bounds__(64 * kSimItemWaves) void k_sim_single(const __bf16*
         const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(d[r], c1, c0));
         rs[t][r] += e;
         col += e;
+        emax = max(emax, __float_as_int(e));
       }
-      dmax = fmaxf(dmax, fmaxf(fmaxf(d[0], d[1]), fmaxf(d[2], d[3])));
     }
-    if (tmax) {                                   // (uniform) the tile's largest d, for k_sim_cand3's skip
-      const int km = wave_max_i32(f32_order_key(dmax));
+    if (tmax) {                                   // (uniform) the tile's largest entry, for k_sim_cand3's skip
+      const int km = wave_max_i32(emax);
       if (lane == 0) tmax[(long long)item * kSimColTiles + (jt - jt_lo)] = km;
     }
     // this lane's column jt * 16 + tl over the 12 rows it holds; the other three lane groups hold the other rows
@@ -3912,7 +3909,7 @@ __global__ __launch_bounds__(64 * kSimItemWaves) void k_sim_cand3(const __bf16* 
                                                               long long pair_stride, const float* __restrict__ lim,
                                                               SimCand* __restrict__ cand, uint32_t* __restrict__ cand_cnt,
                                                               const uint32_t* __restrict__ skip_if, int n_items,
-                                                              const int* __restrict__ tmax) {
+                                                              const int* __restrict__ tmax, const float* __restrict__ gbound) {
   __shared__ SimCand buf_s[kSimItemWaves][kCandBuf];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tl = lane & 15, g = lane >> 4;
   const int item = blockIdx.x * kSimItemWaves + wave;
@@ -3961,8 +3958,10 @@ __global__ __launch_bounds__(64 * kSimItemWaves) void k_sim_cand3(const __bf16* 
     for (int t = 0; t < kSimRT; t++)
 #pragma unroll
       for (int r = 0; r < 4; r++) lmin = fminf(lmin, ld[t][r]);
-    const int kmin = -wave_max_i32(-f32_order_key(lmin - 1e-5f));       // wave minimum of the keys
-    const int km = lane < kSimColTiles ? tmax[(long long)item * kSimColTiles + lane] : (int)0x80000000;
+    // k_sim_single's measure of an entry: exp(d / 0.1 - G) as 2^(d c1 + c0), monotonic in d
+    const float emin = __builtin_amdgcn_exp2f(__builtin_fmaf(lmin - 1e-5f, 14.4269504089f, -gbound[pair] * 1.44269504089f));
+    const int kmin = -wave_max_i32(-__float_as_int(emin));               // wave minimum (positive floats order like their bits)
+    const int km = lane < kSimColTiles ? tmax[(long long)item * kSimColTiles + lane] : -1;
     todo &= __ballot(km >= kmin);
   }
   if (todo == 0ull) return;                      // (nothing buffered yet)
@@ -5100,7 +5099,7 @@ hipError_t LoftrPipeline::transformer_and_head(int n_pairs, float threshold, msf
     if (single) {
       const int n_items = n * kSimItemsPerPair;
       hipLaunchKernelGGL(k_sim_cand3, dim3((n_items + kSimItemWaves - 1) / kSimItemWaves), dim3(64 * kSimItemWaves), 0, st, p0, p1, ts,
-                         P.lim, P.cand, P.cand_cnt, redo, n_items, P.sim_tmax);
+                         P.lim, P.cand, P.cand_cnt, redo, n_items, P.sim_tmax, P.gbound);
       hipLaunchKernelGGL((k_sim_stats<true, true>), dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats, 2LL * NTOK,
                          P.lim, P.cand, P.cand_cnt, p1, p0, redo);      // flagged pairs only
     } else if (p0) hipLaunchKernelGGL((k_sim_stats<true, true>), dim3(head_blocks, n), dim3(256), 0, st, f1s, f0s, ts, P.cstats, 2LL * NTOK,
